@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def golden_models(name):
+    """Yield per-model dicts of a synthetic golden file written by make_golden.synthetic_case."""
+    g = load_golden(name)
+    for i in range(int(g["nmodels"])):
+        pre = f"m{i}_"
+        yield i, {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+
+
+SYNTH_GOLDENS = ["c2_small.npz", "c2_T1000.npz", "c4_missing.npz", "edge_cases.npz", "n17_k3.npz"]
+
+
+@pytest.fixture(scope="session")
+def g1():
+    return load_golden("g1_real.npz")
+
+
+@pytest.fixture(scope="session")
+def g2():
+    return load_golden("g2_seeded.npz")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))

@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory from the *reference itself*.
+
+Run ONCE in the build container (where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+The reference package is imported unmodified through ``_refshim`` (pastas stub,
+un-jitted numba source).  For every case both reference engines are run --
+``seqkalmanfilter`` (the numba source, metran/kalmanfilter.py:236-400) and
+``seqkalmanfilter_np`` (metran/kalmanfilter.py:122-233) -- followed by
+``kalmansmoother`` (metran/kalmanfilter.py:403-476), ``SPKalmanFilter.get_mle``
+(:550-567), ``simulate`` (:569-603) and ``decompose`` (:605-644).
+
+The fixtures are what pins ``oracle/`` (and through it the HIP kernels) to the
+reference; the GPU box has no /root/reference, so nothing at test time reads it.
+"""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _refshim  # noqa: E402
+
+metran = _refshim.install()
+import metran.kalmanfilter as kfm  # noqa: E402
+
+from metran_amd.params import observation_matrix, phi_q_from_alpha  # noqa: E402
+from metran_amd.synthetic import make_dfm  # noqa: E402
+
+
+def run_reference(obs, phi, q, loadings, r=None, warmup=1, engine="numba-source"):
+    """obs [T,N] NaN=missing -> dict of every array the reference path produces."""
+    T, N = obs.shape
+    n = phi.shape[0]
+    kf = kfm.SPKalmanFilter(engine="numpy")
+    kf.filtermethod = kfm.seqkalmanfilter if engine == "numba-source" else kfm.seqkalmanfilter_np
+    kf.set_observations(pd.DataFrame(obs))
+    Z = observation_matrix(loadings)
+    R = np.zeros(N) if r is None else np.asarray(r, float)
+    kf.set_matrices(np.diag(phi), np.diag(q), Z, R)
+    kf.run_smoother()
+    out = dict(
+        sigmas=np.asarray(kf.sigmas, float),
+        detfs=np.asarray(kf.detfs, float),
+        sigmacount=np.int64(len(kf.sigmas)),
+        count=kf.observation_count.copy(),
+        mle=np.float64(kf.get_mle(warmup=warmup)),
+        F=kf.filtered_state_means.copy(),
+        Pf=kf.filtered_state_covariances.copy(),
+        Xp=kf.predicted_state_means.copy(),
+        Pp=kf.predicted_state_covariances.copy(),
+        S=kf.smoothed_state_means.copy(),
+        Ps=kf.smoothed_state_covariances.copy(),
+    )
+    return kf, out
+
+
+def synthetic_case(fname, N, K, T, seed, models, missing=0.0, first_steps=None, cov_every=1,
+                   extra_nan=None):
+    data = {}
+    for i, b in enumerate(models):
+        fs = "observed" if first_steps is None else first_steps[i]
+        y, alpha, loadings, phi, q = make_dfm(N, K, T, seed, b, missing, fs)
+        if extra_nan is not None:
+            extra_nan(i, y)
+        _, a3 = run_reference(y, phi, q, loadings, engine="numba-source")
+        _, a4 = run_reference(y, phi, q, loadings, engine="numpy")
+        # both reference engines agree: record how closely
+        data[f"m{i}_mle_np_engine"] = a4["mle"]
+        assert abs(a3["mle"] - a4["mle"]) <= 1e-12 * abs(a3["mle"]), (a3["mle"], a4["mle"])
+        tsel = np.unique(np.r_[np.arange(0, T, cov_every), T - 1])
+        data[f"m{i}_obs"] = y
+        data[f"m{i}_alpha"] = alpha
+        data[f"m{i}_loadings"] = loadings
+        data[f"m{i}_phi"] = phi
+        data[f"m{i}_q"] = q
+        data[f"m{i}_tsel"] = tsel
+        for k in ("sigmas", "detfs", "sigmacount", "count", "mle", "F", "Xp", "S"):
+            data[f"m{i}_{k}"] = a3[k]
+        for k in ("Pf", "Pp", "Ps"):
+            data[f"m{i}_{k}"] = a3[k][tsel]
+    data["nmodels"] = np.int64(len(models))
+    np.savez_compressed(os.path.join(HERE, fname), **data)
+    print(fname, {k: v.shape for k, v in data.items() if k.startswith("m0_")})
+
+
+def g1_real():
+    """examples/data 5-series / 1-factor model."""
+    d = os.path.join(_refshim.REFERENCE_ROOT, "examples", "data")
+    series = []
+    for i in range(1, 6):
+        s = pd.read_csv(f"{d}/B21B021400{i}_res.csv", index_col=0, parse_dates=True).squeeze()
+        s.name = f"B21B021400{i}"
+        series.append(s)
+    mt = metran.Metran(series, name="B21B0214")
+    mt.get_factors(mt.oseries)
+    mt._init_kalmanfilter(mt.oseries, engine="numpy")
+    mt.set_init_parameters()
+    mt.kf.filtermethod = kfm.seqkalmanfilter  # numba source, un-jitted
+    astar = np.array([5.501017, 13.560042, 4.682870, 11.381674, 13.140605, 22.980925])
+    a10 = np.full(6, 10.0)
+    mle_star = mt.get_mle(astar)
+    mle_10 = mt.get_mle(a10)
+    mt.kf.filtermethod = kfm.seqkalmanfilter_np
+    mle_star_np = mt.get_mle(astar)
+    mt.kf.filtermethod = kfm.seqkalmanfilter
+    p = pd.Series(astar, index=mt.parameters.index)
+    mt.parameters["optimal"] = astar
+    Phi, Q, Z, R = mt._get_matrices(p)
+    mt._run_kalman("smoother", p=p)
+    kf = mt.kf
+    T = kf.observations.shape[0]
+    tsel = np.unique(np.r_[np.arange(0, 25), np.arange(25, T, 40), np.arange(T - 25, T)])
+    Zs = mt.get_scaled_observation_matrix(p=p)
+    sim_m, sim_v = kf.simulate(Zs, method="smoother")
+    simf_m, simf_v = kf.simulate(Zs, method="filter")
+    sdf_m, cdf_m = kf.decompose(Zs, method="smoother")
+    sim5 = mt.get_simulation("B21B0214005", alpha=0.05)
+    dec1 = mt.decompose_simulation("B21B0214001")
+    smeans = mt.get_state_means()
+    data = dict(
+        obs=mt.oseries.values.astype(float),  # standardised, NaN = missing
+        index_ns=mt.oseries.index.values.astype("datetime64[ns]").astype(np.int64),
+        oseries_std=mt.oseries_std,
+        oseries_mean=mt.oseries_mean,
+        loadings=mt.factors,
+        alpha_star=astar,
+        alpha_10=a10,
+        phi=np.diag(Phi).copy(),
+        q=np.diag(Q).copy(),
+        Z=Z,
+        Z_scaled=Zs,
+        mle_star=np.float64(mle_star),
+        mle_star_np_engine=np.float64(mle_star_np),
+        mle_10=np.float64(mle_10),
+        sigmas=np.asarray(kf.sigmas),
+        detfs=np.asarray(kf.detfs),
+        count=kf.observation_count,
+        tsel=tsel,
+        F=kf.filtered_state_means,
+        Xp=kf.predicted_state_means,
+        S=kf.smoothed_state_means,
+        Pf=kf.filtered_state_covariances[tsel],
+        Pp=kf.predicted_state_covariances[tsel],
+        Ps=kf.smoothed_state_covariances[tsel],
+        sim_means=np.asarray(sim_m),
+        sim_vars=np.asarray(sim_v),
+        simf_means=np.asarray(simf_m)[tsel],
+        simf_vars=np.asarray(simf_v)[tsel],
+        sdf_means=np.asarray(sdf_m)[tsel],
+        cdf_means=np.asarray(cdf_m)[:, tsel],
+        get_simulation_005=sim5.values[:50],
+        decompose_001=dec1.values[:50],
+        state_means_head=smeans.values[:5],
+        state_means_tail=smeans.values[-5:],
+    )
+    # masked re-smooth (examples/metran_practical_example.ipynb cell 31-33, tests/test_metran.py:32-40)
+    oseries = mt.get_observations()
+    mask = (0 * oseries).astype(bool)
+    mask.loc["1997-8-28", "B21B0214005"] = True
+    mt.mask_observations(mask)
+    simm = mt.get_simulation("B21B0214005", alpha=None)
+    # NB (0 * oseries).astype(bool) is True wherever oseries is NaN; the one *new* mask is the date
+    data["mask_t"] = np.int64(oseries.index.get_loc(pd.Timestamp("1997-08-28")))
+    data["masked_sim_005"] = simm.values
+    data["masked_mle_star"] = np.float64(mt.get_mle(astar))
+    mt.unmask_observations()
+    np.savez_compressed(os.path.join(HERE, "g1_real.npz"), **data)
+    print("g1_real", mle_star, mle_star_np, mle_10, data["masked_mle_star"])
+
+
+def g2_seeded():
+    """examples/dynamic_factor_model.ipynb cell 7: seeded 2-series synthetic."""
+    np.random.seed(20210505)
+    mean = np.zeros(3)
+    scale = [1, 0.6, 2]
+    noise = np.random.multivariate_normal(mean, np.diag(np.square(scale)), 2001)
+    phi = np.array([0.80, 0.95, 0.90])
+    a = np.zeros_like(noise)
+    for i in range(1, noise.shape[0]):
+        a[i] = noise[i] + np.multiply(a[i - 1], phi)
+    s1 = np.add(a[1:, 0], a[1:, 2])
+    s2 = np.add(a[1:, 1], a[1:, 2])
+    s = pd.DataFrame(
+        data=np.array([s1, s2]).T,
+        index=pd.date_range(start="1-1-2000", periods=2000),
+        columns=["series 1", "series 2"],
+    )
+    mt = metran.Metran(s)
+    mt.get_factors(mt.oseries)
+    mt._init_kalmanfilter(mt.oseries, engine="numpy")
+    mt.set_init_parameters()
+    mt.kf.filtermethod = kfm.seqkalmanfilter
+    a10 = np.full(3, 10.0)
+    mle = mt.get_mle(a10)
+    p = pd.Series(a10, index=mt.parameters.index)
+    Phi, Q, Z, R = mt._get_matrices(p)
+    mt._run_kalman("smoother", p=p)
+    kf = mt.kf
+    tsel = np.arange(0, 2000, 50)
+    np.savez_compressed(
+        os.path.join(HERE, "g2_seeded.npz"),
+        obs=mt.oseries.values.astype(float),
+        loadings=mt.factors,
+        alpha=a10,
+        phi=np.diag(Phi).copy(),
+        q=np.diag(Q).copy(),
+        mle=np.float64(mle),
+        sigmas=np.asarray(kf.sigmas),
+        detfs=np.asarray(kf.detfs),
+        S=kf.smoothed_state_means,
+        F=kf.filtered_state_means,
+        tsel=tsel,
+        Ps=kf.smoothed_state_covariances[tsel],
+        Pf=kf.filtered_state_covariances[tsel],
+    )
+    print("g2_seeded mle", mle, "loadings", mt.factors.ravel())
+
+
+def edge_nan(i, y):
+    # model 0: series 1 never observed; model 1: a run of fully-empty steps and an inf
+    if i == 0:
+        y[:, 1] = np.nan
+    elif i == 1:
+        y[3:7, :] = np.nan
+        y[9, 0] = np.inf
+    elif i == 2:
+        y[:, :] = np.nan
+        y[5, 2] = 0.25  # single observation in the whole record
+
+
+if __name__ == "__main__":
+    g1_real()
+    g2_seeded()
+    # C2 shape (8 series / 2 factors), small T: every array, every step
+    synthetic_case("c2_small.npz", 8, 2, 48, seed=2000, models=[0, 1, 2])
+    # C2 shape at full T=1000: means everywhere, covariances every 50 steps
+    synthetic_case("c2_T1000.npz", 8, 2, 1000, seed=2000, models=[0, 1], cov_every=50)
+    # C4 shape (32 series / 4 factors) with 30 % missing; model 1 has an EMPTY first step
+    synthetic_case("c4_missing.npz", 32, 4, 36, seed=4000, models=[0, 1], missing=0.3,
+                   first_steps=["observed", "empty"], cov_every=5)
+    # small odd shapes / degenerate missingness
+    synthetic_case("edge_cases.npz", 3, 1, 14, seed=77, models=[0, 1, 2], missing=0.25,
+                   first_steps=["observed", "empty", "random"], extra_nan=edge_nan)
+    synthetic_case("n17_k3.npz", 14, 3, 30, seed=1703, models=[0], missing=0.1)

@@ -1,0 +1,159 @@
+"""Pins oracle/ (the CPU restatement) to the reference.
+
+The fixtures in tests/golden/*.npz were produced by tests/golden/make_golden.py from the
+unmodified reference package (/root/reference/metran/kalmanfilter.py), so every assertion
+here is oracle == reference.  The stored-notebook known-answers of BASELINE.md section 2
+are asserted as literals.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import SYNTH_GOLDENS, golden_models, rel_err
+from metran_amd.params import observation_matrix, phi_q_from_alpha
+
+
+def _dense(m):
+    n = m["phi"].shape[0]
+    N = m["obs"].shape[1]
+    return np.diag(m["phi"]), np.diag(m["q"]), observation_matrix(m["loadings"]), np.zeros(N), n
+
+
+def _run_oracle(m):
+    Phi, Q, Z, R, n = _dense(m)
+    o, oi, oc = oracle.set_observations(m["obs"])
+    sg, df, sc, F, Pf, Xp, Pp = oracle.seqkalmanfilter(o, Phi, Q, Z, R, oi, oc, np.zeros(n), np.eye(n))
+    S, Ps = oracle.kalmansmoother(F, Pf, Xp, Pp, Phi)
+    mle = oracle.get_mle(sg[:sc], df[:sc], oc, warmup=1)
+    return dict(sigmas=sg, detfs=df, sigmacount=sc, count=oc, F=F, Pf=Pf, Xp=Xp, Pp=Pp, S=S, Ps=Ps, mle=mle)
+
+
+@pytest.mark.parametrize("fname", SYNTH_GOLDENS)
+def test_filter_bit_level(fname):
+    """seqkalmanfilter restatement: same op order -> (near) bit-identical to the reference."""
+    for i, m in golden_models(fname):
+        r = _run_oracle(m)
+        ts = m["tsel"]
+        assert r["sigmacount"] == int(m["sigmacount"])
+        np.testing.assert_array_equal(r["count"], m["count"])
+        # everything except log() is the same IEEE operation sequence
+        np.testing.assert_array_equal(r["F"], m["F"])
+        np.testing.assert_array_equal(r["Xp"], m["Xp"])
+        np.testing.assert_array_equal(r["Pf"][ts], m["Pf"])
+        np.testing.assert_array_equal(r["Pp"][ts], m["Pp"])
+        # innovation**2 is libm pow() un-jitted but x*x under numba (and here): <= 1 ulp per term
+        sc = r["sigmacount"]  # the golden arrays are already sliced [:sigmacount] (kalmanfilter.py:773-774)
+        np.testing.assert_allclose(r["sigmas"][:sc], m["sigmas"], rtol=4e-16 * m["obs"].shape[1], atol=0)
+        np.testing.assert_allclose(r["detfs"][:sc], m["detfs"], rtol=0, atol=1e-13)  # libm log ulp
+        assert not r["sigmas"][sc:].any() and not r["detfs"][sc:].any()
+        assert abs(r["mle"] - float(m["mle"])) <= 1e-13 * abs(float(m["mle"]))
+
+
+@pytest.mark.parametrize("fname", SYNTH_GOLDENS)
+def test_smoother(fname):
+    """kalmansmoother restatement (Jacobi-eigen pinv vs LAPACK-SVD pinv)."""
+    for i, m in golden_models(fname):
+        r = _run_oracle(m)
+        ts = m["tsel"]
+        assert rel_err(r["S"], m["S"]) < 1e-11
+        assert rel_err(r["Ps"][ts], m["Ps"]) < 1e-11
+
+
+def test_g1_known_answers(g1):
+    """examples/data, 5 series / 1 factor / T=6255."""
+    phi, q = phi_q_from_alpha(g1["alpha_star"], g1["loadings"])
+    np.testing.assert_allclose(phi, g1["phi"], rtol=1e-15)
+    np.testing.assert_allclose(q, g1["q"], rtol=1e-14)
+    # notebook "State parameters" table, examples/metran_practical_example.ipynb:179-184
+    np.testing.assert_allclose(phi, [0.833781, 0.928908, 0.807716, 0.915889, 0.926724, 0.957419], atol=5e-7)
+    np.testing.assert_allclose(q, [0.080429, 0.017023, 0.023102, 0.013316, 0.026607, 0.083349], atol=5e-7)
+    r = oracle.dfm_batch(g1["obs"][None], phi[None], q[None], g1["loadings"][None])
+    assert abs(r["mle"][0] - 2332.327069381027) < 1e-9          # reproduced reference value
+    assert round(r["mle"][0], 2) == 2332.33                      # stored: ipynb:142
+    assert abs(r["mle"][0] - float(g1["mle_star"])) <= 1e-12 * 2332.0
+    np.testing.assert_array_equal(r["sigmacount"], [len(g1["sigmas"])])
+    sc = len(g1["sigmas"])
+    np.testing.assert_allclose(r["sigmas"][0, :sc], g1["sigmas"], rtol=2e-15, atol=0)
+    np.testing.assert_allclose(r["detfs"][0, :sc], g1["detfs"], atol=1e-14, rtol=0)
+    np.testing.assert_array_equal(r["F"][0], g1["F"])
+    ts = g1["tsel"]
+    np.testing.assert_array_equal(r["Pf"][0][ts], g1["Pf"])
+    assert rel_err(r["S"][0], g1["S"]) < 1e-11
+    assert rel_err(r["Ps"][0][ts], g1["Ps"]) < 1e-10
+    # stored smoothed state means, examples/metran_practical_example.ipynb:395-427 (6 dp)
+    head = np.array([[0.226549, 0.021665, 0.028548, 0.026005, 0.153683, 0.809228],
+                     [0.182900, 0.013039, 0.026154, 0.022935, 0.149910, 0.790042]])
+    tail = np.array([[1.068061, -0.511373, -0.025137, -0.066328, 0.143722, -0.823190]])
+    np.testing.assert_allclose(r["S"][0][:2], head, atol=6e-7)
+    np.testing.assert_allclose(r["S"][0][-1:], tail, atol=6e-7)
+    # alpha = 10 everywhere (G1f)
+    phi10, q10 = phi_q_from_alpha(g1["alpha_10"], g1["loadings"])
+    r10 = oracle.dfm_batch(g1["obs"][None], phi10[None], q10[None], g1["loadings"][None], outputs="mle",
+                           smooth=False)
+    assert abs(r10["mle"][0] - 2384.792799342231) < 1e-9
+
+
+def test_g1_projection(g1):
+    """simulate / decompose (kalmanfilter.py:569-644) incl. stored get_simulation rows."""
+    phi, q = g1["phi"], g1["q"]
+    r = oracle.dfm_batch(g1["obs"][None], phi[None], q[None], g1["loadings"][None])
+    sm, sv = oracle.simulate(g1["Z_scaled"], r["S"][0], r["Ps"][0])
+    assert rel_err(sm, g1["sim_means"]) < 1e-11
+    assert np.max(np.abs(sv - g1["sim_vars"])) < 1e-10
+    sdf, cdf = oracle.decompose(g1["Z_scaled"], r["S"][0])
+    ts = g1["tsel"]
+    assert rel_err(sdf[ts], g1["sdf_means"]) < 1e-11
+    assert rel_err(cdf[:, ts], g1["cdf_means"]) < 1e-11
+    # stored: get_simulated_means().head(), examples/metran_practical_example.ipynb cell 15
+    means = sm + g1["oseries_mean"]
+    np.testing.assert_allclose(means[1], [5.094121, 4.132049, 4.500647, 4.514891, 5.348733], atol=6e-7)
+    # stored get_simulation("B21B0214005") rows (cell 17): mean / lower / upper at 1988-10-15
+    from scipy.stats import norm
+    z = norm.ppf(0.975)
+    iv = z * np.sqrt(sv[:, 4])
+    np.testing.assert_allclose([means[1, 4], means[1, 4] - iv[1], means[1, 4] + iv[1]],
+                               [5.348733, 1.669956, 9.027510], atol=6e-6)
+    np.testing.assert_allclose(np.c_[means[:50, 4], means[:50, 4] - iv[:50], means[:50, 4] + iv[:50]],
+                               g1["get_simulation_005"], atol=1e-9)
+
+
+def test_g1_masked(g1):
+    """mask_observations -> re-smooth (metran/metran.py:464-495; tests/test_metran.py:32-40)."""
+    obs = g1["obs"].copy()
+    obs[int(g1["mask_t"]), 4] = np.nan
+    r = oracle.dfm_batch(obs[None], g1["phi"][None], g1["q"][None], g1["loadings"][None])
+    assert abs(r["mle"][0] - float(g1["masked_mle_star"])) <= 1e-12 * abs(float(g1["masked_mle_star"]))
+    sm, _ = oracle.simulate(g1["Z_scaled"], r["S"][0], r["Ps"][0])
+    np.testing.assert_allclose(sm[:, 4] + g1["oseries_mean"][4], g1["masked_sim_005"].ravel(), atol=1e-9)
+
+
+def test_g2_known_answer(g2):
+    """seeded 2-series synthetic, alpha=(10,10,10) -> obj 2431.34."""
+    np.testing.assert_allclose(g2["loadings"].ravel(), [0.93540765, 0.93540765], atol=5e-9)
+    phi, q = phi_q_from_alpha(g2["alpha"], g2["loadings"])
+    np.testing.assert_allclose(phi, [0.904837] * 3, atol=5e-7)      # ipynb:480-482
+    np.testing.assert_allclose(q, [0.022661, 0.022661, 0.181269], atol=5e-7)
+    r = oracle.dfm_batch(g2["obs"][None], phi[None], q[None], g2["loadings"][None])
+    assert abs(r["mle"][0] - 2431.3389452203646) < 1e-9
+    assert round(r["mle"][0], 2) == 2431.34
+    assert rel_err(r["S"][0], g2["S"]) < 1e-11
+    assert rel_err(r["Ps"][0][g2["tsel"]], g2["Ps"]) < 1e-10
+
+
+def test_set_observations_quirks():
+    """NaN and inf are missing; -1e10 is dropped by the reference's nonzero() trick (:666-667)."""
+    y = np.array([[1.0, np.nan, 3.0], [np.inf, -1e10, 0.0], [np.nan, np.nan, np.nan]])
+    o, oi, oc = oracle.set_observations(y)
+    np.testing.assert_array_equal(oc, [2, 1, 0])
+    np.testing.assert_array_equal(oi, [[0, 2, 0], [2, 0, 0], [0, 0, 0]])
+    np.testing.assert_array_equal(o, [[1, 0, 3], [0, 0, 0], [0, 0, 0]])
+
+
+def test_mle_warmup_indexing_quirk():
+    """get_mle drops the first COMPRESSED sigma/detf but the first TIME STEP's count (:563-565)."""
+    sig = np.array([1.0, 2.0, 3.0])
+    det = np.array([0.1, 0.2, 0.3])
+    cnt = np.array([0, 2, 0, 1, 3])  # step 0 empty -> compressed index 0 is time step 1
+    got = oracle.get_mle(sig, det, cnt, warmup=1)
+    want = (2 + 0 + 1 + 3) * np.log(2 * np.pi) + (0.2 + 0.3) + (2.0 + 3.0)
+    assert abs(got - want) < 1e-12
