@@ -1,0 +1,167 @@
+/*
+ * metran_hip.h -- C ABI of libmetran_hip.so: the MI355X (gfx950) batched Kalman filter,
+ * -2 log-likelihood and RTS smoother for Metran's dynamic-factor model.
+ *
+ * This is the drop-in boundary for the hot path of pastas/metran.
+ * The reference has no FFI of its own: its "engine" is a Python callable
+ *     SPKalmanFilter.filtermethod(obs, Phi, Q, Z, R, idx, count, x0, P0) -> 7-tuple
+ *         /root/reference/metran/kalmanfilter.py:494-504 (binding), :761-771 (call site)
+ *     kalmansmoother(F, Pf, Xp, Pp, Phi) -> (S, Ps)
+ *         metran/kalmanfilter.py:685-691 (call site), :403-476 (definition)
+ *     SPKalmanFilter.get_mle(warmup)            metran/kalmanfilter.py:550-567
+ *     SPKalmanFilter.simulate / decompose       metran/kalmanfilter.py:569-644
+ *     Metran._get_matrices(p)                   metran/metran.py:246-416
+ * Each entry point below names the reference function it replaces.  Python binds this
+ * header with ctypes (metran_amd/_lib.py); INTEGRATION.md shows the stub a Metran
+ * maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ exceptions cross the ABI.
+ *   - every function returns 0 (MK_OK) or a negative mk_status; mk_last_error() gives text.
+ *   - "d_" pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()); "h_" are host.
+ *   - all launches are asynchronous on the context's stream (mk_set_stream / mk_sync).
+ *   - layouts are the reference's, with a leading batch axis, row-major double:
+ *       obs [R,T,N] (NaN or +-inf = missing), phi/q [B,n], loadings [R,N,K], obsvar [R,N],
+ *       F/Xp/S [B,T,n], Pf/Pp/Ps [B,T,n,n], sigmas/detfs [B,T], n = N + K.
+ *     B = number of filter instances, R = number of observation records; instance i reads
+ *     record i % R (so the P+1 finite-difference evaluations of one model, or S parameter sets
+ *     per model, share one uploaded observation record).
+ *   - state order: N specific factors then K common factors (metran/metran.py:283-290).
+ *   - the model is Metran's: Phi = diag(phi), Q = diag(q), Z = [I_N | loadings], R = diag(obsvar).
+ */
+#ifndef METRAN_HIP_H
+#define METRAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_API __attribute__((visibility("default")))
+#define MK_ABI_VERSION 1
+
+typedef enum mk_status {
+    MK_OK = 0,
+    MK_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, ...) */
+    MK_ERR_SHAPE = -2,       /* (N,K) has no compiled kernel (see mk_shape_supported) */
+    MK_ERR_HIP = -3,         /* a HIP runtime call failed */
+    MK_ERR_NO_DEVICE = -4,   /* no gfx950 device visible */
+    MK_ERR_ALLOC = -5
+} mk_status;
+
+/* per-instance status bits written to mk_outputs.d_status */
+#define MK_FLAG_NONPOSITIVE_F 1u /* an innovation variance f <= 0 was met in the filter    */
+#define MK_FLAG_NOT_SPD 2u       /* predicted covariance not numerically SPD in the smoother
+                                    (reference would take the pinv branch, kalmanfilter.py:455) */
+
+typedef struct mk_context mk_context; /* opaque; one per (process, device) */
+
+/* Inputs of one batched evaluation.  Replaces the 9 positional arguments of
+ * seqkalmanfilter (metran/kalmanfilter.py:243-253) for B models at once. */
+typedef struct mk_problem {
+    int64_t n_instances; /* B */
+    int64_t n_records;   /* R, 1 <= R <= B */
+    int64_t T, N, K;
+    int64_t warmup;            /* get_mle(warmup), metran/kalmanfilter.py:550; Metran uses 1 */
+    const double *d_obs;       /* [R,T,N]  observations, NaN/inf = missing (kalmanfilter.py:657) */
+    const double *d_phi;       /* [B,n]    diag of transition_matrix      (metran.py:283-290) */
+    const double *d_q;         /* [B,n]    diag of transition_covariance  (metran.py:310-322) */
+    const double *d_loadings;  /* [R,N,K]  observation_matrix[:, N:]      (metran.py:365-370) */
+    const double *d_obsvar;    /* [R,N] or NULL = zeros                   (metran.py:382-384) */
+    const double *d_x0;        /* [B,n] or NULL = zeros       (kalmanfilter.py:747-748) */
+    const double *d_P0;        /* [B,n,n] or NULL = identity  (kalmanfilter.py:749-750) */
+} mk_problem;
+
+/* Outputs; any pointer may be NULL (that output is skipped and costs no HBM traffic).
+ * Replaces the returned 7-tuple of seqkalmanfilter (kalmanfilter.py:392-400), the 2-tuple of
+ * kalmansmoother (:476) and get_mle (:566). */
+typedef struct mk_outputs {
+    double *d_mle;         /* [B]   -2 log L with warm-up skip                  (:563-566) */
+    double *d_sigmas;      /* [B,T] compressed, zero-filled tail                (:380-382) */
+    double *d_detfs;       /* [B,T] compressed, zero-filled tail                           */
+    int64_t *d_sigmacount; /* [B]                                                          */
+    double *d_F;           /* [B,T,n]   filtered_state_means                    (:389)     */
+    double *d_Pf;          /* [B,T,n,n] filtered_state_covariances              (:390)     */
+    double *d_Xp;          /* [B,T,n]   predicted_state_means                   (:332)     */
+    double *d_Pp;          /* [B,T,n,n] predicted_state_covariances             (:333)     */
+    double *d_S;           /* [B,T,n]   smoothed_state_means                    (:461-464) */
+    double *d_Ps;          /* [B,T,n,n] smoothed_state_covariances              (:465-474) */
+    uint32_t *d_status;    /* [B] MK_FLAG_* bits, or NULL                                  */
+} mk_outputs;
+
+/* ---- library / context ------------------------------------------------------------------ */
+MK_API int mk_abi_version(void);
+MK_API const char *mk_last_error(void);
+MK_API int mk_device_count(int *count);
+MK_API int mk_create(int device, mk_context **ctx);
+MK_API int mk_destroy(mk_context *ctx);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
+MK_API int mk_set_stream(mk_context *ctx, void *hip_stream);
+MK_API int mk_sync(mk_context *ctx);
+/* 1 if a kernel for (N,K) is compiled into the library. */
+MK_API int mk_shape_supported(int64_t N, int64_t K);
+/* Writes up to `cap` supported (N,K) pairs into shapes[2*i], shapes[2*i+1]; returns the count. */
+MK_API int mk_supported_shapes(int64_t *shapes, int cap);
+
+/* ---- device memory helpers (for hosts without torch) -------------------------------------- */
+MK_API int mk_malloc(mk_context *ctx, size_t bytes, void **d_ptr);
+MK_API int mk_free(mk_context *ctx, void *d_ptr);
+MK_API int mk_memcpy_h2d(mk_context *ctx, void *d_dst, const void *h_src, size_t bytes);
+MK_API int mk_memcpy_d2h(mk_context *ctx, void *h_dst, const void *d_src, size_t bytes);
+MK_API int mk_memset(mk_context *ctx, void *d_dst, int value, size_t bytes);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* Metran._get_matrices restricted to the diagonals (metran/metran.py:246-322):
+ *   phi = exp(-dt/alpha);  q_i = (1-phi_i^2)(1 - sum_k loadings[i,k]^2) for i<N, 1-phi_i^2 else. */
+MK_API int mk_params_from_alpha(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K,
+                                const double *d_alpha /* [B,n] */,
+                                const double *d_loadings /* [R,N,K] */, double dt,
+                                double *d_phi /* [B,n] */, double *d_q /* [B,n] */);
+
+/* seqkalmanfilter + get_mle for B instances (kalmanfilter.py:236-400, 550-567).
+ * Uses d_mle, d_sigmas, d_detfs, d_sigmacount, d_F, d_Pf, d_Xp, d_Pp, d_status of `out`. */
+MK_API int mk_filter(mk_context *ctx, const mk_problem *prob, const mk_outputs *out);
+
+/* -2 log L only: mk_filter with every state output NULL (the solver's objective,
+ * Metran.get_mle, metran/metran.py:605-622).  d_mle [B] required. */
+MK_API int mk_loglik(mk_context *ctx, const mk_problem *prob, double *d_mle);
+
+/* kalmansmoother for B instances (kalmanfilter.py:403-476).  Reads out->d_F and out->d_Pf
+ * (as written by mk_filter); predicted moments are recomputed from them (Phi diagonal), so
+ * d_Xp/d_Pp are not read.  Writes d_S, d_Ps (either may be NULL), d_status. */
+MK_API int mk_smooth(mk_context *ctx, const mk_problem *prob, const mk_outputs *out);
+
+/* run_smoother (kalmanfilter.py:676-694): mk_filter then mk_smooth on the same stream. */
+MK_API int mk_filter_smooth(mk_context *ctx, const mk_problem *prob, const mk_outputs *out);
+
+/* SPKalmanFilter.simulate (kalmanfilter.py:569-603) for B instances:
+ *   sim_means[b,t,:] = Z_b x[b,t];  sim_vars[b,t,j] = max((Z_b P[b,t] Z_b^T)_jj, 0)
+ * Z is dense [RZ,N,n] (instance b uses Z[b % RZ]); Metran passes the std-scaled matrix
+ * (metran/metran.py:944-961). */
+MK_API int mk_simulate(mk_context *ctx, int64_t B, int64_t RZ, int64_t T, int64_t N, int64_t n,
+                       const double *d_Z, const double *d_means /* [B,T,n] */,
+                       const double *d_covs /* [B,T,n,n] */, double *d_sim_means /* [B,T,N] */,
+                       double *d_sim_vars /* [B,T,N] */);
+
+/* SPKalmanFilter.decompose (kalmanfilter.py:605-644):
+ *   sdf[b,t,:] = Z[:, :N] x[b,t,:N];  cdf[b,k,t,:] = Z[:, N+k] * x[b,t,N+k] */
+MK_API int mk_decompose(mk_context *ctx, int64_t B, int64_t RZ, int64_t T, int64_t N, int64_t n,
+                        const double *d_Z, const double *d_means /* [B,T,n] */,
+                        double *d_sdf /* [B,T,N] */, double *d_cdf /* [B,n-N,T,N] */);
+
+/* Sum of d_mle over the local batch in a fixed order (deterministic tree), for the summed
+ * objective fed back to the solver; the cross-GPU all-reduce is done by the host with RCCL. */
+MK_API int mk_sum(mk_context *ctx, int64_t count, const double *d_values, double *d_result /* [1] */);
+
+/* ---- instrumentation --------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
+MK_API int mk_enable_timing(mk_context *ctx, int enable);
+/* Duration of the most recent filter / smoother kernel (ms); synchronises on their events. */
+MK_API int mk_last_kernel_ms(mk_context *ctx, float *filter_ms, float *smoother_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METRAN_HIP_H */

@@ -1,0 +1,360 @@
+// mk_capi.hip -- C ABI of libmetran_hip.so (declared in include/metran_hip.h).
+// Thin, exception-free layer: argument validation, kernel dispatch by (N,K), HIP error ->
+// mk_status translation, optional hipEvent timing of the two hot kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "mk_internal.h"
+
+struct mk_context {
+    int device;
+    hipStream_t stream;
+    bool timing;
+    hipEvent_t ev[4]; // filter start/stop, smoother start/stop
+    bool have_filter_time, have_smooth_time;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MK_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) return fail(MK_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define MK_CTX(ctx)                                              \
+    if (!(ctx)) return fail(MK_ERR_INVALID, "null mk_context"); \
+    MK_HIP(hipSetDevice((ctx)->device))
+
+extern "C" {
+
+MK_API int mk_abi_version(void) { return MK_ABI_VERSION; }
+MK_API const char *mk_last_error(void) { return g_err; }
+
+MK_API int mk_device_count(int *count)
+{
+    if (!count) return fail(MK_ERR_INVALID, "null count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(MK_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return MK_OK;
+}
+
+MK_API int mk_create(int device, mk_context **out)
+{
+    if (!out) return fail(MK_ERR_INVALID, "null ctx out-pointer");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+        return fail(MK_ERR_NO_DEVICE, "no HIP device visible (libmetran_hip needs an MI355X / gfx950)");
+    if (device < 0 || device >= c) return fail(MK_ERR_INVALID, "device %d out of range [0,%d)", device, c);
+    MK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    mk_context *ctx = new (std::nothrow) mk_context();
+    if (!ctx) return fail(MK_ERR_ALLOC, "out of host memory");
+    ctx->device = device;
+    ctx->stream = nullptr;
+    ctx->timing = false;
+    ctx->have_filter_time = ctx->have_smooth_time = false;
+    for (auto &e : ctx->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return fail(MK_ERR_HIP, "hipEventCreate failed");
+        }
+    }
+    *out = ctx;
+    return MK_OK;
+}
+
+MK_API int mk_destroy(mk_context *ctx)
+{
+    if (!ctx) return MK_OK;
+    (void)hipSetDevice(ctx->device);
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    delete ctx;
+    return MK_OK;
+}
+
+MK_API int mk_set_stream(mk_context *ctx, void *s)
+{
+    MK_CTX(ctx);
+    ctx->stream = (hipStream_t)s;
+    return MK_OK;
+}
+
+MK_API int mk_sync(mk_context *ctx)
+{
+    MK_CTX(ctx);
+    MK_HIP(hipStreamSynchronize(ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_shape_supported(int64_t N, int64_t K)
+{
+    for (int i = 0; i < mk::num_shapes(); ++i) {
+        int n_, k_;
+        mk::get_shape(i, &n_, &k_);
+        if (n_ == N && k_ == K) return 1;
+    }
+    return 0;
+}
+
+MK_API int mk_supported_shapes(int64_t *shapes, int cap)
+{
+    const int cnt = mk::num_shapes();
+    for (int i = 0; i < cnt && i < cap && shapes; ++i) {
+        int n_, k_;
+        mk::get_shape(i, &n_, &k_);
+        shapes[2 * i] = n_;
+        shapes[2 * i + 1] = k_;
+    }
+    return cnt;
+}
+
+MK_API int mk_malloc(mk_context *ctx, size_t bytes, void **p)
+{
+    MK_CTX(ctx);
+    if (!p) return fail(MK_ERR_INVALID, "null out-pointer");
+    *p = nullptr;
+    if (bytes == 0) return MK_OK;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(MK_ERR_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return MK_OK;
+}
+
+MK_API int mk_free(mk_context *ctx, void *p)
+{
+    MK_CTX(ctx);
+    if (p) MK_HIP(hipFree(p));
+    return MK_OK;
+}
+
+MK_API int mk_memcpy_h2d(mk_context *ctx, void *d, const void *h, size_t bytes)
+{
+    MK_CTX(ctx);
+    if (bytes && (!d || !h)) return fail(MK_ERR_INVALID, "null pointer in memcpy_h2d");
+    if (bytes) {
+        MK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        MK_HIP(hipStreamSynchronize(ctx->stream)); // h may be pageable / freed by the caller
+    }
+    return MK_OK;
+}
+
+MK_API int mk_memcpy_d2h(mk_context *ctx, void *h, const void *d, size_t bytes)
+{
+    MK_CTX(ctx);
+    if (bytes && (!d || !h)) return fail(MK_ERR_INVALID, "null pointer in memcpy_d2h");
+    if (bytes) {
+        MK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MK_OK;
+}
+
+MK_API int mk_memset(mk_context *ctx, void *d, int value, size_t bytes)
+{
+    MK_CTX(ctx);
+    if (bytes && !d) return fail(MK_ERR_INVALID, "null pointer in memset");
+    if (bytes) MK_HIP(hipMemsetAsync(d, value, bytes, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_params_from_alpha(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K, const double *alpha,
+                                const double *loadings, double dt, double *phi, double *q)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || R <= 0 || N <= 0 || K < 0 || !alpha || !phi || !q || (K > 0 && !loadings))
+        return fail(MK_ERR_INVALID, "mk_params_from_alpha: bad argument");
+    MK_HIP(mk::launch_params(B, R, (int)N, (int)K, alpha, loadings, dt, phi, q, ctx->stream));
+    return MK_OK;
+}
+
+static int check_problem(const mk_problem *p)
+{
+    if (!p) return fail(MK_ERR_INVALID, "null mk_problem");
+    if (p->n_instances <= 0 || p->n_records <= 0 || p->n_records > p->n_instances)
+        return fail(MK_ERR_INVALID, "need 1 <= n_records <= n_instances (got R=%lld, B=%lld)",
+                    (long long)p->n_records, (long long)p->n_instances);
+    if (p->T <= 0 || p->N <= 0 || p->K <= 0)
+        return fail(MK_ERR_INVALID, "need T, N, K >= 1 (got T=%lld N=%lld K=%lld)", (long long)p->T,
+                    (long long)p->N, (long long)p->K);
+    if (p->warmup < 0) return fail(MK_ERR_INVALID, "warmup must be >= 0");
+    if (!mk_shape_supported(p->N, p->K))
+        return fail(MK_ERR_SHAPE,
+                    "no kernel compiled for (N=%lld series, K=%lld factors); add X(%lld, %lld) to MK_SHAPES in "
+                    "metran_amd/csrc/mk_internal.h and rebuild",
+                    (long long)p->N, (long long)p->K, (long long)p->N, (long long)p->K);
+    if (!p->d_phi || !p->d_q) return fail(MK_ERR_INVALID, "d_phi and d_q are required");
+    return MK_OK;
+}
+
+static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
+{
+    if (!p->d_obs || !p->d_loadings) return fail(MK_ERR_INVALID, "d_obs and d_loadings are required");
+    mk::FilterArgs a;
+    a.B = p->n_instances;
+    a.R = p->n_records;
+    a.T = p->T;
+    a.warmup = p->warmup;
+    a.obs = p->d_obs;
+    a.phi = p->d_phi;
+    a.q = p->d_q;
+    a.loadings = p->d_loadings;
+    a.obsvar = p->d_obsvar;
+    a.x0 = p->d_x0;
+    a.P0 = p->d_P0;
+    a.mle = o->d_mle;
+    a.sigmas = o->d_sigmas;
+    a.detfs = o->d_detfs;
+    a.sigmacount = (long long *)o->d_sigmacount;
+    a.F = o->d_F;
+    a.Pf = o->d_Pf;
+    a.Xp = o->d_Xp;
+    a.Pp = o->d_Pp;
+    a.status = o->d_status;
+    if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    MK_HIP(mk::launch_filter((int)p->N, (int)p->K, a, ctx->stream));
+    if (ctx->timing) {
+        MK_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        ctx->have_filter_time = true;
+    }
+    return MK_OK;
+}
+
+static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
+{
+    if (!o->d_F || !o->d_Pf)
+        return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
+    mk::SmootherArgs a;
+    a.B = p->n_instances;
+    a.T = p->T;
+    a.phi = p->d_phi;
+    a.q = p->d_q;
+    a.F = o->d_F;
+    a.Pf = o->d_Pf;
+    a.S = o->d_S;
+    a.Ps = o->d_Ps;
+    a.status = o->d_status;
+    if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    MK_HIP(mk::launch_smoother((int)p->N, (int)p->K, a, ctx->stream));
+    if (ctx->timing) {
+        MK_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->have_smooth_time = true;
+    }
+    return MK_OK;
+}
+
+MK_API int mk_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
+{
+    MK_CTX(ctx);
+    if (int rc = check_problem(p)) return rc;
+    if (!o) return fail(MK_ERR_INVALID, "null mk_outputs");
+    return do_filter(ctx, p, o);
+}
+
+MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
+{
+    MK_CTX(ctx);
+    if (int rc = check_problem(p)) return rc;
+    if (!d_mle) return fail(MK_ERR_INVALID, "d_mle is required");
+    mk_outputs o;
+    memset(&o, 0, sizeof(o));
+    o.d_mle = d_mle;
+    return do_filter(ctx, p, &o);
+}
+
+MK_API int mk_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
+{
+    MK_CTX(ctx);
+    if (int rc = check_problem(p)) return rc;
+    if (!o) return fail(MK_ERR_INVALID, "null mk_outputs");
+    return do_smooth(ctx, p, o);
+}
+
+MK_API int mk_filter_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
+{
+    MK_CTX(ctx);
+    if (int rc = check_problem(p)) return rc;
+    if (!o) return fail(MK_ERR_INVALID, "null mk_outputs");
+    if (int rc = do_filter(ctx, p, o)) return rc;
+    return do_smooth(ctx, p, o);
+}
+
+MK_API int mk_simulate(mk_context *ctx, int64_t B, int64_t RZ, int64_t T, int64_t N, int64_t n, const double *Z,
+                       const double *means, const double *covs, double *sm, double *sv)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || RZ <= 0 || T <= 0 || N <= 0 || n < N || !Z || !means || (sv && !covs))
+        return fail(MK_ERR_INVALID, "mk_simulate: bad argument");
+    MK_HIP(mk::launch_simulate(B, RZ, T, (int)N, (int)n, Z, means, covs, sm, sv, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_decompose(mk_context *ctx, int64_t B, int64_t RZ, int64_t T, int64_t N, int64_t n, const double *Z,
+                        const double *means, double *sdf, double *cdf)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || RZ <= 0 || T <= 0 || N <= 0 || n < N || !Z || !means)
+        return fail(MK_ERR_INVALID, "mk_decompose: bad argument");
+    MK_HIP(mk::launch_decompose(B, RZ, T, (int)N, (int)n, Z, means, sdf, cdf, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_sum(mk_context *ctx, int64_t count, const double *v, double *out)
+{
+    MK_CTX(ctx);
+    if (count <= 0 || !v || !out) return fail(MK_ERR_INVALID, "mk_sum: bad argument");
+    MK_HIP(mk::launch_sum(count, v, out, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_enable_timing(mk_context *ctx, int enable)
+{
+    MK_CTX(ctx);
+    ctx->timing = enable != 0;
+    ctx->have_filter_time = ctx->have_smooth_time = false;
+    return MK_OK;
+}
+
+MK_API int mk_last_kernel_ms(mk_context *ctx, float *filter_ms, float *smoother_ms)
+{
+    MK_CTX(ctx);
+    if (filter_ms) {
+        *filter_ms = -1.f;
+        if (ctx->have_filter_time) {
+            MK_HIP(hipEventSynchronize(ctx->ev[1]));
+            MK_HIP(hipEventElapsedTime(filter_ms, ctx->ev[0], ctx->ev[1]));
+        }
+    }
+    if (smoother_ms) {
+        *smoother_ms = -1.f;
+        if (ctx->have_smooth_time) {
+            MK_HIP(hipEventSynchronize(ctx->ev[3]));
+            MK_HIP(hipEventElapsedTime(smoother_ms, ctx->ev[2], ctx->ev[3]));
+        }
+    }
+    return MK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,53 @@
+// mk_internal.h -- shared between the kernels (mk_kernels.hip) and the C ABI (mk_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "metran_hip.h"
+
+// (N series, K common factors) shapes compiled ahead of time.  The first is the benchmark
+// shape of BASELINE.json (configs[1], configs[2]); (32,4) is configs[3]; (5,1) is the
+// examples/data model (configs[0]); the rest cover the golden fixtures and common small models.
+#ifndef MK_SHAPES
+#define MK_SHAPES(X) \
+    X(8, 2)          \
+    X(5, 1)          \
+    X(2, 1)          \
+    X(3, 1)          \
+    X(4, 1)          \
+    X(6, 2)          \
+    X(14, 3)         \
+    X(32, 4)
+#endif
+
+namespace mk {
+
+struct FilterArgs {
+    long B, R, T, warmup;
+    const double *obs, *phi, *q, *loadings, *obsvar, *x0, *P0;
+    double *mle, *sigmas, *detfs;
+    long long *sigmacount;
+    double *F, *Pf, *Xp, *Pp;
+    unsigned *status;
+};
+
+struct SmootherArgs {
+    long B, T;
+    const double *phi, *q;
+    const double *F, *Pf;
+    double *S, *Ps;
+    unsigned *status;
+};
+
+hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);
+hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s);
+int num_shapes();
+void get_shape(int i, int *N, int *K);
+hipError_t launch_params(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,
+                         double *phi, double *q, hipStream_t s);
+hipError_t launch_simulate(long B, long RZ, long T, int N, int n, const double *Z, const double *means,
+                           const double *covs, double *sm, double *sv, hipStream_t s);
+hipError_t launch_decompose(long B, long RZ, long T, int N, int n, const double *Z, const double *means,
+                            double *sdf, double *cdf, hipStream_t s);
+hipError_t launch_sum(long count, const double *v, double *out, hipStream_t s);
+
+} // namespace mk

@@ -1,0 +1,325 @@
+"""Batched MI355X engine: thousands of independent Metran dynamic-factor models per launch.
+
+Host-side plumbing only (device memory and streams come from PyTorch-ROCm); every
+number is produced by the HIP kernels behind the C ABI (``include/metran_hip.h``).
+
+Mirrors, batched over a leading axis, the reference call chain
+``SPKalmanFilter.set_observations -> set_matrices -> run_filter / run_smoother -> get_mle /
+simulate / decompose`` (/root/reference/metran/kalmanfilter.py:520-778) and
+``Metran._get_matrices`` (metran/metran.py:386-416).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import MetranHipError, Outputs, Problem, check
+
+__all__ = ["BatchedKalman", "MetranHipError", "FLAG_NONPOSITIVE_F", "FLAG_NOT_SPD"]
+
+FLAG_NONPOSITIVE_F = 1
+FLAG_NOT_SPD = 2
+
+_STATE_OUTPUTS = ("F", "Pf", "Xp", "Pp", "S", "Ps")
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class BatchedKalman:
+    """One context per (process, GPU).
+
+    Parameters
+    ----------
+    device : int or torch.device, optional
+        CUDA/HIP device index; default ``torch.cuda.current_device()``.
+
+    Typical use::
+
+        kf = BatchedKalman()
+        kf.set_observations(obs)            # [R,T,N], NaN = missing; uploaded once
+        kf.set_loadings(loadings)           # [R,N,K]
+        mle = kf.loglik(phi, q)             # [B] -2 log L, B = k*R instances
+        out = kf.filter_smooth(phi, q)      # dict of device tensors F,Pf,Xp,Pp,S,Ps,mle,...
+    """
+
+    def __init__(self, device=None):
+        torch = _torch()
+        L = _lib.lib()  # raises MetranHipError when the HIP library is not built
+        if not torch.cuda.is_available():
+            raise MetranHipError("no GPU visible to PyTorch-ROCm; metran_amd has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self._L = L
+        ctx = ctypes.c_void_p()
+        check(L.mk_create(self.device.index, ctypes.byref(ctx)))
+        self._ctx = ctx
+        self.obs = None
+        self.loadings = None
+        self.obsvar = None
+        self.R = self.T = self.N = self.K = None
+        self._timing = False
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.mk_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, a, shape=None, name="array"):
+        """float64 contiguous tensor on this device (accepts numpy / torch)."""
+        torch = _torch()
+        if a is None:
+            return None
+        if not isinstance(a, torch.Tensor):
+            a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        a = a.to(device=self.device, dtype=torch.float64).contiguous()
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError("%s has shape %s, expected %s" % (name, tuple(a.shape), tuple(shape)))
+        return a
+
+    def _bind_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._L.mk_set_stream(self._ctx, ctypes.c_void_p(s)))
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    # ------------------------------------------------------------------ inputs
+    def set_observations(self, obs):
+        """Upload observation records ``[R,T,N]`` (or ``[T,N]``); NaN/inf = missing
+        (reference packing: metran/kalmanfilter.py:646-674)."""
+        torch = _torch()
+        if not isinstance(obs, torch.Tensor):
+            obs = np.asarray(obs, dtype=np.float64)
+        if obs.ndim == 2:
+            obs = obs[None]
+        if obs.ndim != 3:
+            raise ValueError("observations must be [R,T,N] or [T,N]")
+        self.obs = self._dev(obs)
+        self.R, self.T, self.N = (int(s) for s in self.obs.shape)
+        return self
+
+    def set_loadings(self, loadings, obsvar=None):
+        """Factor loadings ``[R,N,K]`` (``Z = [I | loadings]``, metran/metran.py:365-370) and
+        optional observation variances ``[R,N]`` (zeros in Metran, metran/metran.py:382-384)."""
+        torch = _torch()
+        if self.obs is None:
+            raise MetranHipError("call set_observations first")
+        if not isinstance(loadings, torch.Tensor):
+            loadings = np.asarray(loadings, dtype=np.float64)
+        if loadings.ndim == 2:
+            loadings = loadings[None]
+        self.loadings = self._dev(loadings)
+        if tuple(self.loadings.shape[:2]) != (self.R, self.N):
+            raise ValueError("loadings must be [R=%d,N=%d,K], got %s" % (self.R, self.N, tuple(self.loadings.shape)))
+        self.K = int(self.loadings.shape[2])
+        if not self._L.mk_shape_supported(self.N, self.K):
+            shapes = (ctypes.c_int64 * 128)()
+            cnt = self._L.mk_supported_shapes(shapes, 64)
+            have = [(shapes[2 * i], shapes[2 * i + 1]) for i in range(min(cnt, 64))]
+            raise MetranHipError(
+                "no HIP kernel compiled for (N=%d series, K=%d factors); compiled shapes: %s. Add X(%d, %d) to "
+                "MK_SHAPES in metran_amd/csrc/mk_internal.h and rebuild." % (self.N, self.K, have, self.N, self.K))
+        if obsvar is not None:
+            if not isinstance(obsvar, torch.Tensor):
+                obsvar = np.asarray(obsvar, dtype=np.float64)
+            if obsvar.ndim == 1:
+                obsvar = obsvar[None]
+            self.obsvar = self._dev(obsvar, (self.R, self.N), "obsvar")
+        else:
+            self.obsvar = None
+        return self
+
+    @property
+    def n(self):
+        return self.N + self.K
+
+    def params_from_alpha(self, alpha, dt=1.0):
+        """``alpha [B,n] -> (phi, q)`` on device (Metran._get_matrices diagonals, metran.py:246-322)."""
+        torch = _torch()
+        alpha = self._dev(alpha)
+        if alpha.ndim == 1:
+            alpha = alpha[None]
+        B = int(alpha.shape[0])
+        if alpha.shape[1] != self.n:
+            raise ValueError("alpha must be [B,%d]" % self.n)
+        phi = torch.empty_like(alpha)
+        q = torch.empty_like(alpha)
+        self._bind_stream()
+        check(self._L.mk_params_from_alpha(self._ctx, B, self.R, self.N, self.K, self._p(alpha),
+                                           self._p(self.loadings), float(dt), self._p(phi), self._p(q)))
+        return phi, q
+
+    def _problem(self, phi, q, warmup, x0, P0):
+        if self.obs is None or self.loadings is None:
+            raise MetranHipError("set_observations and set_loadings must be called before running the filter")
+        phi = self._dev(phi)
+        q = self._dev(q)
+        if phi.ndim == 1:
+            phi = phi[None]
+        if q.ndim == 1:
+            q = q[None]
+        B = int(phi.shape[0])
+        if tuple(phi.shape) != (B, self.n) or tuple(q.shape) != (B, self.n):
+            raise ValueError("phi and q must be [B,%d]; got %s, %s" % (self.n, tuple(phi.shape), tuple(q.shape)))
+        if B % self.R != 0:
+            raise ValueError("number of instances B=%d must be a multiple of the number of records R=%d" % (B, self.R))
+        x0 = self._dev(x0, (B, self.n), "x0") if x0 is not None else None
+        P0 = self._dev(P0, (B, self.n, self.n), "P0") if P0 is not None else None
+        prob = Problem(B, self.R, self.T, self.N, self.K, int(warmup), self._p(self.obs), self._p(phi), self._p(q),
+                       self._p(self.loadings), self._p(self.obsvar), self._p(x0), self._p(P0))
+        keep = (phi, q, x0, P0)
+        return prob, keep, B
+
+    # ------------------------------------------------------------------ hot path
+    def loglik(self, phi, q, warmup=1, x0=None, P0=None, out=None):
+        """-2 log L per instance (``Metran.get_mle`` objective, metran/metran.py:605-622)."""
+        torch = _torch()
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        mle = out if out is not None else torch.empty(B, dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        check(self._L.mk_loglik(self._ctx, ctypes.byref(prob), self._p(mle)))
+        return mle
+
+    def _alloc_outputs(self, B, want, bookkeeping=True):
+        torch = _torch()
+        T, n = self.T, self.n
+        f64 = dict(dtype=torch.float64, device=self.device)
+        res = {"mle": torch.empty(B, **f64)}
+        if bookkeeping:
+            res["sigmas"] = torch.empty((B, T), **f64)
+            res["detfs"] = torch.empty((B, T), **f64)
+            res["sigmacount"] = torch.empty(B, dtype=torch.int64, device=self.device)
+        res["status"] = torch.zeros(B, dtype=torch.int32, device=self.device)
+        for k in want:
+            if k not in _STATE_OUTPUTS:
+                raise ValueError("unknown output %r (choose from %s)" % (k, _STATE_OUTPUTS))
+            res[k] = torch.empty((B, T, n) if k in ("F", "Xp", "S") else (B, T, n, n), **f64)
+        return res
+
+    def _outputs_struct(self, res):
+        g = res.get
+        return Outputs(self._p(g("mle")), self._p(g("sigmas")), self._p(g("detfs")), self._p(g("sigmacount")),
+                       self._p(g("F")), self._p(g("Pf")), self._p(g("Xp")), self._p(g("Pp")), self._p(g("S")),
+                       self._p(g("Ps")), self._p(g("status")))
+
+    def filter(self, phi, q, warmup=1, x0=None, P0=None, outputs=("F", "Pf", "Xp", "Pp"), buffers=None):
+        """``run_filter`` for B instances (kalmanfilter.py:696-778).  Returns a dict of device tensors."""
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        res = buffers if buffers is not None else self._alloc_outputs(B, [o for o in outputs if o not in ("S", "Ps")])
+        o = self._outputs_struct(res)
+        self._bind_stream()
+        check(self._L.mk_filter(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
+        return res
+
+    def filter_smooth(self, phi, q, warmup=1, x0=None, P0=None, outputs=_STATE_OUTPUTS, buffers=None):
+        """``run_smoother`` for B instances (kalmanfilter.py:676-694): filter, then RTS smoother."""
+        want = set(outputs) | {"F", "Pf"}  # the backward pass re-reads the filtered moments
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        res = buffers if buffers is not None else self._alloc_outputs(B, [k for k in _STATE_OUTPUTS if k in want])
+        o = self._outputs_struct(res)
+        self._bind_stream()
+        check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
+        return res
+
+    def supported_shapes(self):
+        """(N, K) pairs with kernels compiled into the library."""
+        shapes = (ctypes.c_int64 * 256)()
+        cnt = self._L.mk_supported_shapes(shapes, 128)
+        return [(int(shapes[2 * i]), int(shapes[2 * i + 1])) for i in range(min(cnt, 128))]
+
+    def smooth(self, phi, q, F, Pf, outputs=("S", "Ps")):
+        """``kalmansmoother`` (kalmanfilter.py:403-476) from existing filtered moments
+        ``F [B,T,n]``, ``Pf [B,T,n,n]``; needs no observations (the kernel depends on n only)."""
+        F = self._dev(F)
+        Pf = self._dev(Pf)
+        B, T, n = (int(s) for s in F.shape)
+        if tuple(Pf.shape) != (B, T, n, n):
+            raise ValueError("Pf must be [B,T,n,n]")
+        phi = self._dev(phi, (B, n), "phi")
+        q = self._dev(q, (B, n), "q")
+        shape = [(N, K) for (N, K) in self.supported_shapes() if N + K == n]
+        if not shape:
+            raise MetranHipError("no HIP smoother kernel compiled for state dimension n=%d" % n)
+        N, K = shape[0]
+        prob = Problem(B, 1, T, N, K, 1, None, self._p(phi), self._p(q), None, None, None, None)
+        torch = _torch()
+        res = {"F": F, "Pf": Pf, "status": torch.zeros(B, dtype=torch.int32, device=self.device)}
+        if "S" in outputs:
+            res["S"] = torch.empty_like(F)
+        if "Ps" in outputs:
+            res["Ps"] = torch.empty_like(Pf)
+        o = self._outputs_struct(res)
+        self._bind_stream()
+        check(self._L.mk_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
+        return res
+
+    # ------------------------------------------------------------------ projection epilogues
+    def simulate(self, Z, means, covs):
+        """``SPKalmanFilter.simulate`` (kalmanfilter.py:569-603): Z ``[RZ,N,n]`` or ``[N,n]``."""
+        torch = _torch()
+        Z = self._dev(Z)
+        if Z.ndim == 2:
+            Z = Z[None]
+        means = self._dev(means)
+        covs = self._dev(covs)
+        B, T, n = (int(s) for s in means.shape)
+        RZ, N = int(Z.shape[0]), int(Z.shape[1])
+        sm = torch.empty((B, T, N), dtype=torch.float64, device=self.device)
+        sv = torch.empty((B, T, N), dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        check(self._L.mk_simulate(self._ctx, B, RZ, T, N, n, self._p(Z), self._p(means), self._p(covs), self._p(sm),
+                                  self._p(sv)))
+        return sm, sv
+
+    def decompose(self, Z, means):
+        """``SPKalmanFilter.decompose`` (kalmanfilter.py:605-644) -> (sdf [B,T,N], cdf [B,K,T,N])."""
+        torch = _torch()
+        Z = self._dev(Z)
+        if Z.ndim == 2:
+            Z = Z[None]
+        means = self._dev(means)
+        B, T, n = (int(s) for s in means.shape)
+        RZ, N = int(Z.shape[0]), int(Z.shape[1])
+        sdf = torch.empty((B, T, N), dtype=torch.float64, device=self.device)
+        cdf = torch.empty((B, n - N, T, N), dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        check(self._L.mk_decompose(self._ctx, B, RZ, T, N, n, self._p(Z), self._p(means), self._p(sdf), self._p(cdf)))
+        return sdf, cdf
+
+    def sum(self, values):
+        """Deterministic device sum (fixed order) of a 1-D tensor -> 0-d tensor."""
+        torch = _torch()
+        values = self._dev(values).reshape(-1)
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        self._bind_stream()
+        check(self._L.mk_sum(self._ctx, int(values.numel()), self._p(values), self._p(out)))
+        return out[0]
+
+    # ------------------------------------------------------------------ instrumentation
+    def enable_timing(self, enable=True):
+        self._timing = bool(enable)
+        check(self._L.mk_enable_timing(self._ctx, 1 if enable else 0))
+
+    def last_kernel_ms(self):
+        """(filter_ms, smoother_ms) of the most recent launches, measured with hipEvents on the launch stream."""
+        f, s = ctypes.c_float(-1.0), ctypes.c_float(-1.0)
+        check(self._L.mk_last_kernel_ms(self._ctx, ctypes.byref(f), ctypes.byref(s)))
+        return float(f.value), float(s.value)
+
+    def synchronize(self):
+        check(self._L.mk_sync(self._ctx))

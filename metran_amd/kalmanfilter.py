@@ -1,0 +1,280 @@
+"""Host-side mirror of ``metran/kalmanfilter.py`` with the MI355X engine behind it.
+
+Same names, argument meaning and error behaviour as the reference module so that it can be
+dropped in at Metran's two plug points:
+
+* ``seqkalmanfilter_hip``  -- the 9-argument -> 7-tuple engine callable that
+  ``SPKalmanFilter.filtermethod`` is bound to (/root/reference/metran/kalmanfilter.py:494-504,
+  call site :761-771); replaces ``seqkalmanfilter`` (:236-400) / ``seqkalmanfilter_np`` (:122-233).
+* ``kalmansmoother_hip``   -- replaces the module-level ``kalmansmoother`` (:403-476), which
+  ``run_smoother`` looks up by global name (:685-691).
+* ``SPKalmanFilter``       -- same methods/attributes as the reference class (:479-778) with
+  ``engine="hip"``; usable stand-alone (``Metran._init_kalmanfilter`` override).
+* ``install(metran_module)`` patches the three module globals of an imported reference.
+
+All arithmetic runs in ``libmetran_hip.so``; nothing here falls back to the CPU.
+The engine supports Metran's model structure only: diagonal transition matrix / covariance
+and ``Z = [I | loadings]``; anything else raises (the reference's numba engine itself
+silently assumes a diagonal transition matrix in the covariance prediction, :324-331).
+"""
+import logging
+
+import numpy as np
+
+from .engine import BatchedKalman, MetranHipError
+
+logger = logging.getLogger(__name__)
+
+__all__ = ["seqkalmanfilter_hip", "kalmansmoother_hip", "SPKalmanFilter", "install", "uninstall",
+           "observations_to_nan_encoded", "MetranHipError"]
+
+_ENGINE = None
+
+
+def get_engine():
+    """Process-wide BatchedKalman on the current device (created lazily)."""
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = BatchedKalman()
+    return _ENGINE
+
+
+def _diag_only(M, name):
+    M = np.asarray(M, dtype=np.float64)
+    d = np.diag(M).copy()
+    if M.ndim != 2 or M.shape[0] != M.shape[1] or np.any(M - np.diag(d) != 0.0):
+        msg = "%s must be a diagonal matrix for the hip engine (Metran always passes one)" % name
+        logger.error(msg)
+        raise MetranHipError(msg)
+    return d
+
+
+def _split_observation_matrix(Z):
+    Z = np.asarray(Z, dtype=np.float64)
+    N, n = Z.shape
+    if n <= N or np.any(Z[:, :N] != np.eye(N)):
+        msg = ("observation_matrix must be [I_N | loadings] with at least one common factor "
+               "(metran/metran.py:365-370) for the hip engine")
+        logger.error(msg)
+        raise MetranHipError(msg)
+    return np.ascontiguousarray(Z[:, N:])
+
+
+def observations_to_nan_encoded(observations, observation_indices, observation_count):
+    """Inverse of the reference packing (metran/kalmanfilter.py:646-674): the kernels take one
+    ``[T,N]`` array with NaN for "not listed at this step" instead of the float64 index list."""
+    obs = np.asarray(observations, dtype=np.float64)
+    idx = np.asarray(observation_indices)
+    cnt = np.asarray(observation_count).astype(np.int64)
+    T, N = obs.shape
+    listed = np.arange(N)[None, :] < cnt[:, None]  # position i is valid at step t
+    out = np.full((T, N), np.nan)
+    tt, ii = np.nonzero(listed)
+    jj = idx[tt, ii].astype(np.int64)
+    out[tt, jj] = obs[tt, jj]
+    return out
+
+
+def seqkalmanfilter_hip(observations, transition_matrix, transition_covariance, observation_matrix,
+                        observation_variance, observation_indices, observation_count, filtered_state_mean,
+                        filtered_state_covariance):
+    """Drop-in for ``seqkalmanfilter`` (metran/kalmanfilter.py:243-400): same 9 positional
+    arguments, same 7-tuple ``(sigmas, detfs, sigmacount, filtered_state_means,
+    filtered_state_covariances, predicted_state_means, predicted_state_covariances)``."""
+    phi = _diag_only(transition_matrix, "transition_matrix")
+    q = _diag_only(transition_covariance, "transition_covariance")
+    loadings = _split_observation_matrix(observation_matrix)
+    obs = observations_to_nan_encoded(observations, observation_indices, observation_count)
+    kf = get_engine()
+    kf.set_observations(obs[None])
+    kf.set_loadings(loadings[None], np.asarray(observation_variance, dtype=np.float64)[None])
+    x0 = np.asarray(filtered_state_mean, dtype=np.float64)[None]
+    P0 = np.asarray(filtered_state_covariance, dtype=np.float64)[None]
+    r = kf.filter(phi[None], q[None], warmup=1, x0=x0, P0=P0)
+    sc = int(r["sigmacount"][0].item())
+    cpu = lambda k: r[k][0].cpu().numpy()  # noqa: E731
+    return (cpu("sigmas"), cpu("detfs"), sc, cpu("F"), cpu("Pf"), cpu("Xp"), cpu("Pp"))
+
+
+def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predicted_state_means,
+                       predicted_state_covariances, transition_matrix):
+    """Drop-in for ``kalmansmoother`` (metran/kalmanfilter.py:403-476): 5 arguments ->
+    ``(smoothed_state_means, smoothed_state_covariances)``.
+
+    The kernel recomputes the predicted moments from the filtered ones; the transition
+    variances it needs are recovered from the arguments as
+    ``q = diag(Pp[1]) - phi**2 * diag(Pf[0])`` (exact up to one rounding)."""
+    F = np.ascontiguousarray(filtered_state_means, dtype=np.float64)
+    Pf = np.ascontiguousarray(filtered_state_covariances, dtype=np.float64)
+    Pp = np.asarray(predicted_state_covariances, dtype=np.float64)
+    phi = _diag_only(transition_matrix, "transition_matrix")
+    T, n = F.shape
+    if T < 2:
+        return F.copy(), Pf.copy()
+    q = np.diag(Pp[1]) - phi * np.diag(Pf[0]) * phi
+    kf = get_engine()
+    r = kf.smooth(phi[None], q[None], F[None], Pf[None])
+    return r["S"][0].cpu().numpy(), r["Ps"][0].cpu().numpy()
+
+
+class SPKalmanFilter:
+    """Kalman filter class for Metran, MI355X engine.
+
+    Mirror of ``metran.kalmanfilter.SPKalmanFilter`` (metran/kalmanfilter.py:479-778):
+    identical public methods and attributes; ``engine`` accepts ``"hip"`` only.
+    """
+
+    def __init__(self, engine="hip"):
+        self.init_states()
+        self.detfs = None
+        self.sigmas = None
+        self.nobs = None
+        self.mask = False
+        self._check_engine(engine)
+        self.filtermethod = seqkalmanfilter_hip
+        self._kf = None
+
+    @staticmethod
+    def _check_engine(engine):
+        if engine != "hip":
+            # same failure mode as the reference (kalmanfilter.py:742-745)
+            msg = "Unknown engine defined in run_filter."
+            logger.error(msg)
+            raise Exception(msg)
+
+    def init_states(self):
+        """kalmanfilter.py:506-518"""
+        self.filtered_state_means = None
+        self.filtered_state_covariances = None
+        self.predicted_state_means = None
+        self.predicted_state_covariances = None
+        self.smoothed_state_means = None
+        self.smoothed_state_covariances = None
+
+    def set_matrices(self, transition_matrix, transition_covariance, observation_matrix, observation_variance):
+        """kalmanfilter.py:520-548"""
+        self.transition_matrix = transition_matrix
+        self.transition_covariance = transition_covariance
+        self.observation_matrix = observation_matrix
+        self.observation_variance = observation_variance
+        self.nstate = np.int64(np.asarray(self.transition_matrix).shape[0])
+
+    def set_observations(self, oseries):
+        """kalmanfilter.py:646-674 -- same three arrays (``observations`` with missing -> 0,
+        float64 ``observation_indices``, int64 ``observation_count``) built without the Python
+        loop over time steps, plus the NaN-encoded device copy the kernels read."""
+        self.oseries_index = getattr(oseries, "index", None)
+        y = np.asarray(getattr(oseries, "values", oseries), dtype=np.float64)
+        # masked where not finite (:657); "+1e10 then nonzero()" also drops exactly -1e10 (:666-667)
+        valid = np.isfinite(y) & ((y + 1e10) != 0.0)
+        n_timesteps, dimobs = y.shape
+        self.observation_count = valid.sum(axis=1).astype(np.int64)
+        self.observations = np.where(valid, y, 0.0)
+        order = np.argsort(~valid, axis=1, kind="stable")  # valid indices first, ascending
+        packed = np.where(np.arange(dimobs)[None, :] < self.observation_count[:, None], order, 0)
+        self.observation_indices = packed.astype(np.float64)
+        self._obs_nan = np.where(valid, y, np.nan)
+        self._uploaded = False
+
+    def _engine(self):
+        if self._kf is None:
+            self._kf = get_engine()
+        return self._kf
+
+    def _prepare(self):
+        kf = self._engine()
+        phi = _diag_only(self.transition_matrix, "transition_matrix")
+        q = _diag_only(self.transition_covariance, "transition_covariance")
+        loadings = _split_observation_matrix(self.observation_matrix)
+        kf.set_observations(self._obs_nan[None])
+        kf.set_loadings(loadings[None], np.asarray(self.observation_variance, dtype=np.float64)[None])
+        return kf, phi, q
+
+    def run_filter(self, initial_state_mean=None, initial_state_covariance=None, engine=None):
+        """kalmanfilter.py:696-778"""
+        if self.mask:
+            logger.info("Running Kalman filter with masked observations.")
+        if engine is not None:
+            self._check_engine(engine)
+        kf, phi, q = self._prepare()
+        x0 = None if initial_state_mean is None else np.asarray(initial_state_mean, dtype=np.float64)[None]
+        P0 = None if initial_state_covariance is None else np.asarray(initial_state_covariance, dtype=np.float64)[None]
+        r = kf.filter(phi[None], q[None], warmup=1, x0=x0, P0=P0)
+        self._store_filter(r)
+
+    def _store_filter(self, r):
+        sc = int(r["sigmacount"][0].item())
+        self.sigmas = r["sigmas"][0, :sc].cpu().numpy()
+        self.detfs = r["detfs"][0, :sc].cpu().numpy()
+        self.filtered_state_means = r["F"][0].cpu().numpy()
+        self.filtered_state_covariances = r["Pf"][0].cpu().numpy()
+        self.predicted_state_means = r["Xp"][0].cpu().numpy()
+        self.predicted_state_covariances = r["Pp"][0].cpu().numpy()
+        self._mle_device = float(r["mle"][0].item())
+
+    def run_smoother(self):
+        """kalmanfilter.py:676-694 (filter + RTS smoother in one stream-ordered submission)."""
+        if self.mask:
+            logger.info("Running Kalman filter with masked observations.")
+        kf, phi, q = self._prepare()
+        r = kf.filter_smooth(phi[None], q[None], warmup=1)
+        self._store_filter(r)
+        self.smoothed_state_means = r["S"][0].cpu().numpy()
+        self.smoothed_state_covariances = r["Ps"][0].cpu().numpy()
+
+    def get_mle(self, warmup=1):
+        """kalmanfilter.py:550-567.  For the default warm-up the value fused into the filter
+        kernel's epilogue is returned; other warm-ups re-reduce the stored per-step terms."""
+        if warmup == 1 and getattr(self, "_mle_device", None) is not None:
+            return self._mle_device
+        detfs = self.detfs[warmup:]
+        sigmas = self.sigmas[warmup:]
+        nobs = np.sum(self.observation_count[warmup:])
+        return nobs * np.log(2 * np.pi) + np.sum(detfs) + np.sum(sigmas)
+
+    def simulate(self, observation_matrix, method="smoother"):
+        """kalmanfilter.py:569-603 (projection on the device)."""
+        if method == "filter":
+            means, covariances = self.filtered_state_means, self.filtered_state_covariances
+        else:
+            means, covariances = self.smoothed_state_means, self.smoothed_state_covariances
+        sm, sv = self._engine().simulate(np.asarray(observation_matrix, dtype=np.float64), means[None],
+                                         covariances[None])
+        return list(sm[0].cpu().numpy()), list(sv[0].cpu().numpy())
+
+    def decompose(self, observation_matrix, method="smoother"):
+        """kalmanfilter.py:605-644"""
+        means = self.filtered_state_means if method == "filter" else self.smoothed_state_means
+        sdf, cdf = self._engine().decompose(np.asarray(observation_matrix, dtype=np.float64), means[None])
+        sdf = sdf[0].cpu().numpy()
+        cdf = cdf[0].cpu().numpy()
+        return list(sdf), [list(c) for c in cdf]
+
+
+_PATCHED = {}
+
+
+def install(metran_module=None):
+    """Patch an imported reference so that ``Metran.solve()/get_simulation()/...`` run on the GPU.
+
+    ``Metran.solve`` builds a fresh ``SPKalmanFilter(engine=engine)`` (metran/metran.py:1025, :243),
+    whose ``__init__`` binds ``filtermethod`` to the module globals ``seqkalmanfilter_np`` /
+    ``seqkalmanfilter`` (:501-504) and whose ``run_smoother`` resolves ``kalmansmoother`` at call
+    time (:685) -- so replacing those three globals is sufficient and touches nothing else."""
+    if metran_module is None:
+        import metran as metran_module  # the reference, if importable
+    km = metran_module.kalmanfilter
+    if km not in _PATCHED:
+        _PATCHED[km] = (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother)
+    km.seqkalmanfilter = seqkalmanfilter_hip
+    km.seqkalmanfilter_np = seqkalmanfilter_hip
+    km.kalmansmoother = kalmansmoother_hip
+    return km
+
+
+def uninstall(metran_module=None):
+    if metran_module is None:
+        import metran as metran_module
+    km = metran_module.kalmanfilter
+    if km in _PATCHED:
+        km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother = _PATCHED.pop(km)
