@@ -40,24 +40,132 @@ __device__ __forceinline__ void sfor_down(F &&f) // I = E-1 .. 0 handled as (E-1
 }
 #define MK_LAMBDA(arg) [&](auto arg) __attribute__((always_inline))
 
-// ---------------------------------------------------------------- cross-lane broadcast
+// ---------------------------------------------------------------- cross-lane primitives
+// All cross-lane traffic of the hot kernels goes through three primitives:
+//   bcast<J>(v)                         value of lane J of the group, in every lane
+//   axpy_lane<J,C0,C1>(acc, src, mul)   acc[c] += bcast<J>(src[c]) * mul      c in [C0,C1)
+//   axpy_col<C0,C1>(acc, src, mul)      acc[c] += bcast<c>(src)    * mul      c in [C0,C1)
+//
+// G = 16 (four models per wavefront, one per 16-lane DPP row): gfx950 has DPP64
+// `row_newbcast` on v_mov_b64 and v_fmac_f64, so a broadcast-multiply-accumulate is ONE
+// instruction (v_fmac_f64_dpp) with no LDS and no extra move.  hipcc has no builtin for the
+// fused form, so it is emitted as inline asm; the assembler does not pad the
+// "VALU write -> DPP read" hazard (2 wait states), hence every asm statement opens with
+// `s_nop 1`, and inside a statement no DPP source is written by the two preceding
+// instructions (each instruction writes only its own accumulator).
+// G = 64 (one model per wavefront): v_readlane -> SGPR pair, plain v_fma with a scalar operand.
 template <int G>
 struct Group;
 
-// four models per wavefront, one per 16-lane DPP row: broadcast lane J of each row to its row.
+#define MK_DPPMASK " row_mask:0xf bank_mask:0xf"
+#define MK_FMAC(a, s, m, l) "v_fmac_f64_dpp %" #a ", %" #s ", %" #m " row_newbcast:%" #l MK_DPPMASK "\n\t"
+
 template <>
 struct Group<16> {
+    // compiler-scheduled broadcast (v_mov_b64_dpp); the compiler pads hazards for values IT wrote
     template <int J>
     static __device__ __forceinline__ double bcast(double v)
     {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + J, 0xf, 0xf, false); // row_newbcast:J
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + J, 0xf, 0xf, false);
-        return __hiloint2double(hi, lo);
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); // row_newbcast:J
+    }
+    // broadcast of a value that an asm statement may just have written
+    template <int J>
+    static __device__ __forceinline__ double bcast_safe(double v)
+    {
+        double o;
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2" MK_DPPMASK : "=v"(o) : "v"(v), "n"(J));
+        return o;
+    }
+    // ---- fixed-arity fused broadcast-FMA statements: a_i += bcast<L_i>(s_i) * m
+    template <int L0>
+    static __device__ __forceinline__ void f1(double &a0, double s0, double m)
+    {
+        asm volatile("s_nop 1\n\t" MK_FMAC(0, 1, 2, 3) : "+v"(a0) : "v"(s0), "v"(m), "n"(L0));
+    }
+    template <int L0, int L1>
+    static __device__ __forceinline__ void f2(double &a0, double &a1, double s0, double s1, double m)
+    {
+        asm volatile("s_nop 1\n\t" MK_FMAC(0, 2, 4, 5) MK_FMAC(1, 3, 4, 6)
+                     : "+v"(a0), "+v"(a1)
+                     : "v"(s0), "v"(s1), "v"(m), "n"(L0), "n"(L1));
+    }
+    template <int L0, int L1, int L2>
+    static __device__ __forceinline__ void f3(double &a0, double &a1, double &a2, double s0, double s1, double s2,
+                                              double m)
+    {
+        asm volatile("s_nop 1\n\t" MK_FMAC(0, 3, 6, 7) MK_FMAC(1, 4, 6, 8) MK_FMAC(2, 5, 6, 9)
+                     : "+v"(a0), "+v"(a1), "+v"(a2)
+                     : "v"(s0), "v"(s1), "v"(s2), "v"(m), "n"(L0), "n"(L1), "n"(L2));
+    }
+    template <int L0, int L1, int L2, int L3>
+    static __device__ __forceinline__ void f4(double &a0, double &a1, double &a2, double &a3, double s0, double s1,
+                                              double s2, double s3, double m)
+    {
+        asm volatile("s_nop 1\n\t" MK_FMAC(0, 4, 8, 9) MK_FMAC(1, 5, 8, 10) MK_FMAC(2, 6, 8, 11) MK_FMAC(3, 7, 8, 12)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(m), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
+    }
+    template <int L0, int L1, int L2, int L3, int L4>
+    static __device__ __forceinline__ void f5(double &a0, double &a1, double &a2, double &a3, double &a4, double s0,
+                                              double s1, double s2, double s3, double s4, double m)
+    {
+        asm volatile("s_nop 1\n\t" MK_FMAC(0, 5, 10, 11) MK_FMAC(1, 6, 10, 12) MK_FMAC(2, 7, 10, 13)
+                         MK_FMAC(3, 8, 10, 14) MK_FMAC(4, 9, 10, 15)
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4)
+                     : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(m), "n"(L0), "n"(L1), "n"(L2), "n"(L3),
+                       "n"(L4));
+    }
+    // acc[c] += bcast<J>(src[c]) * mul, c in [C0, C1)
+    template <int J, int C0, int C1, int n>
+    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
+    {
+        if constexpr (C1 - C0 >= 5) {
+            f5<J, J, J, J, J>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], acc[C0 + 4], src[C0], src[C0 + 1],
+                              src[C0 + 2], src[C0 + 3], src[C0 + 4], mul);
+            axpy_lane<J, C0 + 5, C1, n>(acc, src, mul);
+        } else if constexpr (C1 - C0 == 4) {
+            f4<J, J, J, J>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], src[C0], src[C0 + 1], src[C0 + 2],
+                           src[C0 + 3], mul);
+        } else if constexpr (C1 - C0 == 3) {
+            f3<J, J, J>(acc[C0], acc[C0 + 1], acc[C0 + 2], src[C0], src[C0 + 1], src[C0 + 2], mul);
+        } else if constexpr (C1 - C0 == 2) {
+            f2<J, J>(acc[C0], acc[C0 + 1], src[C0], src[C0 + 1], mul);
+        } else if constexpr (C1 - C0 == 1) {
+            f1<J>(acc[C0], src[C0], mul);
+        }
+    }
+    // acc[c] += bcast<c>(src) * mul, c in [C0, C1)
+    template <int C0, int C1, int n>
+    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
+    {
+        if constexpr (C1 - C0 >= 5) {
+            f5<C0, C0 + 1, C0 + 2, C0 + 3, C0 + 4>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], acc[C0 + 4], src,
+                                                   src, src, src, src, mul);
+            axpy_col<C0 + 5, C1, n>(acc, src, mul);
+        } else if constexpr (C1 - C0 == 4) {
+            f4<C0, C0 + 1, C0 + 2, C0 + 3>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], src, src, src, src, mul);
+        } else if constexpr (C1 - C0 == 3) {
+            f3<C0, C0 + 1, C0 + 2>(acc[C0], acc[C0 + 1], acc[C0 + 2], src, src, src, mul);
+        } else if constexpr (C1 - C0 == 2) {
+            f2<C0, C0 + 1>(acc[C0], acc[C0 + 1], src, src, mul);
+        } else if constexpr (C1 - C0 == 1) {
+            f1<C0>(acc[C0], src, mul);
+        }
+    }
+    // acc += bcast<J>(src) * mul (single)
+    template <int J>
+    static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
+    {
+        f1<J>(acc, src, mul);
+    }
+    // per-group mask of lanes whose predicate holds (bit l = lane l of this group)
+    static __device__ __forceinline__ unsigned group_ballot(bool pred)
+    {
+        const unsigned long long m = __ballot(pred);
+        return (unsigned)(m >> ((threadIdx.x & 63) & ~15)) & 0xffffu;
     }
 };
 
-// one model per wavefront: lane J -> SGPR pair.
 template <>
 struct Group<64> {
     template <int J>
@@ -67,6 +175,33 @@ struct Group<64> {
         int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
         return __hiloint2double(hi, lo);
     }
+    template <int J>
+    static __device__ __forceinline__ double bcast_safe(double v)
+    {
+        return bcast<J>(v);
+    }
+    template <int J, int C0, int C1, int n>
+    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
+    {
+        sfor<C0, C1>(MK_LAMBDA(c) {
+            constexpr int cc = decltype(c)::value;
+            acc[cc] = fma(bcast<J>(src[cc]), mul, acc[cc]);
+        });
+    }
+    template <int C0, int C1, int n>
+    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
+    {
+        sfor<C0, C1>(MK_LAMBDA(c) {
+            constexpr int cc = decltype(c)::value;
+            acc[cc] = fma(bcast<cc>(src), mul, acc[cc]);
+        });
+    }
+    template <int J>
+    static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
+    {
+        acc = fma(bcast<J>(src), mul, acc);
+    }
+    static __device__ __forceinline__ unsigned long long group_ballot(bool pred) { return __ballot(pred); }
 };
 
 template <int n>
@@ -99,6 +234,86 @@ __device__ __forceinline__ void load_row(const double *src, double (&row)[n])
     }
 }
 
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (the same refinement LLVM's f64 division uses,
+// without its scaling/fix-up instructions: x is an O(1) variance here, never denormal).
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// ---------------------------------------------------------------- coalesced n x n block I/O
+// A model's covariance at one time step is one contiguous n*n*8-byte block in HBM, but lane r
+// holds row r.  Storing rows directly makes every store instruction touch ~n scattered 16-byte
+// pieces per model (measured: the filter ran at 2.5 TB/s, store-issue bound).  Instead the
+// group's block is transposed through LDS (wave-private, no workgroup barrier): lanes write
+// their rows, then lane l moves the 16-byte chunks l, l+G, l+2G, ... so that one store/load
+// instruction covers G*16 contiguous bytes per model.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS-only ("local") fences: a generic fence would also pin private arrays to scratch memory
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
+
+template <int n, int G>
+struct BlockIO {
+    static constexpr int NN = n * n;
+    static constexpr bool V2 = (NN % 2 == 0);            // 16-byte chunks when the block allows it
+    static constexpr int CH = V2 ? NN / 2 : NN;          // chunks per block
+    static constexpr int PER = (CH + G - 1) / G;         // chunks per lane
+    static constexpr int STRIDE = ((NN * 8 + 255) / 256) * 256 / 8; // doubles between groups' LDS buffers
+    static constexpr int LDS_DOUBLES = (256 / G) * STRIDE;
+    using chunk_t = typename std::conditional<V2, v2d, double>::type;
+
+    // rows (registers) -> LDS -> HBM block
+    static __device__ __forceinline__ void store(double *lds, double *gblock, const double (&row)[n], int lane,
+                                                 bool rowok, bool live)
+    {
+        wave_lds_sync();
+        if (rowok) store_row<n>(lds + lane * n, row);
+        wave_lds_sync();
+        chunk_t *g = reinterpret_cast<chunk_t *>(gblock);
+        const chunk_t *l = reinterpret_cast<const chunk_t *>(lds);
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int qi = lane + m * G;
+            if (qi < CH && live) g[qi] = l[qi];
+        }
+    }
+    // HBM block -> registers (issue early; the data is consumed one time step later)
+    static __device__ __forceinline__ void load_issue(const double *gblock, chunk_t (&buf)[PER], int lane)
+    {
+        const chunk_t *g = reinterpret_cast<const chunk_t *>(gblock);
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int qi = lane + m * G;
+            buf[m] = g[qi < CH ? qi : CH - 1]; // clamped, branch-free (keeps buf in registers)
+        }
+    }
+    // registers -> LDS -> row r
+    static __device__ __forceinline__ void load_finish(double *lds, const chunk_t (&buf)[PER], double (&row)[n],
+                                                       int lane, int r)
+    {
+        wave_lds_sync();
+        chunk_t *l = reinterpret_cast<chunk_t *>(lds);
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int qi = lane + m * G;
+            if (qi < CH) l[qi] = buf[m];
+        }
+        wave_lds_sync();
+        load_row<n>(lds + r * n, row);
+    }
+};
+
 constexpr double kLn2 = 0.693147180559945309417232121458;
 constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 
@@ -112,6 +327,7 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     static_assert(n <= G, "state dimension must fit the lane group");
     using Gp = Group<G>;
     constexpr int GPB = 256 / G; // models per 256-thread workgroup
+    constexpr bool HOIST = (N * K <= 32); // keep Z's loading block replicated in registers
     const int lane = threadIdx.x % G;
     long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
     const bool live = inst < a.B;
@@ -128,11 +344,22 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     const double q_r = a.q[inst * n + r];
     double phic[n]; // diag(Phi), replicated in every lane of the group
     sfor<0, n>(MK_LAMBDA(c) { phic[c] = Gp::template bcast<decltype(c)::value>(phi_r); });
+    double qd[n]; // row r of Q = diag(q)
+#pragma unroll
+    for (int c = 0; c < n; ++c) qd[c] = (c == r) ? q_r : 0.0;
     const int jr = lane < N ? lane : N - 1;
     double gam[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
     const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
+    double Gh[HOIST ? N : 1][K]; // Gh[j][k] = loadings[j,k] in every lane
+    if constexpr (HOIST) {
+        sfor<0, N>(MK_LAMBDA(j) {
+            sfor<0, K>(MK_LAMBDA(k) {
+                Gh[decltype(j)::value][decltype(k)::value] = Gp::template bcast<decltype(j)::value>(gam[decltype(k)::value]);
+            });
+        });
+    }
 
     // initial state (run_filter defaults, kalmanfilter.py:747-750)
     double x = a.x0 ? a.x0[inst * n + r] : 0.0;
@@ -140,61 +367,86 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 #pragma unroll
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
 
+    using BIO = BlockIO<n, G>;
+    __shared__ __attribute__((aligned(16))) double lds_io[BIO::LDS_DOUBLES];
+    double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE; // this model's staging buffer
+
     const double *yp = a.obs + rec * T * N + jr; // lane j streams series j
     double ynext = yp[0];
     double sum_sig = 0.0, sum_det = 0.0;
     long nobs = 0, sc = 0;
     unsigned flags = 0;
+    // running output pointers (row r of step t)
+    const long vec0 = inst * T * n + r;
+    double *pXp = a.Xp ? a.Xp + vec0 : nullptr;
+    double *pF = a.F ? a.F + vec0 : nullptr;
+    double *pPp = a.Pp ? a.Pp + inst * T * n * n : nullptr; // block of step t
+    double *pPf = a.Pf ? a.Pf + inst * T * n * n : nullptr;
 
     for (long t = 0; t < T; ++t) {
         const double y = ynext;
         if (t + 1 < T) ynext = yp[(t + 1) * N]; // prefetch next step's observation
+        // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
+        const auto vm = Gp::group_ballot(lane < N && isfinite(y));
 
         // ---- predict (:318-331; Phi diagonal) ----
         x = phi_r * x;
 #pragma unroll
-        for (int c = 0; c < n; ++c) P[c] = (phi_r * P[c]) * phic[c] + (c == r ? q_r : 0.0);
-        const long row_t = (inst * T + t) * n + r;
-        if (a.Xp && st) a.Xp[row_t] = x;                 // :332
-        if (a.Pp && st) store_row<n>(a.Pp + row_t * n, P); // :333
+        for (int c = 0; c < n; ++c) P[c] = fma(phi_r * P[c], phic[c], qd[c]);
+        if (pXp) {
+            if (st) *pXp = x; // :332
+            pXp += n;
+        }
+        if (pPp) {
+            BIO::store(lds, pPp, P, lane, rowok, live); // :333
+            pPp += n * n;
+        }
 
         // ---- sequential scalar updates (:341-378), observations in ascending series order ----
         double sigma = 0.0, fmant = 1.0;
-        int fexp = 0, cnt = 0;
+        int fexp = 0;
         sfor<0, N>(MK_LAMBDA(jc) {
             constexpr int j = decltype(jc)::value;
-            const double yj = Gp::template bcast<j>(y);
-            if (isfinite(yj)) { // uniform within the model's lane group (:657 masks NaN and inf)
-                double g[K];
-                sfor<0, K>(MK_LAMBDA(k) { g[k] = Gp::template bcast<j>(gam[k]); });
-                // innovation v = y_j - Z_j x,  Z_j = e_j + sum_k g_k e_{N+k}   (:344-347)
-                double zx = Gp::template bcast<j>(x);
-                sfor<0, K>(MK_LAMBDA(k) { zx = fma(g[k], Gp::template bcast<N + decltype(k)::value>(x), zx); });
-                const double v = yj - zx;
+            if ((vm >> j) & 1) { // uniform within the model's lane group
+                // innovation (:344-347): every lane l < N forms v_l = y_l - Z_l x with ITS loadings;
+                // lane j's value is the one used
+                double vl = y - x;
+                sfor<0, K>(MK_LAMBDA(k) {
+                    constexpr int kk = decltype(k)::value;
+                    vl = fma(-gam[kk], Gp::template bcast<N + kk>(x), vl);
+                });
+                const double v = Gp::template bcast<j>(vl);
                 // d = P Z_j^T : lane r computes d_r from its own row (:349-357)
                 double dr = P[j];
-                sfor<0, K>(MK_LAMBDA(k) { dr = fma(P[N + decltype(k)::value], g[k], dr); });
-                double d[n]; // all-gather d across the group
-                sfor<0, n>(MK_LAMBDA(c) { d[c] = Gp::template bcast<decltype(c)::value>(dr); });
-                // innovation variance f = R_j + Z_j d   (:359-362)
-                double zd = d[j];
-                sfor<0, K>(MK_LAMBDA(k) { zd = fma(g[k], d[N + decltype(k)::value], zd); });
-                const double f = Gp::template bcast<j>(rvar) + zd;
-                const double rf = 1.0 / f;
+                sfor<0, K>(MK_LAMBDA(k) {
+                    constexpr int kk = decltype(k)::value;
+                    double g;
+                    if constexpr (HOIST) g = Gh[j][kk];
+                    else g = Gp::template bcast<j>(gam[kk]);
+                    dr = fma(P[N + kk], g, dr);
+                });
+                // innovation variance f = R_j + Z_j d (:359-362), formed at lane j from d_j, d_{N+k}
+                double fl = rvar + dr;
+                sfor<0, K>(MK_LAMBDA(k) {
+                    constexpr int kk = decltype(k)::value;
+                    fl = fma(gam[kk], Gp::template bcast<N + kk>(dr), fl);
+                });
+                const double f = Gp::template bcast<j>(fl);
+                const double rf = rcp_nr(f);
                 const double kr = dr * rf; // Kalman gain element r (:364-366)
-#pragma unroll
-                for (int c = 0; c < n; ++c) P[c] = fma(-kr, d[c], P[c]); // P -= k k^T f (:368-372)
-                x = fma(kr, v, x);                                       // :374-375
-                sigma = fma(v * v, rf, sigma);                           // :377
+                // P -= k k^T f (:368-372): P[r][c] += d_c * (-k_r), d_c broadcast from lane c
+                Gp::template axpy_col<0, n, n>(P, dr, -kr);
+                x = fma(kr, v, x);             // :374-375
+                sigma = fma(v * v, rf, sigma); // :377
                 // detf += log f (:378): accumulate prod f as mantissa * 2^exp, one log per step
                 fmant *= f;
                 fexp += __builtin_amdgcn_frexp_exp(fmant);
                 fmant = __builtin_amdgcn_frexp_mant(fmant);
                 if (!(f > 0.0)) flags |= MK_FLAG_NONPOSITIVE_F;
-                ++cnt;
             }
         });
 
+        const int cnt = __popcll((unsigned long long)vm);
         if (cnt > 0) { // :380-382 compressed bookkeeping
             const double detf = fma((double)fexp, kLn2, log(fmant));
             if (a.sigmas && lead) a.sigmas[inst * T + sc] = sigma;
@@ -207,8 +459,14 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         }
         if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
 
-        if (a.F && st) a.F[row_t] = x;                   // :389
-        if (a.Pf && st) store_row<n>(a.Pf + row_t * n, P); // :390
+        if (pF) {
+            if (st) *pF = x; // :389
+            pF += n;
+        }
+        if (pPf) {
+            BIO::store(lds, pPf, P, lane, rowok, live); // :390
+            pPf += n * n;
+        }
     }
 
     // zero tail of the compressed arrays (np.zeros init, :307-308)
@@ -228,60 +486,16 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 // =====================================================================================
 // RTS smoother                                               (kalmanfilter.py:403-476)
 //   Pp[t+1] = Phi Pf[t] Phi + Q and Xp[t+1] = Phi F[t] are recomputed (Phi diagonal), so only
-//   F and Pf are re-read.  J = Pf Phi^T Pp^{-1} by Cholesky (Pp is SPD whenever q > 0; the
-//   reference's pinv (:455) coincides with the inverse there); lane i solves for ROW i of J.
+//   F and Pf are re-read.  J = Pf Phi^T Pp^{-1} through an LDL^T factorisation of Pp (SPD
+//   whenever q > 0, where the reference's pinv (:455) is the inverse); lane i solves for ROW i of J.
+//   The factor is DISTRIBUTED: lane c keeps L(c, 0..c-1) in place of its row of A.
 // =====================================================================================
-template <int n, bool IN_LDS>
-struct LStore;
-
-template <int n>
-struct LStore<n, false> { // replicated lower-triangular factor in registers
-    double v[n * (n + 1) / 2];
-    __device__ __forceinline__ LStore(double *, int) {}
-    template <int C, int J>
-    __device__ __forceinline__ void set(double x, double /*own*/, int /*lane*/)
-    {
-        v[C * (C + 1) / 2 + J] = x;
-    }
-    template <int C, int J>
-    __device__ __forceinline__ double get() const
-    {
-        return v[C * (C + 1) / 2 + J];
-    }
-    __device__ __forceinline__ void publish() {}
-    static constexpr bool per_lane_write = false;
-};
-
-template <int n>
-struct LStore<n, true> { // one model per wavefront: factor lives in LDS, read by broadcast
-    double *base;
-    __device__ __forceinline__ LStore(double *lds, int wave) : base(lds + wave * (n * (n + 1) / 2)) {}
-    template <int C, int J>
-    __device__ __forceinline__ double get() const
-    {
-        return base[C * (C + 1) / 2 + J];
-    }
-    // lane `lane` (> J) writes its own L(lane, J)
-    template <int J>
-    __device__ __forceinline__ void set_own(double own, int lane)
-    {
-        if (lane > J && lane < n) base[lane * (lane + 1) / 2 + J] = own;
-    }
-    __device__ __forceinline__ void publish()
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-};
-
 template <int n, int G>
 __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
 {
     static_assert(n <= G, "state dimension must fit the lane group");
     using Gp = Group<G>;
     constexpr int GPB = 256 / G;
-    constexpr bool LDSL = (G == 64);
     const int lane = threadIdx.x % G;
     long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
     const bool live = inst < a.B;
@@ -291,40 +505,47 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     const bool st = live && rowok;
     const long T = a.T;
 
-    __shared__ double lds_L[LDSL ? (256 / 64) * (n * (n + 1) / 2) : 1];
-    LStore<n, LDSL> L(lds_L, threadIdx.x / 64);
-
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
     double phic[n];
     sfor<0, n>(MK_LAMBDA(c) { phic[c] = Gp::template bcast<decltype(c)::value>(phi_r); });
 
+    using BIO = BlockIO<n, G>;
+    __shared__ __attribute__((aligned(16))) double lds_io[BIO::LDS_DOUBLES];
+    double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE;
+
     // last step: smoothed = filtered (:450-451)
-    long row_t = (inst * T + (T - 1)) * n + r;
-    double xs = a.F[row_t];
+    const long vecT = (inst * T + (T - 1)) * n + r;
+    const double *pF = a.F + vecT;
+    const double *pPf = a.Pf + (inst * T + (T - 1)) * n * n; // block of step t
+    double *pS = a.S ? a.S + vecT : nullptr;
+    double *pPs = a.Ps ? a.Ps + (inst * T + (T - 1)) * n * n : nullptr;
+    double xs = *pF;
     double Psn[n];
-    load_row<n>(a.Pf + row_t * n, Psn);
-    if (a.S && st) a.S[row_t] = xs;
-    if (a.Ps && st) store_row<n>(a.Ps + row_t * n, Psn);
+    typename BIO::chunk_t pre[BIO::PER];
+    BIO::load_issue(pPf, pre, lane);
+    BIO::load_finish(lds, pre, Psn, lane, r);
+    if (pS && st) *pS = xs;
+    if (pPs) BIO::store(lds, pPs, Psn, lane, rowok, live);
     unsigned flags = 0;
 
-    double Pf[n], xf = 0.0;
+    double xf = 0.0;
     if (T >= 2) { // software prefetch of the next (earlier) time step
-        const long rt = (inst * T + (T - 2)) * n + r;
-        load_row<n>(a.Pf + rt * n, Pf);
-        xf = a.F[rt];
+        pF -= n;
+        pPf -= n * n;
+        BIO::load_issue(pPf, pre, lane);
+        xf = *pF;
     }
 
     for (long t = T - 2; t >= 0; --t) {
-        row_t = (inst * T + t) * n + r;
         double Pfc[n];
-#pragma unroll
-        for (int c = 0; c < n; ++c) Pfc[c] = Pf[c];
+        BIO::load_finish(lds, pre, Pfc, lane, r);
         const double xfc = xf;
         if (t >= 1) {
-            const long rt = row_t - n;
-            load_row<n>(a.Pf + rt * n, Pf);
-            xf = a.F[rt];
+            pF -= n;
+            pPf -= n * n;
+            BIO::load_issue(pPf, pre, lane);
+            xf = *pF;
         }
 
         // W = Pf Phi (column scaling); A = Pp[t+1] = Phi Pf Phi + Q (row r)
@@ -335,82 +556,73 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
             A[c] = fma(phi_r, W[c], (c == r ? q_r : 0.0));
         }
 
-        // ---- Cholesky A = L L^T, right-looking; every lane keeps the whole factor ----
-        double inv[n];
+        // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
+        double dinv[n];
         sfor<0, n>(MK_LAMBDA(jc) {
             constexpr int j = decltype(jc)::value;
-            const double piv = Gp::template bcast<j>(A[j]);
+            const double piv = Gp::template bcast_safe<j>(A[j]); // d_j
             if (!(piv > 0.0)) flags |= MK_FLAG_NOT_SPD;
-            const double ij = 1.0 / sqrt(piv);
-            inv[j] = ij;
-            const double lr = A[j] * ij; // own element of column j: L(r, j) (A symmetric)
-            if constexpr (LDSL) L.template set_own<j>(lr, lane);
-            sfor<j + 1, n>(MK_LAMBDA(cc) {
-                constexpr int c = decltype(cc)::value;
-                const double lc = Gp::template bcast<j>(A[c]) * ij; // L(c, j) replicated
-                if constexpr (!LDSL) L.template set<c, j>(lc, lr, lane);
-                A[c] = fma(-lr, lc, A[c]);
-            });
+            const double ij = rcp_nr(piv);
+            dinv[j] = ij;
+            const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
+            // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
+            Gp::template axpy_lane<j, j + 1, n, n>(A, A, -lr);
+            A[j] = lr;
         });
-        L.publish();
 
         // ---- lane i solves A z = W_i  (row i of J = Pf Phi^T A^{-1}, :458-460) ----
         double z[n];
 #pragma unroll
         for (int c = 0; c < n; ++c) z[c] = W[c];
-        sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b
+        sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
             constexpr int k = decltype(kc)::value;
-            z[k] *= inv[k];
-            sfor<k + 1, n>(MK_LAMBDA(cc) {
-                constexpr int c = decltype(cc)::value;
-                z[c] = fma(-L.template get<c, k>(), z[k], z[c]);
-            });
+            Gp::template axpy_col<k + 1, n, n>(z, A[k], -z[k]);
         });
-        sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y
+#pragma unroll
+        for (int c = 0; c < n; ++c) z[c] *= dinv[c]; // D^{-1}
+        sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y;  z[c] -= L(k,c) z_k, L(k,c) lives in lane k
             constexpr int k = decltype(kc)::value;
-            z[k] *= inv[k];
-            sfor<0, k>(MK_LAMBDA(cc) {
-                constexpr int c = decltype(cc)::value;
-                z[c] = fma(-L.template get<k, c>(), z[k], z[c]);
-            });
+            Gp::template axpy_lane<k, 0, k, n>(z, A, -z[k]);
         });
         // z = J[r, :]
 
         // ---- smoothed mean (:461-464): xs[t] = F[t] + J (xs[t+1] - Phi F[t]) ----
         const double delta = xs - phi_r * xfc;
-        double acc = xfc;
-        sfor<0, n>(MK_LAMBDA(c) {
-            acc = fma(z[decltype(c)::value], Gp::template bcast<decltype(c)::value>(delta), acc);
+        double acc0 = xfc, acc1 = 0.0;
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
+            else Gp::template fmac<c>(acc1, delta, z[c]);
         });
-        xs = acc;
+        xs = acc0 + acc1;
 
         // ---- smoothed covariance (:465-474): Ps[t] = Pf[t] + J (Ps[t+1] - Pp[t+1]) J^T ----
         double D[n];
 #pragma unroll
         for (int c = 0; c < n; ++c) D[c] = Psn[c] - fma(phi_r, W[c], (c == r ? q_r : 0.0));
-        double V[n]; // V = J D (row r)
+        double V[n]; // V = J D (row r):  V[c] += J[r][k] * D[k][c], D[k][:] broadcast from lane k
 #pragma unroll
         for (int c = 0; c < n; ++c) V[c] = 0.0;
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
-            sfor<0, n>(MK_LAMBDA(cc) {
-                constexpr int c = decltype(cc)::value;
-                V[c] = fma(z[k], Gp::template bcast<k>(D[c]), V[c]);
-            });
+            Gp::template axpy_lane<k, 0, n, n>(V, D, z[k]);
         });
-        sfor<0, n>(MK_LAMBDA(cc) { // Ps[r, c] = Pf[r, c] + V[r, :] . J[c, :]
-            constexpr int c = decltype(cc)::value;
-            double s = Pfc[c];
-            sfor<0, n>(MK_LAMBDA(kc) {
-                constexpr int k = decltype(kc)::value;
-                s = fma(V[k], Gp::template bcast<c>(z[k]), s);
-            });
-            Psn[c] = s;
+        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
+#pragma unroll
+        for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
+        sfor<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_col<0, n, n>(Psn, z[k], V[k]);
         });
-        L.publish(); // all reads of L done before the next step overwrites it
 
-        if (a.S && st) a.S[row_t] = xs;
-        if (a.Ps && st) store_row<n>(a.Ps + row_t * n, Psn);
+        if (pS) {
+            pS -= n;
+            if (st) *pS = xs;
+        }
+        if (pPs) {
+            pPs -= n * n;
+            BIO::store(lds, pPs, Psn, lane, rowok, live);
+        }
     }
     if (a.status && live && lane == 0 && flags) atomicOr(a.status + inst, flags);
 }
