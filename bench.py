@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loglik-only", action="store_true", help="time the solver objective (no state outputs)")
+    ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"],
+                    help="memory layout of the per-step arrays (see BatchedKalman)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +115,7 @@ def main():
     B, N, K, T = args.batch, args.series, args.factors, args.T
     n = N + K
     d = make_dfm_batch_torch(B, N, K, T, seed=2000 + rank, device=dev)
-    kf = BatchedKalman(local_rank)
+    kf = BatchedKalman(local_rank, layout=args.layout)
     kf.set_observations(d["obs"]).set_loadings(d["loadings"])
     outputs = () if args.loglik_only else ("F", "Pf", "Xp", "Pp", "S", "Ps")
     bufs = kf._alloc_outputs(B, list(outputs))
@@ -189,7 +191,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: batch=%d synthetic %d-series/%d-factor DFMs per GPU, "
                                    "T=%d, fp64%s" % (B, N, K, T, ", loglik only" if args.loglik_only else
                                                      ", filter+smoother, outputs F,Pf,Xp,Pp,S,Ps"),
-                       "batch_per_gpu": B, "series": N, "factors": K, "T": T, "parallelism": "dp%d" % world},
+                       "batch_per_gpu": B, "series": N, "factors": K, "T": T, "parallelism": "dp%d" % world,
+                       "layout": args.layout},
             "models_per_s": models_per_s,
             "models_per_s_per_gpu": models_per_s / world,
             "roofline": roofline,

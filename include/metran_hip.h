@@ -22,7 +22,9 @@
  *   - all launches are asynchronous on the context's stream (mk_set_stream / mk_sync).
  *   - layouts are the reference's, with a leading batch axis, row-major double:
  *       obs [R,T,N] (NaN or +-inf = missing), phi/q [B,n], loadings [R,N,K], obsvar [R,N],
- *       F/Xp/S [B,T,n], Pf/Pp/Ps [B,T,n,n], sigmas/detfs [B,T], n = N + K.
+ *       F/Xp/S [B,T,n], Pf/Pp/Ps [B,T,n,n], sigmas/detfs [B,T], n = N + K;
+ *     optionally TIME-MAJOR ([T,B,...], mk_outputs.time_major / mk_problem.obs_time_major): the
+ *     same per-model [T,...] arrays, interleaved so that one time step of all models is contiguous.
  *     B = number of filter instances, R = number of observation records; instance i reads
  *     record i % R (so the P+1 finite-difference evaluations of one model, or S parameter sets
  *     per model, share one uploaded observation record).
@@ -72,6 +74,7 @@ typedef struct mk_problem {
     const double *d_obsvar;    /* [R,N] or NULL = zeros                   (metran.py:382-384) */
     const double *d_x0;        /* [B,n] or NULL = zeros       (kalmanfilter.py:747-748) */
     const double *d_P0;        /* [B,n,n] or NULL = identity  (kalmanfilter.py:749-750) */
+    int64_t obs_time_major;    /* 0: d_obs is [R,T,N] (reference layout); 1: d_obs is [T,R,N] */
 } mk_problem;
 
 /* Outputs; any pointer may be NULL (that output is skipped and costs no HBM traffic).
@@ -89,6 +92,10 @@ typedef struct mk_outputs {
     double *d_S;           /* [B,T,n]   smoothed_state_means                    (:461-464) */
     double *d_Ps;          /* [B,T,n,n] smoothed_state_covariances              (:465-474) */
     uint32_t *d_status;    /* [B] MK_FLAG_* bits, or NULL                                  */
+    int64_t time_major;    /* 0: per-step arrays are [B,T,...] (reference layout with a leading batch
+                              axis); 1: they are [T,B,...] -- all models' step-t blocks contiguous, the
+                              HBM-friendly layout (a [B,T,...] strided view of it costs nothing).
+                              Applies to d_sigmas, d_detfs, d_F, d_Pf, d_Xp, d_Pp, d_S, d_Ps.        */
 } mk_outputs;
 
 /* ---- library / context ------------------------------------------------------------------ */

@@ -41,6 +41,7 @@ class Problem(Structure):
         ("d_obsvar", c_void_p),
         ("d_x0", c_void_p),
         ("d_P0", c_void_p),
+        ("obs_time_major", c_int64),
     ]
 
 
@@ -59,6 +60,7 @@ class Outputs(Structure):
         ("d_S", c_void_p),
         ("d_Ps", c_void_p),
         ("d_status", c_void_p),
+        ("time_major", c_int64),
     ]
 
 

@@ -217,6 +217,10 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.R = p->n_records;
     a.T = p->T;
     a.warmup = p->warmup;
+    a.bs = o->time_major ? 1 : p->T;
+    a.ts = o->time_major ? p->n_instances : 1;
+    a.obs_bs = p->obs_time_major ? 1 : p->T;
+    a.obs_ts = p->obs_time_major ? p->n_records : 1;
     a.obs = p->d_obs;
     a.phi = p->d_phi;
     a.q = p->d_q;
@@ -249,6 +253,8 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     mk::SmootherArgs a;
     a.B = p->n_instances;
     a.T = p->T;
+    a.bs = o->time_major ? 1 : p->T;
+    a.ts = o->time_major ? p->n_instances : 1;
     a.phi = p->d_phi;
     a.q = p->d_q;
     a.F = o->d_F;

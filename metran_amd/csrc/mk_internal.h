@@ -23,6 +23,8 @@ namespace mk {
 
 struct FilterArgs {
     long B, R, T, warmup;
+    long bs, ts;         // state/bookkeeping outputs: block (b, t) at index b*bs + t*ts
+    long obs_bs, obs_ts; // observations: record (r, t) at row r*obs_bs + t*obs_ts
     const double *obs, *phi, *q, *loadings, *obsvar, *x0, *P0;
     double *mle, *sigmas, *detfs;
     long long *sigmacount;
@@ -32,6 +34,7 @@ struct FilterArgs {
 
 struct SmootherArgs {
     long B, T;
+    long bs, ts;
     const double *phi, *q;
     const double *F, *Pf;
     double *S, *Ps;

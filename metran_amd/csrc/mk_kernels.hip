@@ -371,21 +371,24 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     __shared__ __attribute__((aligned(16))) double lds_io[BIO::LDS_DOUBLES];
     double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE; // this model's staging buffer
 
-    const double *yp = a.obs + rec * T * N + jr; // lane j streams series j
+    const double *yp = a.obs + rec * a.obs_bs * N + jr; // lane j streams series j
+    const long ystep = a.obs_ts * N;
     double ynext = yp[0];
     double sum_sig = 0.0, sum_det = 0.0;
     long nobs = 0, sc = 0;
     unsigned flags = 0;
     // running output pointers (row r of step t)
-    const long vec0 = inst * T * n + r;
+    // (b, t) lives at block index b * bs + t * ts: (bs, ts) = (T, 1) model-major [B,T,..] or (1, B) time-major [T,B,..]
+    const long vstep = a.ts * n, bstep = a.ts * n * n;
+    const long vec0 = inst * a.bs * n + r;
     double *pXp = a.Xp ? a.Xp + vec0 : nullptr;
     double *pF = a.F ? a.F + vec0 : nullptr;
-    double *pPp = a.Pp ? a.Pp + inst * T * n * n : nullptr; // block of step t
-    double *pPf = a.Pf ? a.Pf + inst * T * n * n : nullptr;
+    double *pPp = a.Pp ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
+    double *pPf = a.Pf ? a.Pf + inst * a.bs * n * n : nullptr;
 
     for (long t = 0; t < T; ++t) {
         const double y = ynext;
-        if (t + 1 < T) ynext = yp[(t + 1) * N]; // prefetch next step's observation
+        if (t + 1 < T) ynext = yp[(t + 1) * ystep]; // prefetch next step's observation
         // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
         const auto vm = Gp::group_ballot(lane < N && isfinite(y));
 
@@ -395,11 +398,11 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         for (int c = 0; c < n; ++c) P[c] = fma(phi_r * P[c], phic[c], qd[c]);
         if (pXp) {
             if (st) *pXp = x; // :332
-            pXp += n;
+            pXp += vstep;
         }
         if (pPp) {
             BIO::store(lds, pPp, P, lane, rowok, live); // :333
-            pPp += n * n;
+            pPp += bstep;
         }
 
         // ---- sequential scalar updates (:341-378), observations in ascending series order ----
@@ -449,8 +452,8 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         const int cnt = __popcll((unsigned long long)vm);
         if (cnt > 0) { // :380-382 compressed bookkeeping
             const double detf = fma((double)fexp, kLn2, log(fmant));
-            if (a.sigmas && lead) a.sigmas[inst * T + sc] = sigma;
-            if (a.detfs && lead) a.detfs[inst * T + sc] = detf;
+            if (a.sigmas && lead) a.sigmas[inst * a.bs + sc * a.ts] = sigma;
+            if (a.detfs && lead) a.detfs[inst * a.bs + sc * a.ts] = detf;
             if (sc >= a.warmup) { // get_mle: detfs[warmup:], sigmas[warmup:] are COMPRESSED indices (:563-564)
                 sum_det += detf;
                 sum_sig += sigma;
@@ -461,19 +464,19 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 
         if (pF) {
             if (st) *pF = x; // :389
-            pF += n;
+            pF += vstep;
         }
         if (pPf) {
             BIO::store(lds, pPf, P, lane, rowok, live); // :390
-            pPf += n * n;
+            pPf += bstep;
         }
     }
 
     // zero tail of the compressed arrays (np.zeros init, :307-308)
     if (live) {
         for (long i = sc + lane; i < T; i += G) {
-            if (a.sigmas) a.sigmas[inst * T + i] = 0.0;
-            if (a.detfs) a.detfs[inst * T + i] = 0.0;
+            if (a.sigmas) a.sigmas[inst * a.bs + i * a.ts] = 0.0;
+            if (a.detfs) a.detfs[inst * a.bs + i * a.ts] = 0.0;
         }
     }
     if (lead) {
@@ -515,11 +518,13 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE;
 
     // last step: smoothed = filtered (:450-451)
-    const long vecT = (inst * T + (T - 1)) * n + r;
+    const long vstep = a.ts * n, bstep = a.ts * n * n;
+    const long blkT = inst * a.bs + (T - 1) * a.ts; // block index of (inst, T-1)
+    const long vecT = blkT * n + r;
     const double *pF = a.F + vecT;
-    const double *pPf = a.Pf + (inst * T + (T - 1)) * n * n; // block of step t
+    const double *pPf = a.Pf + blkT * n * n; // block of step t
     double *pS = a.S ? a.S + vecT : nullptr;
-    double *pPs = a.Ps ? a.Ps + (inst * T + (T - 1)) * n * n : nullptr;
+    double *pPs = a.Ps ? a.Ps + blkT * n * n : nullptr;
     double xs = *pF;
     double Psn[n];
     typename BIO::chunk_t pre[BIO::PER];
@@ -531,8 +536,8 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
 
     double xf = 0.0;
     if (T >= 2) { // software prefetch of the next (earlier) time step
-        pF -= n;
-        pPf -= n * n;
+        pF -= vstep;
+        pPf -= bstep;
         BIO::load_issue(pPf, pre, lane);
         xf = *pF;
     }
@@ -542,8 +547,8 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         BIO::load_finish(lds, pre, Pfc, lane, r);
         const double xfc = xf;
         if (t >= 1) {
-            pF -= n;
-            pPf -= n * n;
+            pF -= vstep;
+            pPf -= bstep;
             BIO::load_issue(pPf, pre, lane);
             xf = *pF;
         }
@@ -616,11 +621,11 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         });
 
         if (pS) {
-            pS -= n;
+            pS -= vstep;
             if (st) *pS = xs;
         }
         if (pPs) {
-            pPs -= n * n;
+            pPs -= bstep;
             BIO::store(lds, pPs, Psn, lane, rowok, live);
         }
     }

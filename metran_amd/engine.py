@@ -46,8 +46,15 @@ class BatchedKalman:
         out = kf.filter_smooth(phi, q)      # dict of device tensors F,Pf,Xp,Pp,S,Ps,mle,...
     """
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, layout="model_major"):
+        """layout: "model_major" -- per-step arrays are ``[B,T,...]`` contiguous (the reference's
+        per-model arrays stacked); "time_major" -- the memory is ``[T,B,...]`` (one time step of all
+        models contiguous: every wavefront's stores land next to its neighbours', which is what HBM
+        wants) and the tensors handed back are ``[B,T,...]`` *views* of it, so indexing is unchanged."""
         torch = _torch()
+        if layout not in ("model_major", "time_major"):
+            raise ValueError("layout must be 'model_major' or 'time_major'")
+        self.time_major = layout == "time_major"
         L = _lib.lib()  # raises MetranHipError when the HIP library is not built
         if not torch.cuda.is_available():
             raise MetranHipError("no GPU visible to PyTorch-ROCm; metran_amd has no CPU fallback")
@@ -109,9 +116,24 @@ class BatchedKalman:
             obs = obs[None]
         if obs.ndim != 3:
             raise ValueError("observations must be [R,T,N] or [T,N]")
-        self.obs = self._dev(obs)
+        self.obs = self._layout(self._dev(obs))
         self.R, self.T, self.N = (int(s) for s in self.obs.shape)
         return self
+
+    def _layout(self, t):
+        """Logical ``[B,T,...]`` tensor whose memory follows the engine's layout."""
+        if not self.time_major:
+            return t.contiguous()
+        if t.transpose(0, 1).is_contiguous():
+            return t
+        return t.transpose(0, 1).contiguous().transpose(0, 1)
+
+    def _empty_bt(self, B, T, *rest, dtype=None):
+        torch = _torch()
+        dtype = dtype or torch.float64
+        if self.time_major:
+            return torch.empty((T, B) + tuple(rest), dtype=dtype, device=self.device).transpose(0, 1)
+        return torch.empty((B, T) + tuple(rest), dtype=dtype, device=self.device)
 
     def set_loadings(self, loadings, obsvar=None):
         """Factor loadings ``[R,N,K]`` (``Z = [I | loadings]``, metran/metran.py:365-370) and
@@ -181,7 +203,8 @@ class BatchedKalman:
         x0 = self._dev(x0, (B, self.n), "x0") if x0 is not None else None
         P0 = self._dev(P0, (B, self.n, self.n), "P0") if P0 is not None else None
         prob = Problem(B, self.R, self.T, self.N, self.K, int(warmup), self._p(self.obs), self._p(phi), self._p(q),
-                       self._p(self.loadings), self._p(self.obsvar), self._p(x0), self._p(P0))
+                       self._p(self.loadings), self._p(self.obsvar), self._p(x0), self._p(P0),
+                       1 if self.time_major else 0)
         keep = (phi, q, x0, P0)
         return prob, keep, B
 
@@ -201,21 +224,21 @@ class BatchedKalman:
         f64 = dict(dtype=torch.float64, device=self.device)
         res = {"mle": torch.empty(B, **f64)}
         if bookkeeping:
-            res["sigmas"] = torch.empty((B, T), **f64)
-            res["detfs"] = torch.empty((B, T), **f64)
+            res["sigmas"] = self._empty_bt(B, T)
+            res["detfs"] = self._empty_bt(B, T)
             res["sigmacount"] = torch.empty(B, dtype=torch.int64, device=self.device)
         res["status"] = torch.zeros(B, dtype=torch.int32, device=self.device)
         for k in want:
             if k not in _STATE_OUTPUTS:
                 raise ValueError("unknown output %r (choose from %s)" % (k, _STATE_OUTPUTS))
-            res[k] = torch.empty((B, T, n) if k in ("F", "Xp", "S") else (B, T, n, n), **f64)
+            res[k] = self._empty_bt(B, T, n) if k in ("F", "Xp", "S") else self._empty_bt(B, T, n, n)
         return res
 
     def _outputs_struct(self, res):
         g = res.get
         return Outputs(self._p(g("mle")), self._p(g("sigmas")), self._p(g("detfs")), self._p(g("sigmacount")),
                        self._p(g("F")), self._p(g("Pf")), self._p(g("Xp")), self._p(g("Pp")), self._p(g("S")),
-                       self._p(g("Ps")), self._p(g("status")))
+                       self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0)
 
     def filter(self, phi, q, warmup=1, x0=None, P0=None, outputs=("F", "Pf", "Xp", "Pp"), buffers=None):
         """``run_filter`` for B instances (kalmanfilter.py:696-778).  Returns a dict of device tensors."""
@@ -245,8 +268,8 @@ class BatchedKalman:
     def smooth(self, phi, q, F, Pf, outputs=("S", "Ps")):
         """``kalmansmoother`` (kalmanfilter.py:403-476) from existing filtered moments
         ``F [B,T,n]``, ``Pf [B,T,n,n]``; needs no observations (the kernel depends on n only)."""
-        F = self._dev(F)
-        Pf = self._dev(Pf)
+        F = self._layout(self._dev(F) if not isinstance(F, _torch().Tensor) else F.to(self.device))
+        Pf = self._layout(self._dev(Pf) if not isinstance(Pf, _torch().Tensor) else Pf.to(self.device))
         B, T, n = (int(s) for s in F.shape)
         if tuple(Pf.shape) != (B, T, n, n):
             raise ValueError("Pf must be [B,T,n,n]")
@@ -256,13 +279,13 @@ class BatchedKalman:
         if not shape:
             raise MetranHipError("no HIP smoother kernel compiled for state dimension n=%d" % n)
         N, K = shape[0]
-        prob = Problem(B, 1, T, N, K, 1, None, self._p(phi), self._p(q), None, None, None, None)
+        prob = Problem(B, 1, T, N, K, 1, None, self._p(phi), self._p(q), None, None, None, None, 0)
         torch = _torch()
         res = {"F": F, "Pf": Pf, "status": torch.zeros(B, dtype=torch.int32, device=self.device)}
         if "S" in outputs:
-            res["S"] = torch.empty_like(F)
+            res["S"] = self._empty_bt(B, T, n)
         if "Ps" in outputs:
-            res["Ps"] = torch.empty_like(Pf)
+            res["Ps"] = self._empty_bt(B, T, n, n)
         o = self._outputs_struct(res)
         self._bind_stream()
         check(self._L.mk_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))

@@ -8,7 +8,7 @@ from metran_amd.synthetic import make_dfm_batch_torch
 B = int(os.environ.get("B", 4096)); N, K, T = 8, 2, 1000
 dev = torch.device("cuda", 0)
 d = make_dfm_batch_torch(B, N, K, T, seed=2000, device=dev)
-kf = BatchedKalman(0)
+kf = BatchedKalman(0, layout=os.environ.get("LAYOUT", "model_major"))
 kf.set_observations(d["obs"]).set_loadings(d["loadings"])
 kf.enable_timing(True)
 def run(tag, outs, smooth=False, reps=5):

@@ -19,14 +19,15 @@ FILT_ATOL = 1e-10
 SMOOTH_ATOL = 1e-9
 
 
-@pytest.fixture(scope="module")
-def kf():
+@pytest.fixture(scope="module", params=["model_major", "time_major"])
+def kf(request):
+    """Both memory layouts of the per-step arrays ([B,T,...] and [T,B,...] behind [B,T,...] views)."""
     import torch
 
     from metran_amd.engine import BatchedKalman
 
     assert torch.cuda.is_available()
-    return BatchedKalman(0)
+    return BatchedKalman(0, layout=request.param)
 
 
 def _np(t):
