@@ -1,0 +1,93 @@
+"""Multi-GPU sharding of the batch axis: one process per GPU, ``torch.distributed`` (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The path shards trivially: every dynamic-factor model is independent, so
+rank r owns a contiguous slice of the records and runs the same kernels on it -- there is NO
+data-path collective.  The only exchange is the summed objective fed back to the solver
+(shared-parameter calibration): each rank reduces its own -2 log L values in a fixed order
+(``BatchedKalman.sum``) and one all-reduce(sum) of a single float64 (8 bytes, latency-bound)
+combines the ranks.  The reference has no counterpart (single process, metran/solver.py:42-63).
+"""
+import os
+
+__all__ = ["shard_range", "init_from_env", "allreduce_sum", "gather_concat", "ShardedObjective"]
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous, balanced slice ``[lo, hi)`` of ``n_items`` for ``rank`` (first ``n % world``
+    ranks get one extra item).  Deterministic and order-preserving, so concatenating the ranks'
+    results in rank order reproduces the single-process order."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of size %d" % (rank, world_size))
+    base, extra = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, local_rank)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local_rank
+
+
+def allreduce_sum(t):
+    """In-place all-reduce(sum) of a tensor over the default group; no-op for a single process."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def gather_concat(t):
+    """All-gather rank-local 1-D results (possibly of different lengths) and concatenate them in
+    rank order (optional reporting path; the hot path never needs it)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    world = dist.get_world_size()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    m = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t.reshape(-1)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: int(s.item())] for p, s in zip(parts, sizes)])
+
+
+class ShardedObjective:
+    """Summed -2 log L of B models sharded over the ranks.
+
+    ``local_loglik(params) -> 1-D tensor`` evaluates this rank's models (on the GPU:
+    ``BatchedKalman.loglik``); ``local_sum`` reduces them deterministically
+    (``BatchedKalman.sum``); the ranks are combined with one all-reduce.
+    """
+
+    def __init__(self, local_loglik, local_sum=None):
+        self.local_loglik = local_loglik
+        self.local_sum = local_sum or (lambda v: v.sum())
+
+    def __call__(self, params):
+        vals = self.local_loglik(params)
+        total = self.local_sum(vals).reshape(1).clone()
+        return allreduce_sum(total)[0]

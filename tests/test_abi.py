@@ -1,0 +1,98 @@
+"""The C-ABI library loads and exports every symbol include/metran_hip.h declares (no compute
+calls: this runs without a GPU), and the ctypes binding matches the header."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "metran_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"MK_API\s+[\w\s\*]+?\b(mk_\w+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from metran_amd import _lib
+
+    if not os.path.exists(_lib.library_path()):
+        g.build()
+    return _lib.lib()
+
+
+def test_header_declares_the_api():
+    names = _declared()
+    for must in ("mk_create", "mk_filter", "mk_smooth", "mk_filter_smooth", "mk_loglik", "mk_params_from_alpha",
+                 "mk_simulate", "mk_decompose", "mk_sum", "mk_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from metran_amd import _lib
+
+    for name in _declared():
+        assert hasattr(lib, name), "libmetran_hip.so does not export %s" % name
+    assert sorted(_lib.API) == _declared(), "ctypes binding table and header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.library_path()], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(_declared()) <= exported
+    # nothing but the ABI is exported with default visibility
+    assert {e for e in exported if not e.startswith(("mk_", "_init", "_fini", "__hip"))} == set()
+
+
+def test_struct_layout_matches_header(lib):
+    """Field order/count of the ctypes structs equals the C structs (all fields are 8 bytes)."""
+    from metran_amd._lib import Outputs, Problem
+
+    src = open(HEADER).read()
+    for cname, cls in (("mk_problem", Problem), ("mk_outputs", Outputs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            first = re.findall(r"(\w+)\s*$", names[0].strip())[0]
+            fields.append(first)
+            fields += [re.findall(r"(\w+)\s*$", x.strip())[0] for x in names[1:]]
+        assert fields == [f[0] for f in cls._fields_], (cname, fields)
+        assert ctypes.sizeof(cls) == 8 * len(fields)
+
+
+def test_no_gpu_calls_fail_loudly_not_silently(lib):
+    """Without a device the context cannot be created and the error is explicit (no CPU fallback)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = ctypes.c_void_p()
+    rc = lib.mk_create(0, ctypes.byref(ctx))
+    assert rc != 0 and not ctx.value
+    assert b"device" in lib.mk_last_error().lower() or b"hip" in lib.mk_last_error().lower()
+    from metran_amd.engine import BatchedKalman, MetranHipError
+
+    with pytest.raises(MetranHipError):
+        BatchedKalman()
+    assert lib.mk_abi_version() == 1
+    assert lib.mk_shape_supported(8, 2) == 1 and lib.mk_shape_supported(32, 4) == 1
+    assert lib.mk_shape_supported(7, 7) == 0
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module of the package may reference it."""
+    pkg = os.path.join(ROOT, "metran_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
+                assert "kalman_oracle" not in txt, f

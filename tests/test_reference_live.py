@@ -1,0 +1,59 @@
+"""Differential tests against the reference ITSELF, executed only where /root/reference exists
+(the build container); skipped on the GPU box.  Complements the committed goldens with fresh random
+cases and checks the monkey-patch plug points of INTEGRATION.md section 2 exist in the reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import _refshim  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not _refshim.reference_available(), reason="reference not mounted")
+
+
+@pytest.fixture(scope="module")
+def metran():
+    return _refshim.install()
+
+
+def test_oracle_vs_reference_random(metran):
+    import pandas as pd
+
+    import oracle
+    from metran_amd.params import observation_matrix
+    from metran_amd.synthetic import make_dfm
+
+    kfm = metran.kalmanfilter
+    for seed, (N, K, T, miss) in enumerate([(6, 2, 40, 0.3), (3, 1, 25, 0.5), (9, 3, 20, 0.0)]):
+        y, alpha, load, phi, q = make_dfm(N, K, T, 900 + seed, 0, miss, "random")
+        kf = kfm.SPKalmanFilter(engine="numpy")
+        kf.filtermethod = kfm.seqkalmanfilter
+        kf.set_observations(pd.DataFrame(y))
+        kf.set_matrices(np.diag(phi), np.diag(q), observation_matrix(load), np.zeros(N))
+        kf.run_smoother()
+        r = oracle.dfm_batch(y[None], phi[None], q[None], load[None])
+        np.testing.assert_array_equal(r["F"][0], kf.filtered_state_means)
+        np.testing.assert_array_equal(r["Pf"][0], kf.filtered_state_covariances)
+        np.testing.assert_allclose(r["S"][0], kf.smoothed_state_means, atol=1e-11)
+        np.testing.assert_allclose(r["Ps"][0], kf.smoothed_state_covariances, atol=1e-11)
+        assert abs(r["mle"][0] - kf.get_mle()) <= 1e-12 * abs(kf.get_mle())
+
+
+def test_install_patches_the_plug_points(metran):
+    """The three globals that INTEGRATION.md section 2 replaces exist and are what
+    SPKalmanFilter binds (kalmanfilter.py:501-504, :685)."""
+    import metran_amd.kalmanfilter as hip
+
+    km = metran.kalmanfilter
+    orig = (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother)
+    hip.install(metran)
+    try:
+        assert km.seqkalmanfilter is hip.seqkalmanfilter_hip
+        assert km.seqkalmanfilter_np is hip.seqkalmanfilter_hip
+        assert km.kalmansmoother is hip.kalmansmoother_hip
+        assert km.SPKalmanFilter(engine="numpy").filtermethod is hip.seqkalmanfilter_hip
+    finally:
+        hip.uninstall(metran)
+    assert (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother) == orig
