@@ -1,0 +1,86 @@
+"""GPU drop-in tests: the host mirror of metran/kalmanfilter.py (same callables / class as the
+reference's plug points) reproduces the reference results stored in tests/golden (bodies modelled on
+/root/reference/tests/test_metran.py:12-40, which only assert "it runs"; here values are asserted)."""
+import numpy as np
+import pytest
+
+import oracle
+from metran_amd.params import observation_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _mirror(g1, obs=None):
+    import pandas as pd
+
+    from metran_amd.kalmanfilter import SPKalmanFilter
+
+    kf = SPKalmanFilter(engine="hip")
+    y = g1["obs"] if obs is None else obs
+    idx = pd.to_datetime(g1["index_ns"])
+    kf.set_observations(pd.DataFrame(y, index=idx))
+    kf.set_matrices(np.diag(g1["phi"]), np.diag(g1["q"]), g1["Z"], np.zeros(5))
+    return kf
+
+
+def test_spkalmanfilter_mirror_g1(g1):
+    kf = _mirror(g1)
+    kf.run_filter()                                   # Metran.get_mle path (metran.py:619-621)
+    assert abs(kf.get_mle() - 2332.327069381027) < 1e-9 * 2332
+    assert len(kf.sigmas) == len(g1["sigmas"])
+    np.testing.assert_allclose(kf.sigmas, g1["sigmas"], rtol=1e-10)
+    np.testing.assert_allclose(kf.detfs, g1["detfs"], atol=1e-11)
+    np.testing.assert_allclose(kf.filtered_state_means, g1["F"], atol=1e-10)
+    np.testing.assert_allclose(kf.predicted_state_means, g1["Xp"], atol=1e-10)
+    np.testing.assert_allclose(kf.filtered_state_covariances[g1["tsel"]], g1["Pf"], atol=1e-10)
+    np.testing.assert_allclose(kf.predicted_state_covariances[g1["tsel"]], g1["Pp"], atol=1e-10)
+    assert abs(kf.get_mle(warmup=3) - oracle.get_mle(g1["sigmas"], g1["detfs"], g1["count"], 3)) < 1e-8
+    kf.run_smoother()                                 # Metran._run_kalman("smoother") (metran.py:985-989)
+    np.testing.assert_allclose(kf.smoothed_state_means, g1["S"], atol=1e-9)
+    np.testing.assert_allclose(kf.smoothed_state_covariances[g1["tsel"]], g1["Ps"], atol=1e-9)
+    sm, sv = kf.simulate(g1["Z_scaled"], method="smoother")       # get_simulated_means/variances
+    np.testing.assert_allclose(np.asarray(sm), g1["sim_means"], atol=1e-9)
+    np.testing.assert_allclose(np.asarray(sv), g1["sim_vars"], atol=1e-9)
+    fm, fv = kf.simulate(g1["Z_scaled"], method="filter")
+    np.testing.assert_allclose(np.asarray(fm)[g1["tsel"]], g1["simf_means"], atol=1e-9)
+    sdf, cdf = kf.decompose(g1["Z_scaled"], method="smoother")    # decompose_simulation
+    np.testing.assert_allclose(np.asarray(sdf)[g1["tsel"]], g1["sdf_means"], atol=1e-9)
+    np.testing.assert_allclose(np.asarray(cdf)[:, g1["tsel"]], g1["cdf_means"], atol=1e-9)
+    # stored notebook rows, examples/metran_practical_example.ipynb:395-427
+    np.testing.assert_allclose(kf.smoothed_state_means[0], [0.226549, 0.021665, 0.028548, 0.026005, 0.153683,
+                                                            0.809228], atol=6e-7)
+
+
+def test_masked_differs_and_matches_reference(g1):
+    """tests/test_metran.py:32-40 (mask -> simulation changes), with the reference value asserted."""
+    obs = g1["obs"].copy()
+    obs[int(g1["mask_t"]), 4] = np.nan
+    kf = _mirror(g1, obs)
+    kf.mask = True
+    kf.run_smoother()
+    sm, _ = kf.simulate(g1["Z_scaled"])
+    got = np.asarray(sm)[:, 4] + g1["oseries_mean"][4]
+    np.testing.assert_allclose(got, g1["masked_sim_005"].ravel(), atol=1e-8)
+    assert np.max(np.abs(got - (g1["sim_means"][:, 4] + g1["oseries_mean"][4]))) > 1e-3
+
+
+def test_nine_arg_and_five_arg_adapters(g2):
+    """The exact callables the reference binds: 9 args -> 7-tuple (kalmanfilter.py:761-771) and
+    5 args -> 2-tuple (:685-691)."""
+    from metran_amd.kalmanfilter import kalmansmoother_hip, seqkalmanfilter_hip
+
+    y = g2["obs"]
+    o, oi, oc = oracle.set_observations(y)
+    Phi, Q, Z = np.diag(g2["phi"]), np.diag(g2["q"]), observation_matrix(g2["loadings"])
+    res = seqkalmanfilter_hip(o, Phi, Q, Z, np.zeros(2), oi, oc, np.zeros(3), np.eye(3))
+    ref = oracle.seqkalmanfilter(o, Phi, Q, Z, np.zeros(2), oi, oc, np.zeros(3), np.eye(3))
+    assert len(res) == 7 and res[2] == ref[2]
+    for a, b in zip(res[:2], ref[:2]):
+        np.testing.assert_allclose(a[: res[2]], b[: res[2]], rtol=1e-10, atol=1e-11)
+    for a, b in zip(res[3:], ref[3:]):
+        np.testing.assert_allclose(a, b, atol=1e-10)
+    mle = oc[1:].sum() * np.log(2 * np.pi) + res[1][1:res[2]].sum() + res[0][1:res[2]].sum()
+    assert abs(mle - 2431.3389452203646) < 1e-8
+    S, Ps = kalmansmoother_hip(res[3], res[4], res[5], res[6], Phi)
+    np.testing.assert_allclose(S, g2["S"], atol=1e-9)
+    np.testing.assert_allclose(Ps[g2["tsel"]], g2["Ps"], atol=1e-9)
