@@ -42,127 +42,63 @@ __device__ __forceinline__ void sfor_down(F &&f) // I = E-1 .. 0 handled as (E-1
 
 // ---------------------------------------------------------------- cross-lane primitives
 // All cross-lane traffic of the hot kernels goes through three primitives:
-//   bcast<J>(v)                         value of lane J of the group, in every lane
-//   axpy_lane<J,C0,C1>(acc, src, mul)   acc[c] += bcast<J>(src[c]) * mul      c in [C0,C1)
-//   axpy_col<C0,C1>(acc, src, mul)      acc[c] += bcast<c>(src)    * mul      c in [C0,C1)
+//   bcast<J>(v)                          value of lane J of the group, in every lane
+//   axpy_lane<J,C0,C1>(acc, src, mul)    acc[c] (+|-)= bcast<J>(src[c]) * mul      c in [C0,C1)
+//   axpy_col<C0,C1>(acc, src, mul)       acc[c] (+|-)= bcast<c>(src)    * mul      c in [C0,C1)
 //
 // G = 16 (four models per wavefront, one per 16-lane DPP row): gfx950 has DPP64
 // `row_newbcast` on v_mov_b64 and v_fmac_f64, so a broadcast-multiply-accumulate is ONE
-// instruction (v_fmac_f64_dpp) with no LDS and no extra move.  hipcc has no builtin for the
-// fused form, so it is emitted as inline asm; the assembler does not pad the
-// "VALU write -> DPP read" hazard (2 wait states), hence every asm statement opens with
-// `s_nop 1`, and inside a statement no DPP source is written by the two preceding
-// instructions (each instruction writes only its own accumulator).
+// instruction (v_fmac_f64_dpp; negation is a free source modifier) with no LDS and no extra
+// move.  hipcc has no builtin for the fused form, so it is emitted as inline asm.
+// HAZARD: "VALU writes a VGPR -> DPP reads it as src0" needs 2 wait states and neither the
+// assembler nor hipcc's hazard recogniser pads it around inline asm.  A lone wavefront issues one
+// instruction per ~5 cycles and pays ~9 for an `s_nop 1`, so no blanket nops are emitted;
+// instead scripts/check_dpp_hazards.py statically verifies the generated assembly at build time
+// (see __graft_entry__.build) and `dpp_guard()` is placed where it reports a producer too close.
 // G = 64 (one model per wavefront): v_readlane -> SGPR pair, plain v_fma with a scalar operand.
 template <int G>
 struct Group;
 
 #define MK_DPPMASK " row_mask:0xf bank_mask:0xf"
-#define MK_FMAC(a, s, m, l) "v_fmac_f64_dpp %" #a ", %" #s ", %" #m " row_newbcast:%" #l MK_DPPMASK "\n\t"
+
+__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
 
 template <>
 struct Group<16> {
-    // compiler-scheduled broadcast (v_mov_b64_dpp); the compiler pads hazards for values IT wrote
     template <int J>
     static __device__ __forceinline__ double bcast(double v)
     {
-        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); // row_newbcast:J
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); // v_mov_b64_dpp row_newbcast:J
     }
-    // broadcast of a value that an asm statement may just have written
-    template <int J>
-    static __device__ __forceinline__ double bcast_safe(double v)
-    {
-        double o;
-        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2" MK_DPPMASK : "=v"(o) : "v"(v), "n"(J));
-        return o;
-    }
-    // ---- fixed-arity fused broadcast-FMA statements: a_i += bcast<L_i>(s_i) * m
-    template <int L0>
-    static __device__ __forceinline__ void f1(double &a0, double s0, double m)
-    {
-        asm volatile("s_nop 1\n\t" MK_FMAC(0, 1, 2, 3) : "+v"(a0) : "v"(s0), "v"(m), "n"(L0));
-    }
-    template <int L0, int L1>
-    static __device__ __forceinline__ void f2(double &a0, double &a1, double s0, double s1, double m)
-    {
-        asm volatile("s_nop 1\n\t" MK_FMAC(0, 2, 4, 5) MK_FMAC(1, 3, 4, 6)
-                     : "+v"(a0), "+v"(a1)
-                     : "v"(s0), "v"(s1), "v"(m), "n"(L0), "n"(L1));
-    }
-    template <int L0, int L1, int L2>
-    static __device__ __forceinline__ void f3(double &a0, double &a1, double &a2, double s0, double s1, double s2,
-                                              double m)
-    {
-        asm volatile("s_nop 1\n\t" MK_FMAC(0, 3, 6, 7) MK_FMAC(1, 4, 6, 8) MK_FMAC(2, 5, 6, 9)
-                     : "+v"(a0), "+v"(a1), "+v"(a2)
-                     : "v"(s0), "v"(s1), "v"(s2), "v"(m), "n"(L0), "n"(L1), "n"(L2));
-    }
-    template <int L0, int L1, int L2, int L3>
-    static __device__ __forceinline__ void f4(double &a0, double &a1, double &a2, double &a3, double s0, double s1,
-                                              double s2, double s3, double m)
-    {
-        asm volatile("s_nop 1\n\t" MK_FMAC(0, 4, 8, 9) MK_FMAC(1, 5, 8, 10) MK_FMAC(2, 6, 8, 11) MK_FMAC(3, 7, 8, 12)
-                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-                     : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(m), "n"(L0), "n"(L1), "n"(L2), "n"(L3));
-    }
-    template <int L0, int L1, int L2, int L3, int L4>
-    static __device__ __forceinline__ void f5(double &a0, double &a1, double &a2, double &a3, double &a4, double s0,
-                                              double s1, double s2, double s3, double s4, double m)
-    {
-        asm volatile("s_nop 1\n\t" MK_FMAC(0, 5, 10, 11) MK_FMAC(1, 6, 10, 12) MK_FMAC(2, 7, 10, 13)
-                         MK_FMAC(3, 8, 10, 14) MK_FMAC(4, 9, 10, 15)
-                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4)
-                     : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(m), "n"(L0), "n"(L1), "n"(L2), "n"(L3),
-                       "n"(L4));
-    }
-    // acc[c] += bcast<J>(src[c]) * mul, c in [C0, C1)
-    template <int J, int C0, int C1, int n>
-    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
-    {
-        if constexpr (C1 - C0 >= 5) {
-            f5<J, J, J, J, J>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], acc[C0 + 4], src[C0], src[C0 + 1],
-                              src[C0 + 2], src[C0 + 3], src[C0 + 4], mul);
-            axpy_lane<J, C0 + 5, C1, n>(acc, src, mul);
-        } else if constexpr (C1 - C0 == 4) {
-            f4<J, J, J, J>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], src[C0], src[C0 + 1], src[C0 + 2],
-                           src[C0 + 3], mul);
-        } else if constexpr (C1 - C0 == 3) {
-            f3<J, J, J>(acc[C0], acc[C0 + 1], acc[C0 + 2], src[C0], src[C0 + 1], src[C0 + 2], mul);
-        } else if constexpr (C1 - C0 == 2) {
-            f2<J, J>(acc[C0], acc[C0 + 1], src[C0], src[C0 + 1], mul);
-        } else if constexpr (C1 - C0 == 1) {
-            f1<J>(acc[C0], src[C0], mul);
-        }
-    }
-    // acc[c] += bcast<c>(src) * mul, c in [C0, C1)
-    template <int C0, int C1, int n>
-    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
-    {
-        if constexpr (C1 - C0 >= 5) {
-            f5<C0, C0 + 1, C0 + 2, C0 + 3, C0 + 4>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], acc[C0 + 4], src,
-                                                   src, src, src, src, mul);
-            axpy_col<C0 + 5, C1, n>(acc, src, mul);
-        } else if constexpr (C1 - C0 == 4) {
-            f4<C0, C0 + 1, C0 + 2, C0 + 3>(acc[C0], acc[C0 + 1], acc[C0 + 2], acc[C0 + 3], src, src, src, src, mul);
-        } else if constexpr (C1 - C0 == 3) {
-            f3<C0, C0 + 1, C0 + 2>(acc[C0], acc[C0 + 1], acc[C0 + 2], src, src, src, mul);
-        } else if constexpr (C1 - C0 == 2) {
-            f2<C0, C0 + 1>(acc[C0], acc[C0 + 1], src, src, mul);
-        } else if constexpr (C1 - C0 == 1) {
-            f1<C0>(acc[C0], src, mul);
-        }
-    }
-    // acc += bcast<J>(src) * mul (single)
-    template <int J>
+    // acc += bcast<J>(src) * mul   /   acc -= bcast<J>(src) * mul
+    template <int J, bool NEG = false>
     static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
     {
-        f1<J>(acc, src, mul);
+        if constexpr (NEG)
+            asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+        else
+            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+    }
+    template <int J, int C0, int C1, bool NEG, int n>
+    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
+    {
+        sfor<C0, C1>(MK_LAMBDA(c) { fmac<J, NEG>(acc[decltype(c)::value], src[decltype(c)::value], mul); });
+    }
+    template <int C0, int C1, bool NEG, int n>
+    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
+    {
+        sfor<C0, C1>(MK_LAMBDA(c) { fmac<decltype(c)::value, NEG>(acc[decltype(c)::value], src, mul); });
     }
     // per-group mask of lanes whose predicate holds (bit l = lane l of this group)
-    static __device__ __forceinline__ unsigned group_ballot(bool pred)
+    static __device__ __forceinline__ unsigned group_bits(unsigned long long m)
     {
-        const unsigned long long m = __ballot(pred);
         return (unsigned)(m >> ((threadIdx.x & 63) & ~15)) & 0xffffu;
+    }
+    // ballot pattern with bits [0,N) set in every group
+    static constexpr unsigned long long full_mask(int N)
+    {
+        const unsigned long long g = (1ull << N) - 1ull;
+        return g | (g << 16) | (g << 32) | (g << 48);
     }
 };
 
@@ -175,33 +111,23 @@ struct Group<64> {
         int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
         return __hiloint2double(hi, lo);
     }
-    template <int J>
-    static __device__ __forceinline__ double bcast_safe(double v)
-    {
-        return bcast<J>(v);
-    }
-    template <int J, int C0, int C1, int n>
-    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
-    {
-        sfor<C0, C1>(MK_LAMBDA(c) {
-            constexpr int cc = decltype(c)::value;
-            acc[cc] = fma(bcast<J>(src[cc]), mul, acc[cc]);
-        });
-    }
-    template <int C0, int C1, int n>
-    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
-    {
-        sfor<C0, C1>(MK_LAMBDA(c) {
-            constexpr int cc = decltype(c)::value;
-            acc[cc] = fma(bcast<cc>(src), mul, acc[cc]);
-        });
-    }
-    template <int J>
+    template <int J, bool NEG = false>
     static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
     {
-        acc = fma(bcast<J>(src), mul, acc);
+        acc = fma(NEG ? -bcast<J>(src) : bcast<J>(src), mul, acc);
     }
-    static __device__ __forceinline__ unsigned long long group_ballot(bool pred) { return __ballot(pred); }
+    template <int J, int C0, int C1, bool NEG, int n>
+    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
+    {
+        sfor<C0, C1>(MK_LAMBDA(c) { fmac<J, NEG>(acc[decltype(c)::value], src[decltype(c)::value], mul); });
+    }
+    template <int C0, int C1, bool NEG, int n>
+    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
+    {
+        sfor<C0, C1>(MK_LAMBDA(c) { fmac<decltype(c)::value, NEG>(acc[decltype(c)::value], src, mul); });
+    }
+    static __device__ __forceinline__ unsigned long long group_bits(unsigned long long m) { return m; }
+    static constexpr unsigned long long full_mask(int N) { return N >= 64 ? ~0ull : (1ull << N) - 1ull; }
 };
 
 template <int n>
@@ -232,6 +158,15 @@ __device__ __forceinline__ void load_row(const double *src, double (&row)[n])
 #pragma unroll
         for (int c = 0; c < n; ++c) row[c] = src[c];
     }
+}
+
+// single v_min_f64 (fmin() adds a canonicalising v_max); NaN operands are ignored, which is fine:
+// a NaN variance propagates into the outputs by itself
+__device__ __forceinline__ double min_f64(double a, double b)
+{
+    double o;
+    asm("v_min_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
 }
 
 // 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (the same refinement LLVM's f64 division uses,
@@ -273,20 +208,27 @@ struct BlockIO {
     static constexpr int LDS_DOUBLES = (256 / G) * STRIDE;
     using chunk_t = typename std::conditional<V2, v2d, double>::type;
 
-    // rows (registers) -> LDS -> HBM block
-    static __device__ __forceinline__ void store(double *lds, double *gblock, const double (&row)[n], int lane,
-                                                 bool rowok, bool live)
+    // Lanes >= n (and the groups of a partial last workgroup) are exact REPLICAS of lane n-1 (of the
+    // last model): same inputs, same instruction stream.  They therefore write identical bytes to
+    // identical addresses, and no store in the hot loops needs an exec mask.
+    // rows (registers) -> LDS -> HBM block; r = min(lane, n-1)
+    static __device__ __forceinline__ void store(double *lds, double *gblock, const double (&row)[n], int lane, int r)
     {
         wave_lds_sync();
-        if (rowok) store_row<n>(lds + lane * n, row);
+        store_row<n>(lds + r * n, row);
         wave_lds_sync();
         chunk_t *g = reinterpret_cast<chunk_t *>(gblock);
         const chunk_t *l = reinterpret_cast<const chunk_t *>(lds);
+        chunk_t tmp[PER];
+        int qi[PER];
 #pragma unroll
         for (int m = 0; m < PER; ++m) {
-            const int qi = lane + m * G;
-            if (qi < CH && live) g[qi] = l[qi];
+            qi[m] = lane + m * G;
+            if (qi[m] > CH - 1) qi[m] = CH - 1; // duplicates of the last chunk: same data, same address
+            tmp[m] = l[qi[m]];
         }
+#pragma unroll
+        for (int m = 0; m < PER; ++m) g[qi[m]] = tmp[m];
     }
     // HBM block -> registers (issue early; the data is consumed one time step later)
     static __device__ __forceinline__ void load_issue(const double *gblock, chunk_t (&buf)[PER], int lane)
@@ -307,7 +249,7 @@ struct BlockIO {
 #pragma unroll
         for (int m = 0; m < PER; ++m) {
             const int qi = lane + m * G;
-            if (qi < CH) l[qi] = buf[m];
+            l[qi < CH ? qi : CH - 1] = buf[m];
         }
         wave_lds_sync();
         load_row<n>(lds + r * n, row);
@@ -319,8 +261,12 @@ constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 
 // =====================================================================================
 // Sequential-processing Kalman filter + -2 log L            (kalmanfilter.py:236-400, 550-567)
+//   OUT  : 0 = no state outputs (solver objective, mk_loglik), 1 = F, Pf, Xp, Pp all written,
+//          2 = any subset (runtime null checks)
+//   BOOK : per-step sigmas/detfs arrays are written (needs one log per step); otherwise the
+//          log-determinant is accumulated as a normalised product with ONE log at the end
 // =====================================================================================
-template <int N, int K, int G>
+template <int N, int K, int G, int OUT, bool BOOK>
 __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 {
     constexpr int n = N + K;
@@ -331,22 +277,21 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     const int lane = threadIdx.x % G;
     long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
     const bool live = inst < a.B;
-    if (!live) inst = a.B - 1; // keep every lane executing (DPP rows stay uniform); stores are masked
+    if (!live) inst = a.B - 1; // surplus groups replicate the last model (identical stores, see BlockIO)
     const long rec = inst % a.R;
     const bool rowok = lane < n;
     const int r = rowok ? lane : n - 1;
-    const bool st = live && rowok;
-    const bool lead = live && lane == 0;
+    const bool lead = lane == 0;
     const long T = a.T;
 
     // per-model constants: lane r holds phi_r, q_r; lane j < N holds loadings[j,:] and obsvar[j]
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
-    double phic[n]; // diag(Phi), replicated in every lane of the group
-    sfor<0, n>(MK_LAMBDA(c) { phic[c] = Gp::template bcast<decltype(c)::value>(phi_r); });
-    double qd[n]; // row r of Q = diag(q)
-#pragma unroll
-    for (int c = 0; c < n; ++c) qd[c] = (c == r) ? q_r : 0.0;
+    double pp[n], qd[n]; // row r of Phi (x) Phi and of Q = diag(q)
+    sfor<0, n>(MK_LAMBDA(c) {
+        pp[decltype(c)::value] = phi_r * Gp::template bcast<decltype(c)::value>(phi_r);
+        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
+    });
     const int jr = lane < N ? lane : N - 1;
     double gam[K];
 #pragma unroll
@@ -368,121 +313,159 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
 
     using BIO = BlockIO<n, G>;
-    __shared__ __attribute__((aligned(16))) double lds_io[BIO::LDS_DOUBLES];
-    double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE; // this model's staging buffer
+    __shared__ __attribute__((aligned(16))) double lds_io[OUT ? BIO::LDS_DOUBLES : 2];
+    double *lds = lds_io + (OUT ? (threadIdx.x / G) * BIO::STRIDE : 0); // this model's staging buffer
 
     const double *yp = a.obs + rec * a.obs_bs * N + jr; // lane j streams series j
     const long ystep = a.obs_ts * N;
     double ynext = yp[0];
     double sum_sig = 0.0, sum_det = 0.0;
+    double run_mant = 1.0; // !BOOK: prod of f over the counted steps, normalised
+    long run_exp = 0;
     long nobs = 0, sc = 0;
-    unsigned flags = 0;
-    // running output pointers (row r of step t)
+    double fmin_seen = 1.0;
     // (b, t) lives at block index b * bs + t * ts: (bs, ts) = (T, 1) model-major [B,T,..] or (1, B) time-major [T,B,..]
     const long vstep = a.ts * n, bstep = a.ts * n * n;
     const long vec0 = inst * a.bs * n + r;
-    double *pXp = a.Xp ? a.Xp + vec0 : nullptr;
-    double *pF = a.F ? a.F + vec0 : nullptr;
-    double *pPp = a.Pp ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
-    double *pPf = a.Pf ? a.Pf + inst * a.bs * n * n : nullptr;
+    double *pXp = (OUT && a.Xp) ? a.Xp + vec0 : nullptr;
+    double *pF = (OUT && a.F) ? a.F + vec0 : nullptr;
+    double *pPp = (OUT && a.Pp) ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
+    double *pPf = (OUT && a.Pf) ? a.Pf + inst * a.bs * n * n : nullptr;
 
     for (long t = 0; t < T; ++t) {
         const double y = ynext;
         if (t + 1 < T) ynext = yp[(t + 1) * ystep]; // prefetch next step's observation
         // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
-        const auto vm = Gp::group_ballot(lane < N && isfinite(y));
+        const unsigned long long ball = __ballot(lane < N && isfinite(y));
+        const auto vm = Gp::group_bits(ball);
 
         // ---- predict (:318-331; Phi diagonal) ----
         x = phi_r * x;
 #pragma unroll
-        for (int c = 0; c < n; ++c) P[c] = fma(phi_r * P[c], phic[c], qd[c]);
-        if (pXp) {
-            if (st) *pXp = x; // :332
+        for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
+        if constexpr (OUT == 1) {
+            *pXp = x; // :332
             pXp += vstep;
-        }
-        if (pPp) {
-            BIO::store(lds, pPp, P, lane, rowok, live); // :333
+            BIO::store(lds, pPp, P, lane, r); // :333
             pPp += bstep;
+        } else if constexpr (OUT == 2) {
+            if (pXp) {
+                *pXp = x;
+                pXp += vstep;
+            }
+            if (pPp) {
+                BIO::store(lds, pPp, P, lane, r);
+                pPp += bstep;
+            }
         }
 
         // ---- sequential scalar updates (:341-378), observations in ascending series order ----
         double sigma = 0.0, fmant = 1.0;
         int fexp = 0;
-        sfor<0, N>(MK_LAMBDA(jc) {
+        auto update = MK_LAMBDA(jc) {
             constexpr int j = decltype(jc)::value;
-            if ((vm >> j) & 1) { // uniform within the model's lane group
-                // innovation (:344-347): every lane l < N forms v_l = y_l - Z_l x with ITS loadings;
-                // lane j's value is the one used
-                double vl = y - x;
-                sfor<0, K>(MK_LAMBDA(k) {
-                    constexpr int kk = decltype(k)::value;
-                    vl = fma(-gam[kk], Gp::template bcast<N + kk>(x), vl);
-                });
-                const double v = Gp::template bcast<j>(vl);
-                // d = P Z_j^T : lane r computes d_r from its own row (:349-357)
-                double dr = P[j];
-                sfor<0, K>(MK_LAMBDA(k) {
-                    constexpr int kk = decltype(k)::value;
-                    double g;
-                    if constexpr (HOIST) g = Gh[j][kk];
-                    else g = Gp::template bcast<j>(gam[kk]);
-                    dr = fma(P[N + kk], g, dr);
-                });
-                // innovation variance f = R_j + Z_j d (:359-362), formed at lane j from d_j, d_{N+k}
-                double fl = rvar + dr;
-                sfor<0, K>(MK_LAMBDA(k) {
-                    constexpr int kk = decltype(k)::value;
-                    fl = fma(gam[kk], Gp::template bcast<N + kk>(dr), fl);
-                });
-                const double f = Gp::template bcast<j>(fl);
-                const double rf = rcp_nr(f);
-                const double kr = dr * rf; // Kalman gain element r (:364-366)
-                // P -= k k^T f (:368-372): P[r][c] += d_c * (-k_r), d_c broadcast from lane c
-                Gp::template axpy_col<0, n, n>(P, dr, -kr);
-                x = fma(kr, v, x);             // :374-375
-                sigma = fma(v * v, rf, sigma); // :377
-                // detf += log f (:378): accumulate prod f as mantissa * 2^exp, one log per step
-                fmant *= f;
+            // innovation (:344-347): every lane l < N forms v_l = y_l - Z_l x with ITS loadings;
+            // lane j's value is the one used
+            double vl = y - x;
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                vl = fma(-gam[kk], Gp::template bcast<N + kk>(x), vl);
+            });
+            const double v = Gp::template bcast<j>(vl);
+            // d = P Z_j^T : lane r computes d_r from its own row (:349-357)
+            double dr = P[j];
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                double g;
+                if constexpr (HOIST) g = Gh[j][kk];
+                else g = Gp::template bcast<j>(gam[kk]);
+                dr = fma(P[N + kk], g, dr);
+            });
+            // innovation variance f = R_j + Z_j d (:359-362), formed at lane j from d_j, d_{N+k}
+            double fl = rvar + dr;
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                fl = fma(gam[kk], Gp::template bcast<N + kk>(dr), fl);
+            });
+            const double f = Gp::template bcast<j>(fl);
+            const double rf = rcp_nr(f);
+            const double kr = dr * rf; // Kalman gain element r (:364-366)
+            // P -= k k^T f (:368-372): P[r][c] -= d_c * k_r, d_c broadcast from lane c
+            Gp::template axpy_col<0, n, true, n>(P, dr, kr);
+            x = fma(kr, v, x);             // :374-375
+            sigma = fma(v * v, rf, sigma); // :377
+            // detf += log f (:378): accumulate prod f as mantissa * 2^exp
+            fmant *= f;
+            if constexpr ((j & 3) == 3 || j == N - 1) {
                 fexp += __builtin_amdgcn_frexp_exp(fmant);
                 fmant = __builtin_amdgcn_frexp_mant(fmant);
-                if (!(f > 0.0)) flags |= MK_FLAG_NONPOSITIVE_F;
             }
-        });
+            fmin_seen = min_f64(fmin_seen, f);
+        };
+        if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
+            sfor<0, N>(update);
+        } else {
+            sfor<0, N>(MK_LAMBDA(jc) {
+                if ((vm >> decltype(jc)::value) & 1) { // uniform within the model's lane group
+                    update(jc);
+                } else if constexpr ((decltype(jc)::value & 3) == 3 || decltype(jc)::value == N - 1) {
+                    fexp += __builtin_amdgcn_frexp_exp(fmant); // keep the product normalised
+                    fmant = __builtin_amdgcn_frexp_mant(fmant);
+                }
+            });
+        }
 
         const int cnt = __popcll((unsigned long long)vm);
         if (cnt > 0) { // :380-382 compressed bookkeeping
-            const double detf = fma((double)fexp, kLn2, log(fmant));
-            if (a.sigmas && lead) a.sigmas[inst * a.bs + sc * a.ts] = sigma;
-            if (a.detfs && lead) a.detfs[inst * a.bs + sc * a.ts] = detf;
-            if (sc >= a.warmup) { // get_mle: detfs[warmup:], sigmas[warmup:] are COMPRESSED indices (:563-564)
-                sum_det += detf;
-                sum_sig += sigma;
+            if constexpr (BOOK) {
+                const double detf = fma((double)fexp, kLn2, log(fmant));
+                if (a.sigmas && lead) a.sigmas[inst * a.bs + sc * a.ts] = sigma;
+                if (a.detfs && lead) a.detfs[inst * a.bs + sc * a.ts] = detf;
+                if (sc >= a.warmup) { // get_mle: detfs[warmup:], sigmas[warmup:] are COMPRESSED indices (:563-564)
+                    sum_det += detf;
+                    sum_sig += sigma;
+                }
+            } else {
+                if (sc >= a.warmup) {
+                    sum_sig += sigma;
+                    run_mant *= fmant;
+                    run_exp += fexp + __builtin_amdgcn_frexp_exp(run_mant);
+                    run_mant = __builtin_amdgcn_frexp_mant(run_mant);
+                }
             }
             ++sc;
         }
         if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
 
-        if (pF) {
-            if (st) *pF = x; // :389
+        if constexpr (OUT == 1) {
+            *pF = x; // :389
             pF += vstep;
-        }
-        if (pPf) {
-            BIO::store(lds, pPf, P, lane, rowok, live); // :390
+            BIO::store(lds, pPf, P, lane, r); // :390
             pPf += bstep;
+        } else if constexpr (OUT == 2) {
+            if (pF) {
+                *pF = x;
+                pF += vstep;
+            }
+            if (pPf) {
+                BIO::store(lds, pPf, P, lane, r);
+                pPf += bstep;
+            }
         }
     }
 
     // zero tail of the compressed arrays (np.zeros init, :307-308)
-    if (live) {
+    if (BOOK) {
         for (long i = sc + lane; i < T; i += G) {
             if (a.sigmas) a.sigmas[inst * a.bs + i * a.ts] = 0.0;
             if (a.detfs) a.detfs[inst * a.bs + i * a.ts] = 0.0;
         }
     }
     if (lead) {
+        if (!BOOK) sum_det = fma((double)run_exp, kLn2, log(run_mant));
         if (a.mle) a.mle[inst] = ((double)nobs * kLog2Pi + sum_det) + sum_sig; // :566
         if (a.sigmacount) a.sigmacount[inst] = sc;
-        if (a.status) a.status[inst] = flags;
+        if (a.status) a.status[inst] = (fmin_seen > 0.0) ? 0u : MK_FLAG_NONPOSITIVE_F; // NaN f also flags
     }
 }
 
@@ -505,7 +488,6 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     if (!live) inst = a.B - 1;
     const bool rowok = lane < n;
     const int r = rowok ? lane : n - 1;
-    const bool st = live && rowok;
     const long T = a.T;
 
     const double phi_r = a.phi[inst * n + r];
@@ -530,9 +512,9 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     typename BIO::chunk_t pre[BIO::PER];
     BIO::load_issue(pPf, pre, lane);
     BIO::load_finish(lds, pre, Psn, lane, r);
-    if (pS && st) *pS = xs;
-    if (pPs) BIO::store(lds, pPs, Psn, lane, rowok, live);
-    unsigned flags = 0;
+    if (pS) *pS = xs;
+    if (pPs) BIO::store(lds, pPs, Psn, lane, r);
+    double pivmin = 1.0;
 
     double xf = 0.0;
     if (T >= 2) { // software prefetch of the next (earlier) time step
@@ -565,13 +547,13 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         double dinv[n];
         sfor<0, n>(MK_LAMBDA(jc) {
             constexpr int j = decltype(jc)::value;
-            const double piv = Gp::template bcast_safe<j>(A[j]); // d_j
-            if (!(piv > 0.0)) flags |= MK_FLAG_NOT_SPD;
+            const double piv = Gp::template bcast<j>(A[j]); // d_j
+            pivmin = min_f64(pivmin, piv);
             const double ij = rcp_nr(piv);
             dinv[j] = ij;
             const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
             // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
-            Gp::template axpy_lane<j, j + 1, n, n>(A, A, -lr);
+            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
             A[j] = lr;
         });
 
@@ -581,13 +563,13 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         for (int c = 0; c < n; ++c) z[c] = W[c];
         sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
             constexpr int k = decltype(kc)::value;
-            Gp::template axpy_col<k + 1, n, n>(z, A[k], -z[k]);
+            Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
         });
 #pragma unroll
         for (int c = 0; c < n; ++c) z[c] *= dinv[c]; // D^{-1}
         sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y;  z[c] -= L(k,c) z_k, L(k,c) lives in lane k
             constexpr int k = decltype(kc)::value;
-            Gp::template axpy_lane<k, 0, k, n>(z, A, -z[k]);
+            Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
         });
         // z = J[r, :]
 
@@ -610,26 +592,26 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         for (int c = 0; c < n; ++c) V[c] = 0.0;
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
-            Gp::template axpy_lane<k, 0, n, n>(V, D, z[k]);
+            Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
         });
         // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
 #pragma unroll
         for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
-            Gp::template axpy_col<0, n, n>(Psn, z[k], V[k]);
+            Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
         });
 
         if (pS) {
             pS -= vstep;
-            if (st) *pS = xs;
+            *pS = xs;
         }
         if (pPs) {
             pPs -= bstep;
-            BIO::store(lds, pPs, Psn, lane, rowok, live);
+            BIO::store(lds, pPs, Psn, lane, r);
         }
     }
-    if (a.status && live && lane == 0 && flags) atomicOr(a.status + inst, flags);
+    if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
 }
 
 // =====================================================================================
@@ -726,7 +708,17 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     constexpr int G = n <= 16 ? 16 : 64;
     constexpr int GPB = 256 / G;
     const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
-    hipLaunchKernelGGL((filter_kernel<N, K, G>), dim3(grid), dim3(256), 0, s, a);
+    const bool book = a.sigmas || a.detfs;
+    const bool any = a.F || a.Pf || a.Xp || a.Pp;
+    const bool all = a.F && a.Pf && a.Xp && a.Pp;
+    if (!any && !book)
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (!any)
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 0, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (all)
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 1, true>), dim3(grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 2, true>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
