@@ -61,7 +61,16 @@ struct Group;
 
 #define MK_DPPMASK " row_mask:0xf bank_mask:0xf"
 
-__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
+// Two wait states between the producers of `arr` and the DPP reads that follow: the empty asm
+// statements pin every element (its producer cannot be scheduled below them), the nop follows.
+template <int n>
+__device__ __forceinline__ void dpp_guard(double (&arr)[n])
+{
+#pragma unroll
+    for (int c = 0; c < n; ++c) asm volatile("" : "+v"(arr[c]));
+    asm volatile("s_nop 1");
+}
+__device__ __forceinline__ void dpp_pin(double &v) { asm volatile("" : "+v"(v)); }
 
 template <>
 struct Group<16> {
@@ -169,16 +178,15 @@ __device__ __forceinline__ double min_f64(double a, double b)
     return o;
 }
 
-// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (the same refinement LLVM's f64 division uses,
-// without its scaling/fix-up instructions: x is an O(1) variance here, never denormal).
+// 1/x to ~1 ulp: v_rcp_f64 (measured relative error < 2^-25 on gfx950, tests/test_hip_parity.py::
+// test_rcp_accuracy) + one cubically convergent step (3 dependent FMAs instead of the 4 of two Newton
+// steps; no scaling/fix-up: x is an O(1) variance here, never denormal).
 __device__ __forceinline__ double rcp_nr(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    return r;
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);   // relative error of r0
+    const double p = fma(e, e, e);        // e + e^2
+    return fma(r0, p, r0);                // r0 (1 + e + e^2): error e^3
 }
 
 // ---------------------------------------------------------------- coalesced n x n block I/O
@@ -229,6 +237,56 @@ struct BlockIO {
         }
 #pragma unroll
         for (int m = 0; m < PER; ++m) g[qi[m]] = tmp[m];
+    }
+    // two blocks (predicted + filtered covariance of one step) through ONE LDS round trip;
+    // lds must hold 2 * STRIDE doubles for this group
+    static __device__ __forceinline__ void store2(double *lds, double *g0, const double (&row0)[n], double *g1,
+                                                  const double (&row1)[n], int lane, int r)
+    {
+        wave_lds_sync();
+        store_row<n>(lds + r * n, row0);
+        store_row<n>(lds + STRIDE + r * n, row1);
+        wave_lds_sync();
+        const chunk_t *l0 = reinterpret_cast<const chunk_t *>(lds);
+        const chunk_t *l1 = reinterpret_cast<const chunk_t *>(lds + STRIDE);
+        chunk_t t0[PER], t1[PER];
+        int qi[PER];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            qi[m] = lane + m * G;
+            if (qi[m] > CH - 1) qi[m] = CH - 1;
+            t0[m] = l0[qi[m]];
+            t1[m] = l1[qi[m]];
+        }
+#pragma unroll
+        for (int m = 0; m < PER; ++m) reinterpret_cast<chunk_t *>(g0)[qi[m]] = t0[m];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) reinterpret_cast<chunk_t *>(g1)[qi[m]] = t1[m];
+    }
+    // Split form of store2 for kernels that spread their global stores over the following compute:
+    // a CU's vector-memory path moves only ~64 B/clk and is shared by its wavefronts, so a burst of
+    // back-to-back 1 KB stores stalls the issuing wavefront (measured: +0.8 ms on the filter);
+    // issued one at a time between the scalar updates of the NEXT step they cost almost nothing.
+    static __device__ __forceinline__ int chunk_index(int lane, int m)
+    {
+        const int qi = lane + m * G;
+        return qi > CH - 1 ? CH - 1 : qi;
+    }
+    static __device__ __forceinline__ void stage2(double *lds, const double (&row0)[n], const double (&row1)[n],
+                                                  chunk_t (&t0)[PER], chunk_t (&t1)[PER], int lane, int r)
+    {
+        wave_lds_sync();
+        store_row<n>(lds + r * n, row0);
+        store_row<n>(lds + STRIDE + r * n, row1);
+        wave_lds_sync();
+        const chunk_t *l0 = reinterpret_cast<const chunk_t *>(lds);
+        const chunk_t *l1 = reinterpret_cast<const chunk_t *>(lds + STRIDE);
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int qi = chunk_index(lane, m);
+            t0[m] = l0[qi];
+            t1[m] = l1[qi];
+        }
     }
     // HBM block -> registers (issue early; the data is consumed one time step later)
     static __device__ __forceinline__ void load_issue(const double *gblock, chunk_t (&buf)[PER], int lane)
@@ -313,12 +371,18 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
 
     using BIO = BlockIO<n, G>;
-    __shared__ __attribute__((aligned(16))) double lds_io[OUT ? BIO::LDS_DOUBLES : 2];
-    double *lds = lds_io + (OUT ? (threadIdx.x / G) * BIO::STRIDE : 0); // this model's staging buffer
+    constexpr int LDS_PER_GROUP = (OUT == 1 ? 2 : 1) * BIO::STRIDE;
+    __shared__ __attribute__((aligned(16))) double lds_io[OUT ? (256 / G) * LDS_PER_GROUP : 2];
+    double *lds = lds_io + (OUT ? (threadIdx.x / G) * LDS_PER_GROUP : 0); // this model's staging buffer
 
     const double *yp = a.obs + rec * a.obs_bs * N + jr; // lane j streams series j
     const long ystep = a.obs_ts * N;
-    double ynext = yp[0];
+    // observation ring: y of step t was requested YQ steps earlier (HBM latency under the store
+    // traffic of this kernel exceeds one time step when a SIMD holds a single wavefront)
+    constexpr int YQ = 2;
+    double yq[YQ];
+#pragma unroll
+    for (int i = 0; i < YQ; ++i) yq[i] = yp[(i < T ? i : T - 1) * ystep];
     double sum_sig = 0.0, sum_det = 0.0;
     double run_mant = 1.0; // !BOOK: prod of f over the counted steps, normalised
     long run_exp = 0;
@@ -332,9 +396,29 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     double *pPp = (OUT && a.Pp) ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
     double *pPf = (OUT && a.Pf) ? a.Pf + inst * a.bs * n * n : nullptr;
 
+    // OUT == 1: the covariance blocks of step t are transposed to 16-byte chunks at the end of step t and
+    // written during step t+1, one store after each scalar update.  The staging registers start as
+    // zeros aimed at block 0, which the real step-0 data overwrites later (same wavefront, in order).
+    constexpr int PERC = OUT == 1 ? BIO::PER : 1;
+    constexpr int NSLOT = 2 * PERC;                 // stores per step
+    constexpr int SPO = (NSLOT + N - 1) / N;        // stores issued after each scalar update
+    typename BIO::chunk_t stg0[PERC], stg1[PERC];
+#pragma unroll
+    for (int m = 0; m < PERC; ++m) stg0[m] = stg1[m] = typename BIO::chunk_t(0.0);
+    double *sPp = pPp, *sPf = pPf;
+    auto emit = MK_LAMBDA(sc) {
+        constexpr int slot = decltype(sc)::value;
+        if constexpr (slot < PERC)
+            reinterpret_cast<typename BIO::chunk_t *>(sPp)[BIO::chunk_index(lane, slot)] = stg0[slot];
+        else
+            reinterpret_cast<typename BIO::chunk_t *>(sPf)[BIO::chunk_index(lane, slot - PERC)] = stg1[slot - PERC];
+    };
+
     for (long t = 0; t < T; ++t) {
-        const double y = ynext;
-        if (t + 1 < T) ynext = yp[(t + 1) * ystep]; // prefetch next step's observation
+        const double y = yq[0];
+#pragma unroll
+        for (int i = 0; i + 1 < YQ; ++i) yq[i] = yq[i + 1];
+        yq[YQ - 1] = yp[(t + YQ < T ? t + YQ : T - 1) * ystep]; // clamped: branch-free prefetch
         // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
         const unsigned long long ball = __ballot(lane < N && isfinite(y));
         const auto vm = Gp::group_bits(ball);
@@ -343,11 +427,12 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         x = phi_r * x;
 #pragma unroll
         for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
+        double Ppred[OUT == 1 ? n : 1]; // OUT == 1: keep the predicted row, store it with the filtered one
         if constexpr (OUT == 1) {
-            *pXp = x; // :332
+            *pXp = x; // :332 (replica lanes rewrite lane n-1's element)
             pXp += vstep;
-            BIO::store(lds, pPp, P, lane, r); // :333
-            pPp += bstep;
+#pragma unroll
+            for (int c = 0; c < n; ++c) Ppred[c] = P[c]; // :333, written at the end of the step
         } else if constexpr (OUT == 2) {
             if (pXp) {
                 *pXp = x;
@@ -402,8 +487,18 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
             }
             fmin_seen = min_f64(fmin_seen, f);
         };
+        auto stores_after = MK_LAMBDA(jc) { // previous step's staged chunks, SPO per scalar update
+            if constexpr (OUT == 1) {
+                constexpr int s0 = decltype(jc)::value * SPO;
+                constexpr int s1 = (s0 + SPO) < NSLOT ? (s0 + SPO) : NSLOT;
+                sfor<s0, s1>(emit);
+            }
+        };
         if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
-            sfor<0, N>(update);
+            sfor<0, N>(MK_LAMBDA(jc) {
+                update(jc);
+                stores_after(jc);
+            });
         } else {
             sfor<0, N>(MK_LAMBDA(jc) {
                 if ((vm >> decltype(jc)::value) & 1) { // uniform within the model's lane group
@@ -412,6 +507,7 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
                     fexp += __builtin_amdgcn_frexp_exp(fmant); // keep the product normalised
                     fmant = __builtin_amdgcn_frexp_mant(fmant);
                 }
+                stores_after(jc);
             });
         }
 
@@ -440,7 +536,10 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         if constexpr (OUT == 1) {
             *pF = x; // :389
             pF += vstep;
-            BIO::store(lds, pPf, P, lane, r); // :390
+            BIO::stage2(lds, Ppred, P, stg0, stg1, lane, r); // :333, :390 -> written during the next step
+            sPp = pPp;
+            sPf = pPf;
+            pPp += bstep;
             pPf += bstep;
         } else if constexpr (OUT == 2) {
             if (pF) {
@@ -453,6 +552,8 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
             }
         }
     }
+
+    if constexpr (OUT == 1) sfor<0, NSLOT>(emit); // flush the last step's blocks
 
     // zero tail of the compressed arrays (np.zeros init, :307-308)
     if (BOOK) {
@@ -499,6 +600,10 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     __shared__ __attribute__((aligned(16))) double lds_io[BIO::LDS_DOUBLES];
     double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE;
 
+    double qd[n]; // row r of Q = diag(q)
+#pragma unroll
+    for (int c = 0; c < n; ++c) qd[c] = (c == r) ? q_r : 0.0;
+
     // last step: smoothed = filtered (:450-451)
     const long vstep = a.ts * n, bstep = a.ts * n * n;
     const long blkT = inst * a.bs + (T - 1) * a.ts; // block index of (inst, T-1)
@@ -516,32 +621,37 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     if (pPs) BIO::store(lds, pPs, Psn, lane, r);
     double pivmin = 1.0;
 
-    double xf = 0.0;
-    if (T >= 2) { // software prefetch of the next (earlier) time step
+    // Software pipeline: at the top of iteration t the ROWS of Pf[t] (Pfc) and F[t] (xfc) are already in
+    // registers and the 16-byte chunks of Pf[t-1] (pre) are in flight from HBM; their LDS transposition
+    // (pre -> Pfn) is issued in the middle of the iteration so that its latency hides behind the
+    // Ps sweep, and the HBM loads for t-2 are issued right after it.
+    double Pfc[n], xfc = 0.0, xfn = 0.0;
+    if (T >= 2) {
         pF -= vstep;
         pPf -= bstep;
         BIO::load_issue(pPf, pre, lane);
-        xf = *pF;
-    }
-
-    for (long t = T - 2; t >= 0; --t) {
-        double Pfc[n];
+        xfc = *pF;
         BIO::load_finish(lds, pre, Pfc, lane, r);
-        const double xfc = xf;
-        if (t >= 1) {
+        if (T >= 3) {
             pF -= vstep;
             pPf -= bstep;
             BIO::load_issue(pPf, pre, lane);
-            xf = *pF;
+            xfn = *pF;
         }
+    }
 
-        // W = Pf Phi (column scaling); A = Pp[t+1] = Phi Pf Phi + Q (row r)
-        double W[n], A[n];
+    for (long t = T - 2; t >= 0; --t) {
+        // W = Pf Phi (column scaling); A = Pp[t+1] = Phi Pf Phi + Q (row r); D = Ps[t+1] - Pp[t+1]
+        double A[n], z[n], D[n];
 #pragma unroll
         for (int c = 0; c < n; ++c) {
-            W[c] = Pfc[c] * phic[c];
-            A[c] = fma(phi_r, W[c], (c == r ? q_r : 0.0));
+            z[c] = Pfc[c] * phic[c]; // W, the right-hand side of the solve
+            A[c] = fma(phi_r, z[c], qd[c]);
+            D[c] = Psn[c] - A[c];
         }
+
+        double delta = xs - phi_r * xfc; // xs[t+1] - Xp[t+1]; formed early so that it is "old" when DPP-read
+        if constexpr (G == 16) dpp_pin(delta);
 
         // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
         double dinv[n];
@@ -558,9 +668,6 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         });
 
         // ---- lane i solves A z = W_i  (row i of J = Pf Phi^T A^{-1}, :458-460) ----
-        double z[n];
-#pragma unroll
-        for (int c = 0; c < n; ++c) z[c] = W[c];
         sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
             constexpr int k = decltype(kc)::value;
             Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
@@ -574,7 +681,6 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         // z = J[r, :]
 
         // ---- smoothed mean (:461-464): xs[t] = F[t] + J (xs[t+1] - Phi F[t]) ----
-        const double delta = xs - phi_r * xfc;
         double acc0 = xfc, acc1 = 0.0;
         sfor<0, n>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
@@ -584,19 +690,31 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
         xs = acc0 + acc1;
 
         // ---- smoothed covariance (:465-474): Ps[t] = Pf[t] + J (Ps[t+1] - Pp[t+1]) J^T ----
-        double D[n];
-#pragma unroll
-        for (int c = 0; c < n; ++c) D[c] = Psn[c] - fma(phi_r, W[c], (c == r ? q_r : 0.0));
         double V[n]; // V = J D (row r):  V[c] += J[r][k] * D[k][c], D[k][:] broadcast from lane k
 #pragma unroll
         for (int c = 0; c < n; ++c) V[c] = 0.0;
+        if constexpr (G == 16) dpp_guard(D); // D is compiler-produced (build-time hazard check)
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
             Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
         });
-        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
 #pragma unroll
         for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
+
+        // mid-iteration: transpose the chunks of Pf[t-1] into rows (LDS latency hides behind the
+        // sweep below) and issue the HBM loads of Pf[t-2]
+        const double xf_next = xfn;
+        if (t >= 1) {
+            BIO::load_finish(lds, pre, Pfc, lane, r);
+            if (t >= 2) {
+                pF -= vstep;
+                pPf -= bstep;
+                BIO::load_issue(pPf, pre, lane);
+                xfn = *pF;
+            }
+        }
+
+        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
             Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
@@ -610,6 +728,7 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
             pPs -= bstep;
             BIO::store(lds, pPs, Psn, lane, r);
         }
+        xfc = xf_next;
     }
     if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
 }
