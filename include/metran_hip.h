@@ -96,6 +96,17 @@ typedef struct mk_outputs {
                               axis); 1: they are [T,B,...] -- all models' step-t blocks contiguous, the
                               HBM-friendly layout (a [B,T,...] strided view of it costs nothing).
                               Applies to d_sigmas, d_detfs, d_F, d_Pf, d_Xp, d_Pp, d_S, d_Ps.        */
+    int64_t record_stride; /* 0: every array above is dense.  RS = mk_record_stride(n): PACKED RECORDS, the
+                              fast path.  Each moment set is ONE array of RS doubles per (model, step):
+                                [ mean(n) | covariance(n*n) | sigma, detf (filtered set only) | zero pad ]
+                              and the pointers are views into it: d_Pp = d_Xp + n, d_Pf = d_F + n,
+                              d_Ps = d_S + n, d_sigmas = d_F + n + n*n, d_detfs = d_sigmas + 1 (or NULL);
+                              element (b,t) of any of them sits RS doubles after element (b,t)-1 of the
+                              layout chosen by time_major.  RS*8 is a multiple of 128 bytes: all stores of
+                              the kernels then cover whole cache lines (partial-line stores of the small
+                              vectors were measured to throttle HBM writes).  mk_filter uses records when
+                              the predicted AND filtered sets are both requested this way; mk_smooth when
+                              d_F (and d_S) are record arrays.                                         */
 } mk_outputs;
 
 /* ---- library / context ------------------------------------------------------------------ */
@@ -109,6 +120,8 @@ MK_API int mk_set_stream(mk_context *ctx, void *hip_stream);
 MK_API int mk_sync(mk_context *ctx);
 /* 1 if a kernel for (N,K) is compiled into the library. */
 MK_API int mk_shape_supported(int64_t N, int64_t K);
+/* Doubles per packed record (see mk_outputs.record_stride) for state dimension n = N + K. */
+MK_API int64_t mk_record_stride(int64_t n);
 /* Writes up to `cap` supported (N,K) pairs into shapes[2*i], shapes[2*i+1]; returns the count. */
 MK_API int mk_supported_shapes(int64_t *shapes, int cap);
 

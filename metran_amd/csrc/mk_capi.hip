@@ -121,6 +121,8 @@ MK_API int mk_shape_supported(int64_t N, int64_t K)
     return 0;
 }
 
+MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
+
 MK_API int mk_supported_shapes(int64_t *shapes, int cap)
 {
     const int cnt = mk::num_shapes();
@@ -210,10 +212,33 @@ static int check_problem(const mk_problem *p)
     return MK_OK;
 }
 
+// Packed-record convention of mk_outputs.record_stride: returns 0 if `o` does not use records,
+// 1 if it does (and is consistent), < 0 on an inconsistent description.
+static int records_filter(const mk_problem *p, const mk_outputs *o)
+{
+    if (o->record_stride == 0) return 0;
+    const int64_t n = p->N + p->K, nv = n + n * n;
+    if (o->record_stride != mk::record_stride((int)n))
+        return fail(MK_ERR_INVALID, "record_stride must be mk_record_stride(n) = %d doubles", mk::record_stride((int)n));
+    const bool any = o->d_F || o->d_Pf || o->d_Xp || o->d_Pp;
+    if (!any) return 0; // bookkeeping-only / loglik launches do not touch state arrays
+    if (!(o->d_F && o->d_Xp && o->d_Pf == o->d_F + n && o->d_Pp == o->d_Xp + n))
+        return fail(MK_ERR_INVALID, "record layout needs d_Xp, d_F record arrays with d_Pp = d_Xp + n, d_Pf = d_F + n");
+    if (o->d_sigmas || o->d_detfs)
+        if (o->d_sigmas != o->d_F + nv || (o->d_detfs && o->d_detfs != o->d_sigmas + 1))
+            return fail(MK_ERR_INVALID, "record layout needs d_sigmas = d_F + n + n*n and d_detfs = d_sigmas + 1");
+    return 1;
+}
+
 static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
 {
     if (!p->d_obs || !p->d_loadings) return fail(MK_ERR_INVALID, "d_obs and d_loadings are required");
+    const int rec = records_filter(p, o);
+    if (rec < 0) return rec;
     mk::FilterArgs a;
+    a.rs = rec ? o->record_stride : 0;
+    // dense sigmas/detfs are [B,T] (stride 1); inside filtered records they are RS doubles apart
+    a.sig_stride = o->record_stride ? o->record_stride : 1;
     a.B = p->n_instances;
     a.R = p->n_records;
     a.T = p->T;
@@ -253,6 +278,15 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (!o->d_F || !o->d_Pf)
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
     mk::SmootherArgs a;
+    a.rs = 0;
+    if (o->record_stride) {
+        const int64_t n = p->N + p->K;
+        if (o->record_stride != mk::record_stride((int)n))
+            return fail(MK_ERR_INVALID, "record_stride must be mk_record_stride(n) = %d doubles", mk::record_stride((int)n));
+        if (!(o->d_Pf == o->d_F + n && o->d_S && o->d_Ps == o->d_S + n))
+            return fail(MK_ERR_INVALID, "record layout needs d_Pf = d_F + n and a smoothed record array d_S with d_Ps = d_S + n");
+        a.rs = o->record_stride;
+    }
     a.B = p->n_instances;
     a.T = p->T;
     a.bs = o->time_major ? 1 : p->T;

@@ -24,6 +24,8 @@ namespace mk {
 struct FilterArgs {
     long B, R, T, warmup;
     long bs, ts;         // state/bookkeeping outputs: block (b, t) at index b*bs + t*ts
+    long rs;             // > 0: packed records of rs doubles (Xp/F are the record arrays), 0: dense arrays
+    long sig_stride;     // element stride of sigmas/detfs entries (1 for dense [B,T] arrays)
     long obs_bs, obs_ts; // observations: record (r, t) at row r*obs_bs + t*obs_ts
     const double *obs, *phi, *q, *loadings, *obsvar, *x0, *P0;
     double *mle, *sigmas, *detfs;
@@ -35,6 +37,7 @@ struct FilterArgs {
 struct SmootherArgs {
     long B, T;
     long bs, ts;
+    long rs;             // > 0: F and S are packed-record arrays (Pf = F + n, Ps = S + n)
     const double *phi, *q;
     const double *F, *Pf;
     double *S, *Ps;
@@ -43,6 +46,7 @@ struct SmootherArgs {
 
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);
 hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s);
+int record_stride(int n); // doubles per packed record for state dimension n
 int num_shapes();
 void get_shape(int i, int *N, int *K);
 hipError_t launch_params(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,

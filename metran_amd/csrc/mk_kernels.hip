@@ -314,6 +314,113 @@ struct BlockIO {
     }
 };
 
+// ---------------------------------------------------------------- packed-record I/O (fast path)
+// Measured on MI355X (scripts/ubench/store_pattern2.hip): 6.5 GB of 3200-byte block stores per
+// launch are almost free next to a busy VALU, but the 80-byte mean vectors and 8-byte sigma/detf
+// scalars written as separate arrays cost ~8x more per byte -- they leave every cache line partially
+// written when it is evicted, and partial-line writes throttle HBM.  The fast path therefore keeps
+// ONE record per (model, step) and moment set:
+//     [ x(n) | P(n*n) row-major | sigma, detf (filtered record only) | zero pad ]   RS doubles,
+// RS*8 a multiple of 128 bytes, so that every store instruction covers whole cache lines.  The
+// reference-shaped arrays (F [B,T,n], Pf [B,T,n,n], sigmas [B,T] ...) are strided VIEWS of the record
+// arrays on the host; nothing is copied.  A wavefront's GW models are adjacent in the time-major
+// layout, so lane l moves the 16-byte chunks l, l+64, ... of the wavefront's GW*RS*8 contiguous bytes.
+template <int n, int G>
+struct RecordIO {
+    static constexpr int NV = n + n * n;                    // payload doubles
+    static constexpr int RS = ((NV + 2 + 15) / 16) * 16;    // record stride in doubles (128-byte multiple)
+    static constexpr int RC = RS / 2;                       // 16-byte chunks per record
+    static constexpr int GW = 64 / G;                       // models per wavefront
+    static constexpr int CW = GW * RC;                      // chunks per wavefront-step
+    static constexpr int PER = (CW + 63) / 64;              // chunks per lane
+    static constexpr int LDS_PER_WAVE = GW * RS;            // doubles of one wavefront image
+    using chunk_t = v2d;
+
+    struct Map {          // loop-invariant per-lane addressing of its PER chunks
+        long off[PER];    // element offset of the chunk inside the record ARRAY at t = 0
+        int lq[PER];      // chunk index inside the wavefront's LDS image
+    };
+    static __device__ __forceinline__ Map make_map(int lane64, long inst0, long B, long bs)
+    {
+        Map mp;
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            int q = lane64 + 64 * m;
+            if (q > CW - 1) q = CW - 1; // surplus lanes duplicate the last chunk (same bytes, same address)
+            const int g = q / RC, w = q - g * RC;
+            long ig = inst0 + g;
+            if (ig > B - 1) ig = B - 1; // surplus groups replicate the last model
+            mp.off[m] = ig * bs * RS + 2 * w;
+            mp.lq[m] = q;
+        }
+        return mp;
+    }
+    // registers -> this model's record in the wavefront's LDS image
+    static __device__ __forceinline__ void put(double *img, int g, int r, double x, const double (&row)[n])
+    {
+        img[g * RS + r] = x;
+        store_row<n>(img + g * RS + n + r * n, row);
+    }
+    static __device__ __forceinline__ void put_pad(double *img, int g, double s0, double s1)
+    {
+        *reinterpret_cast<v2d *>(img + g * RS + NV) = v2d{s0, s1};
+    }
+    // zero the pad tail [NV+2, RS) of every record once (it is never rewritten)
+    static __device__ __forceinline__ void clear_tail(double *img, int lane64)
+    {
+        for (int i = lane64; i < GW * (RS - NV - 2); i += 64) {
+            const int g = i / (RS - NV - 2 > 0 ? RS - NV - 2 : 1), w = i % (RS - NV - 2 > 0 ? RS - NV - 2 : 1);
+            img[g * RS + NV + 2 + w] = 0.0;
+        }
+    }
+    // LDS image -> HBM records of this step (base = record array + t*ts*RS)
+    static __device__ __forceinline__ void emit(const double *img, double *base, const Map &mp)
+    {
+        wave_lds_sync();
+        const chunk_t *l = reinterpret_cast<const chunk_t *>(img);
+        chunk_t tmp[PER];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) tmp[m] = l[mp.lq[m]];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base + mp.off[m]) = tmp[m];
+    }
+    static __device__ __forceinline__ void emit2(const double *img0, double *base0, const double *img1, double *base1,
+                                                 const Map &mp)
+    {
+        wave_lds_sync();
+        const chunk_t *l0 = reinterpret_cast<const chunk_t *>(img0);
+        const chunk_t *l1 = reinterpret_cast<const chunk_t *>(img1);
+        chunk_t t0[PER], t1[PER];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            t0[m] = l0[mp.lq[m]];
+            t1[m] = l1[mp.lq[m]];
+        }
+#pragma unroll
+        for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base0 + mp.off[m]) = t0[m];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base1 + mp.off[m]) = t1[m];
+    }
+    // HBM records -> registers (issued one step ahead of use)
+    static __device__ __forceinline__ void load_issue(const double *base, const Map &mp, chunk_t (&buf)[PER])
+    {
+#pragma unroll
+        for (int m = 0; m < PER; ++m) buf[m] = *reinterpret_cast<const chunk_t *>(base + mp.off[m]);
+    }
+    // registers -> LDS image -> x element r and row r of this model
+    static __device__ __forceinline__ void load_finish(double *img, const chunk_t (&buf)[PER], const Map &mp, int g,
+                                                       int r, double &x, double (&row)[n])
+    {
+        wave_lds_sync();
+        chunk_t *l = reinterpret_cast<chunk_t *>(img);
+#pragma unroll
+        for (int m = 0; m < PER; ++m) l[mp.lq[m]] = buf[m];
+        wave_lds_sync();
+        x = img[g * RS + r];
+        load_row<n>(img + g * RS + n + r * n, row);
+    }
+};
+
 constexpr double kLn2 = 0.693147180559945309417232121458;
 constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 
@@ -370,19 +477,61 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 #pragma unroll
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
 
+    // OUT == 1: packed records (RecordIO) -- two wavefront images (predicted, filtered) per wavefront;
+    // OUT == 2: dense arrays with arbitrary strides (BlockIO), one staging buffer per model
     using BIO = BlockIO<n, G>;
-    constexpr int LDS_PER_GROUP = (OUT == 1 ? 2 : 1) * BIO::STRIDE;
-    __shared__ __attribute__((aligned(16))) double lds_io[OUT ? (256 / G) * LDS_PER_GROUP : 2];
-    double *lds = lds_io + (OUT ? (threadIdx.x / G) * LDS_PER_GROUP : 0); // this model's staging buffer
+    using RIO = RecordIO<n, G>;
+    constexpr int LDS_DOUBLES = OUT == 1 ? 4 * 2 * RIO::LDS_PER_WAVE : (OUT == 2 ? BIO::LDS_DOUBLES : 2);
+    __shared__ __attribute__((aligned(16))) double lds_io[LDS_DOUBLES];
+    double *lds = lds_io + (OUT == 2 ? (threadIdx.x / G) * BIO::STRIDE : 0); // OUT == 2: this model's buffer
+    const int lane64 = threadIdx.x & 63;
+    const int gw = lane64 / G; // model index inside the wavefront
+    double *imgP = lds_io + (OUT == 1 ? (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE : 0);
+    double *imgF = imgP + (OUT == 1 ? RIO::LDS_PER_WAVE : 0);
+    typename RIO::Map rmap;
+    if constexpr (OUT == 1) {
+        rmap = RIO::make_map(lane64, (long)blockIdx.x * GPB + (threadIdx.x / 64) * RIO::GW, a.B, a.bs);
+        RIO::clear_tail(imgP, lane64);
+        RIO::clear_tail(imgF, lane64);
+        RIO::put_pad(imgP, gw, 0.0, 0.0);
+    }
+    const long rstep = a.ts * RIO::RS;  // record-array advance per time step
+    double *recP = a.Xp, *recF = a.F;   // OUT == 1: record arrays (Pp = Xp + n, Pf = F + n inside a record)
 
-    const double *yp = a.obs + rec * a.obs_bs * N + jr; // lane j streams series j
-    const long ystep = a.obs_ts * N;
-    // observation ring: y of step t was requested YQ steps earlier (HBM latency under the store
-    // traffic of this kernel exceeds one time step when a SIMD holds a single wavefront)
-    constexpr int YQ = 2;
-    double yq[YQ];
+    // ---- observation stream: tiles of TS = G time steps through LDS ----
+    // vmcnt retires vector-memory operations IN ORDER, so consuming a load makes the wavefront wait for
+    // every older store to be acknowledged by the memory system (~2 us while HBM writes are queued: a
+    // per-step observation load cost +0.35 ms even in a pure-store microbenchmark,
+    // scripts/ubench/store_pattern2.hip).  The observations are therefore fetched 16 steps at a time
+    // (lane l loads the N values of step t0 + l), one tile (16 steps) ahead of use, parked in LDS, and the
+    // per-step value comes from LDS (lgkmcnt, independent of the store queue).
+    constexpr int TS = 16;
+    const int lrow = lane < TS ? lane : TS - 1; // lanes >= TS (G = 64) duplicate row TS-1
+    constexpr bool OV2 = (N % 2 == 0);             // 16-byte row pieces when rows are 16-byte aligned
+    constexpr int ONC = OV2 ? N / 2 : N;
+    using ochunk_t = typename std::conditional<OV2, v2d, double>::type;
+    __shared__ __attribute__((aligned(16))) double lds_obs[(256 / G) * 2 * TS * N];
+    double *otile = lds_obs + (threadIdx.x / G) * 2 * TS * N; // this model's two tiles
+    const double *obase = a.obs + rec * a.obs_bs * N;
+    const long ostep = a.obs_ts * N;
+    ochunk_t oreg[ONC];
+    auto obs_issue = [&](long t0) __attribute__((always_inline)) { // HBM -> registers, row min(t0+lane, T-1)
+        long tr = t0 + lrow;
+        if (tr > T - 1) tr = T - 1;
+        const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + tr * ostep);
 #pragma unroll
-    for (int i = 0; i < YQ; ++i) yq[i] = yp[(i < T ? i : T - 1) * ystep];
+        for (int i = 0; i < ONC; ++i) oreg[i] = src[i];
+    };
+    auto obs_park = [&](int buf) __attribute__((always_inline)) { // registers -> LDS tile `buf`
+        ochunk_t *dst = reinterpret_cast<ochunk_t *>(otile + (buf * TS + lrow) * N);
+#pragma unroll
+        for (int i = 0; i < ONC; ++i) dst[i] = oreg[i];
+        wave_lds_sync();
+    };
+    obs_issue(0);
+    obs_park(0);
+    obs_issue(TS);
+    double ynext = otile[jr]; // y of step 0 for series jr
     double sum_sig = 0.0, sum_det = 0.0;
     double run_mant = 1.0; // !BOOK: prod of f over the counted steps, normalised
     long run_exp = 0;
@@ -391,34 +540,21 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     // (b, t) lives at block index b * bs + t * ts: (bs, ts) = (T, 1) model-major [B,T,..] or (1, B) time-major [T,B,..]
     const long vstep = a.ts * n, bstep = a.ts * n * n;
     const long vec0 = inst * a.bs * n + r;
-    double *pXp = (OUT && a.Xp) ? a.Xp + vec0 : nullptr;
-    double *pF = (OUT && a.F) ? a.F + vec0 : nullptr;
-    double *pPp = (OUT && a.Pp) ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
-    double *pPf = (OUT && a.Pf) ? a.Pf + inst * a.bs * n * n : nullptr;
-
-    // OUT == 1: the covariance blocks of step t are transposed to 16-byte chunks at the end of step t and
-    // written during step t+1, one store after each scalar update.  The staging registers start as
-    // zeros aimed at block 0, which the real step-0 data overwrites later (same wavefront, in order).
-    constexpr int PERC = OUT == 1 ? BIO::PER : 1;
-    constexpr int NSLOT = 2 * PERC;                 // stores per step
-    constexpr int SPO = (NSLOT + N - 1) / N;        // stores issued after each scalar update
-    typename BIO::chunk_t stg0[PERC], stg1[PERC];
-#pragma unroll
-    for (int m = 0; m < PERC; ++m) stg0[m] = stg1[m] = typename BIO::chunk_t(0.0);
-    double *sPp = pPp, *sPf = pPf;
-    auto emit = MK_LAMBDA(sc) {
-        constexpr int slot = decltype(sc)::value;
-        if constexpr (slot < PERC)
-            reinterpret_cast<typename BIO::chunk_t *>(sPp)[BIO::chunk_index(lane, slot)] = stg0[slot];
-        else
-            reinterpret_cast<typename BIO::chunk_t *>(sPf)[BIO::chunk_index(lane, slot - PERC)] = stg1[slot - PERC];
-    };
+    double *pXp = (OUT == 2 && a.Xp) ? a.Xp + vec0 : nullptr;
+    double *pF = (OUT == 2 && a.F) ? a.F + vec0 : nullptr;
+    double *pPp = (OUT == 2 && a.Pp) ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
+    double *pPf = (OUT == 2 && a.Pf) ? a.Pf + inst * a.bs * n * n : nullptr;
 
     for (long t = 0; t < T; ++t) {
-        const double y = yq[0];
-#pragma unroll
-        for (int i = 0; i + 1 < YQ; ++i) yq[i] = yq[i + 1];
-        yq[YQ - 1] = yp[(t + YQ < T ? t + YQ : T - 1) * ystep]; // clamped: branch-free prefetch
+        const double y = ynext;
+        {
+            const long t1 = t + 1; // read next step's observation from LDS now (latency hidden by this step)
+            if ((t1 & (TS - 1)) == 0) { // tile boundary: park the tile loaded TS steps ago, request the next one
+                obs_park((int)((t1 / TS) & 1));
+                obs_issue(t1 + TS);
+            }
+            ynext = otile[(((t1 / TS) & 1) * TS + (t1 & (TS - 1))) * N + jr];
+        }
         // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
         const unsigned long long ball = __ballot(lane < N && isfinite(y));
         const auto vm = Gp::group_bits(ball);
@@ -427,12 +563,8 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         x = phi_r * x;
 #pragma unroll
         for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
-        double Ppred[OUT == 1 ? n : 1]; // OUT == 1: keep the predicted row, store it with the filtered one
         if constexpr (OUT == 1) {
-            *pXp = x; // :332 (replica lanes rewrite lane n-1's element)
-            pXp += vstep;
-#pragma unroll
-            for (int c = 0; c < n; ++c) Ppred[c] = P[c]; // :333, written at the end of the step
+            RIO::put(imgP, gw, r, x, P); // :332-333 predicted record -> LDS image (emitted at the end of the step)
         } else if constexpr (OUT == 2) {
             if (pXp) {
                 *pXp = x;
@@ -487,18 +619,8 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
             }
             fmin_seen = min_f64(fmin_seen, f);
         };
-        auto stores_after = MK_LAMBDA(jc) { // previous step's staged chunks, SPO per scalar update
-            if constexpr (OUT == 1) {
-                constexpr int s0 = decltype(jc)::value * SPO;
-                constexpr int s1 = (s0 + SPO) < NSLOT ? (s0 + SPO) : NSLOT;
-                sfor<s0, s1>(emit);
-            }
-        };
         if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
-            sfor<0, N>(MK_LAMBDA(jc) {
-                update(jc);
-                stores_after(jc);
-            });
+            sfor<0, N>(update);
         } else {
             sfor<0, N>(MK_LAMBDA(jc) {
                 if ((vm >> decltype(jc)::value) & 1) { // uniform within the model's lane group
@@ -507,16 +629,27 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
                     fexp += __builtin_amdgcn_frexp_exp(fmant); // keep the product normalised
                     fmant = __builtin_amdgcn_frexp_mant(fmant);
                 }
-                stores_after(jc);
             });
         }
 
         const int cnt = __popcll((unsigned long long)vm);
+        double pad0 = 0.0, pad1 = 0.0;
+        bool pad_here = false;
         if (cnt > 0) { // :380-382 compressed bookkeeping
             if constexpr (BOOK) {
                 const double detf = fma((double)fexp, kLn2, log(fmant));
-                if (a.sigmas && lead) a.sigmas[inst * a.bs + sc * a.ts] = sigma;
-                if (a.detfs && lead) a.detfs[inst * a.bs + sc * a.ts] = detf;
+                if constexpr (OUT == 1) {
+                    // compressed entry sc lives in the pad of filtered record sc; sc == t unless an earlier
+                    // step of this model was empty (then: one scattered 16-byte store, rare)
+                    pad0 = sigma;
+                    pad1 = detf;
+                    pad_here = (sc == t);
+                    if (!pad_here && lead && a.sigmas)
+                        *reinterpret_cast<v2d *>(a.F + (inst * a.bs + sc * a.ts) * RIO::RS + RIO::NV) = v2d{sigma, detf};
+                } else {
+                    if (a.sigmas && lead) a.sigmas[(inst * a.bs + sc * a.ts) * a.sig_stride] = sigma;
+                    if (a.detfs && lead) a.detfs[(inst * a.bs + sc * a.ts) * a.sig_stride] = detf;
+                }
                 if (sc >= a.warmup) { // get_mle: detfs[warmup:], sigmas[warmup:] are COMPRESSED indices (:563-564)
                     sum_det += detf;
                     sum_sig += sigma;
@@ -534,13 +667,11 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
 
         if constexpr (OUT == 1) {
-            *pF = x; // :389
-            pF += vstep;
-            BIO::stage2(lds, Ppred, P, stg0, stg1, lane, r); // :333, :390 -> written during the next step
-            sPp = pPp;
-            sPf = pPf;
-            pPp += bstep;
-            pPf += bstep;
+            RIO::put(imgF, gw, r, x, P); // :389-390 filtered record
+            RIO::put_pad(imgF, gw, pad_here ? pad0 : 0.0, pad_here ? pad1 : 0.0);
+            RIO::emit2(imgP, recP, imgF, recF, rmap); // whole-cache-line stores of both records
+            recP += rstep;
+            recF += rstep;
         } else if constexpr (OUT == 2) {
             if (pF) {
                 *pF = x;
@@ -553,13 +684,11 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         }
     }
 
-    if constexpr (OUT == 1) sfor<0, NSLOT>(emit); // flush the last step's blocks
-
     // zero tail of the compressed arrays (np.zeros init, :307-308)
-    if (BOOK) {
+    if (BOOK && OUT != 1) { // (OUT == 1: the pads of records >= sigmacount were written as zeros)
         for (long i = sc + lane; i < T; i += G) {
-            if (a.sigmas) a.sigmas[inst * a.bs + i * a.ts] = 0.0;
-            if (a.detfs) a.detfs[inst * a.bs + i * a.ts] = 0.0;
+            if (a.sigmas) a.sigmas[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
+            if (a.detfs) a.detfs[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
         }
     }
     if (lead) {
@@ -577,7 +706,7 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 //   whenever q > 0, where the reference's pinv (:455) is the inverse); lane i solves for ROW i of J.
 //   The factor is DISTRIBUTED: lane c keeps L(c, 0..c-1) in place of its row of A.
 // =====================================================================================
-template <int n, int G>
+template <int n, int G, bool REC>
 __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
 {
     static_assert(n <= G, "state dimension must fit the lane group");
@@ -586,58 +715,103 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     const int lane = threadIdx.x % G;
     long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
     const bool live = inst < a.B;
-    if (!live) inst = a.B - 1;
-    const bool rowok = lane < n;
-    const int r = rowok ? lane : n - 1;
+    if (!live) inst = a.B - 1; // surplus groups replicate the last model (identical stores)
+    const int r = lane < n ? lane : n - 1; // lanes >= n replicate lane n-1
     const long T = a.T;
 
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
-    double phic[n];
-    sfor<0, n>(MK_LAMBDA(c) { phic[c] = Gp::template bcast<decltype(c)::value>(phi_r); });
+    double phic[n], qd[n]; // diag(Phi) replicated; row r of Q = diag(q)
+    sfor<0, n>(MK_LAMBDA(c) {
+        phic[decltype(c)::value] = Gp::template bcast<decltype(c)::value>(phi_r);
+        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
+    });
 
+    // REC: packed records (RecordIO): one load image and one store image per wavefront;
+    // !REC: dense arrays with arbitrary strides (BlockIO), one staging buffer per model
     using BIO = BlockIO<n, G>;
-    __shared__ __attribute__((aligned(16))) double lds_io[BIO::LDS_DOUBLES];
-    double *lds = lds_io + (threadIdx.x / G) * BIO::STRIDE;
+    using RIO = RecordIO<n, G>;
+    constexpr int LDS_DOUBLES = REC ? 4 * 2 * RIO::LDS_PER_WAVE : BIO::LDS_DOUBLES;
+    __shared__ __attribute__((aligned(16))) double lds_io[LDS_DOUBLES];
+    double *lds = lds_io + (REC ? 0 : (threadIdx.x / G) * BIO::STRIDE);
+    const int lane64 = threadIdx.x & 63;
+    const int gw = lane64 / G;
+    double *imgL = lds_io + (REC ? (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE : 0);
+    double *imgS = imgL + (REC ? RIO::LDS_PER_WAVE : 0);
+    typename RIO::Map rmap;
+    if constexpr (REC) {
+        rmap = RIO::make_map(lane64, (long)blockIdx.x * GPB + (threadIdx.x / 64) * RIO::GW, a.B, a.bs);
+        RIO::clear_tail(imgS, lane64);
+        RIO::put_pad(imgS, gw, 0.0, 0.0);
+    }
+    constexpr int PERB = REC ? 1 : BIO::PER, PERR = REC ? RIO::PER : 1;
+    typename BIO::chunk_t preb[PERB]; // !REC: chunks of the next covariance block
+    typename RIO::chunk_t prer[PERR]; //  REC: chunks of the next filtered record
 
-    double qd[n]; // row r of Q = diag(q)
-#pragma unroll
-    for (int c = 0; c < n; ++c) qd[c] = (c == r) ? q_r : 0.0;
+    // addressing: (b, t) at block index b*bs + t*ts
+    const long rstep = a.ts * RIO::RS, vstep = a.ts * n, bstep = a.ts * n * n;
+    const double *recF = REC ? a.F + (T - 1) * rstep : nullptr; // record array positioned at step t
+    double *recS = REC ? a.S + (T - 1) * rstep : nullptr;
+    const long blkT = inst * a.bs + (T - 1) * a.ts;
+    const double *pF = REC ? nullptr : a.F + blkT * n + r;
+    const double *pPf = REC ? nullptr : a.Pf + blkT * n * n;
+    double *pS = (!REC && a.S) ? a.S + blkT * n + r : nullptr;
+    double *pPs = (!REC && a.Ps) ? a.Ps + blkT * n * n : nullptr;
+
+    // fetch helpers: issue the HBM loads of one step / turn them into (x_r, row r)
+    auto issue = [&](double &xnext) __attribute__((always_inline)) {
+        if constexpr (REC) {
+            recF -= rstep;
+            RIO::load_issue(recF, rmap, prer);
+        } else {
+            pF -= vstep;
+            pPf -= bstep;
+            BIO::load_issue(pPf, preb, lane);
+            xnext = *pF;
+        }
+    };
+    auto finish = [&](double &xv, double(&row)[n]) __attribute__((always_inline)) {
+        if constexpr (REC) RIO::load_finish(imgL, prer, rmap, gw, r, xv, row);
+        else BIO::load_finish(lds, preb, row, lane, r);
+    };
+    auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
+        if constexpr (REC) {
+            RIO::put(imgS, gw, r, xv, row);
+            RIO::emit(imgS, recS, rmap);
+            recS -= rstep;
+        } else {
+            if (pS) {
+                *pS = xv;
+                pS -= vstep;
+            }
+            if (pPs) {
+                BIO::store(lds, pPs, row, lane, r);
+                pPs -= bstep;
+            }
+        }
+    };
 
     // last step: smoothed = filtered (:450-451)
-    const long vstep = a.ts * n, bstep = a.ts * n * n;
-    const long blkT = inst * a.bs + (T - 1) * a.ts; // block index of (inst, T-1)
-    const long vecT = blkT * n + r;
-    const double *pF = a.F + vecT;
-    const double *pPf = a.Pf + blkT * n * n; // block of step t
-    double *pS = a.S ? a.S + vecT : nullptr;
-    double *pPs = a.Ps ? a.Ps + blkT * n * n : nullptr;
-    double xs = *pF;
-    double Psn[n];
-    typename BIO::chunk_t pre[BIO::PER];
-    BIO::load_issue(pPf, pre, lane);
-    BIO::load_finish(lds, pre, Psn, lane, r);
-    if (pS) *pS = xs;
-    if (pPs) BIO::store(lds, pPs, Psn, lane, r);
+    double xs, Psn[n];
+    if constexpr (REC) {
+        RIO::load_issue(recF, rmap, prer);
+    } else {
+        BIO::load_issue(pPf, preb, lane);
+        xs = *pF;
+    }
+    finish(xs, Psn);
+    store(xs, Psn);
     double pivmin = 1.0;
 
     // Software pipeline: at the top of iteration t the ROWS of Pf[t] (Pfc) and F[t] (xfc) are already in
-    // registers and the 16-byte chunks of Pf[t-1] (pre) are in flight from HBM; their LDS transposition
-    // (pre -> Pfn) is issued in the middle of the iteration so that its latency hides behind the
-    // Ps sweep, and the HBM loads for t-2 are issued right after it.
+    // registers and the 16-byte chunks of step t-1 are in flight from HBM; their LDS transposition is issued
+    // in the middle of the iteration so that its latency hides behind the Ps sweep, and the HBM loads for
+    // t-2 are issued right after it.
     double Pfc[n], xfc = 0.0, xfn = 0.0;
     if (T >= 2) {
-        pF -= vstep;
-        pPf -= bstep;
-        BIO::load_issue(pPf, pre, lane);
-        xfc = *pF;
-        BIO::load_finish(lds, pre, Pfc, lane, r);
-        if (T >= 3) {
-            pF -= vstep;
-            pPf -= bstep;
-            BIO::load_issue(pPf, pre, lane);
-            xfn = *pF;
-        }
+        issue(xfc);
+        finish(xfc, Pfc);
+        if (T >= 3) issue(xfn);
     }
 
     for (long t = T - 2; t >= 0; --t) {
@@ -649,11 +823,11 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
             A[c] = fma(phi_r, z[c], qd[c]);
             D[c] = Psn[c] - A[c];
         }
-
         double delta = xs - phi_r * xfc; // xs[t+1] - Xp[t+1]; formed early so that it is "old" when DPP-read
         if constexpr (G == 16) dpp_pin(delta);
 
         // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
+        if constexpr (G == 16) dpp_guard(A); // A is compiler-produced (build-time hazard check)
         double dinv[n];
         sfor<0, n>(MK_LAMBDA(jc) {
             constexpr int j = decltype(jc)::value;
@@ -701,17 +875,12 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
 #pragma unroll
         for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
 
-        // mid-iteration: transpose the chunks of Pf[t-1] into rows (LDS latency hides behind the
-        // sweep below) and issue the HBM loads of Pf[t-2]
-        const double xf_next = xfn;
+        // mid-iteration: transpose the chunks of step t-1 into rows (LDS latency hides behind the
+        // sweep below) and issue the HBM loads of step t-2
+        double xf_next = xfn;
         if (t >= 1) {
-            BIO::load_finish(lds, pre, Pfc, lane, r);
-            if (t >= 2) {
-                pF -= vstep;
-                pPf -= bstep;
-                BIO::load_issue(pPf, pre, lane);
-                xfn = *pF;
-            }
+            finish(xf_next, Pfc);
+            if (t >= 2) issue(xfn);
         }
 
         // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
@@ -720,14 +889,7 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
             Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
         });
 
-        if (pS) {
-            pS -= vstep;
-            *pS = xs;
-        }
-        if (pPs) {
-            pPs -= bstep;
-            BIO::store(lds, pPs, Psn, lane, r);
-        }
+        store(xs, Psn);
         xfc = xf_next;
     }
     if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
@@ -829,12 +991,11 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
     const bool book = a.sigmas || a.detfs;
     const bool any = a.F || a.Pf || a.Xp || a.Pp;
-    const bool all = a.F && a.Pf && a.Xp && a.Pp;
     if (!any && !book)
         hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false>), dim3(grid), dim3(256), 0, s, a);
     else if (!any)
         hipLaunchKernelGGL((filter_kernel<N, K, G, 0, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (all)
+    else if (a.rs > 0) // packed records (validated by the C ABI): whole-cache-line stores
         hipLaunchKernelGGL((filter_kernel<N, K, G, 1, true>), dim3(grid), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((filter_kernel<N, K, G, 2, true>), dim3(grid), dim3(256), 0, s, a);
@@ -847,7 +1008,10 @@ static hipError_t launch_smoother_n(const SmootherArgs &a, hipStream_t s)
     constexpr int G = n <= 16 ? 16 : 64;
     constexpr int GPB = 256 / G;
     const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
-    hipLaunchKernelGGL((smoother_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
+    if (a.rs > 0)
+        hipLaunchKernelGGL((smoother_kernel<n, G, true>), dim3(grid), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((smoother_kernel<n, G, false>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -870,6 +1034,8 @@ hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s)
 }
 
 static const int kShapes[][2] = {MK_SHAPES(MK_CASE_LIST)};
+
+int record_stride(int n) { return ((n + n * n + 2 + 15) / 16) * 16; } // == RecordIO<n, G>::RS
 
 int num_shapes() { return (int)(sizeof(kShapes) / sizeof(kShapes[0])); }
 void get_shape(int i, int *N, int *K)

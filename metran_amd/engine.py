@@ -218,19 +218,49 @@ class BatchedKalman:
         check(self._L.mk_loglik(self._ctx, ctypes.byref(prob), self._p(mle)))
         return mle
 
+    def record_stride(self):
+        """Doubles per packed (model, step) record for this state dimension (C ABI ``mk_record_stride``)."""
+        return int(self._L.mk_record_stride(self.n))
+
+    def _alloc_records(self, B):
+        """One record array ``[B,T,RS]`` (logical; memory follows the engine layout) and its views
+        ``(mean [B,T,n], cov [B,T,n,n], pad0 [B,T], pad1 [B,T])``."""
+        T, n = self.T, self.n
+        RS = self.record_stride()
+        rec = self._empty_bt(B, T, RS)
+        nv = n + n * n
+        return rec, rec[..., :n], rec[..., n:nv].unflatten(-1, (n, n)), rec[..., nv], rec[..., nv + 1]
+
     def _alloc_outputs(self, B, want, bookkeeping=True):
+        """Output tensors for one launch.  When the predicted and filtered moments (and, if any, both
+        smoothed moments) are all requested, they are allocated as PACKED RECORDS (the kernels' fast
+        path, see ``mk_outputs.record_stride``) and the entries of the returned dict are views."""
         torch = _torch()
         T, n = self.T, self.n
         f64 = dict(dtype=torch.float64, device=self.device)
-        res = {"mle": torch.empty(B, **f64)}
-        if bookkeeping:
-            res["sigmas"] = self._empty_bt(B, T)
-            res["detfs"] = self._empty_bt(B, T)
-            res["sigmacount"] = torch.empty(B, dtype=torch.int64, device=self.device)
-        res["status"] = torch.zeros(B, dtype=torch.int32, device=self.device)
+        want = list(want)
         for k in want:
             if k not in _STATE_OUTPUTS:
                 raise ValueError("unknown output %r (choose from %s)" % (k, _STATE_OUTPUTS))
+        res = {"mle": torch.empty(B, **f64)}
+        res["status"] = torch.zeros(B, dtype=torch.int32, device=self.device)
+        if bookkeeping:
+            res["sigmacount"] = torch.empty(B, dtype=torch.int64, device=self.device)
+        smooth_pair = ("S" in want) + ("Ps" in want)
+        records = all(k in want for k in ("F", "Pf", "Xp", "Pp")) and smooth_pair in (0, 2)
+        if records:
+            res["_rs"] = self.record_stride()
+            res["_rec_pred"], res["Xp"], res["Pp"], _, _ = self._alloc_records(B)
+            res["_rec_filt"], res["F"], res["Pf"], sig, det = self._alloc_records(B)
+            if bookkeeping:
+                res["sigmas"], res["detfs"] = sig, det
+            if smooth_pair:
+                res["_rec_smooth"], res["S"], res["Ps"], _, _ = self._alloc_records(B)
+            return res
+        if bookkeeping:
+            res["sigmas"] = self._empty_bt(B, T)
+            res["detfs"] = self._empty_bt(B, T)
+        for k in want:
             res[k] = self._empty_bt(B, T, n) if k in ("F", "Xp", "S") else self._empty_bt(B, T, n, n)
         return res
 
@@ -238,7 +268,7 @@ class BatchedKalman:
         g = res.get
         return Outputs(self._p(g("mle")), self._p(g("sigmas")), self._p(g("detfs")), self._p(g("sigmacount")),
                        self._p(g("F")), self._p(g("Pf")), self._p(g("Xp")), self._p(g("Pp")), self._p(g("S")),
-                       self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0)
+                       self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0, int(g("_rs", 0)))
 
     def filter(self, phi, q, warmup=1, x0=None, P0=None, outputs=("F", "Pf", "Xp", "Pp"), buffers=None):
         """``run_filter`` for B instances (kalmanfilter.py:696-778).  Returns a dict of device tensors."""
@@ -252,6 +282,8 @@ class BatchedKalman:
     def filter_smooth(self, phi, q, warmup=1, x0=None, P0=None, outputs=_STATE_OUTPUTS, buffers=None):
         """``run_smoother`` for B instances (kalmanfilter.py:676-694): filter, then RTS smoother."""
         want = set(outputs) | {"F", "Pf"}  # the backward pass re-reads the filtered moments
+        if {"Xp", "Pp"} <= want:
+            want |= {"S", "Ps"}  # full output set -> packed records for all three moment sets
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         res = buffers if buffers is not None else self._alloc_outputs(B, [k for k in _STATE_OUTPUTS if k in want])
         o = self._outputs_struct(res)

@@ -11,7 +11,10 @@ __global__ void k(v2d* a0, v2d* a1, double* v0, double* v1, double* s0, double* 
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     double acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = lane + i;
+    const double* yp = v1 + ((wave * 4 + g) * 8 + (l & 7));  // FLAGS&16: obs-like read, time-major [T][models][8]
+    double ynext = (FLAGS & 16) ? yp[0] : 0.0;
     for (int t = 0; t < T; ++t) {
+        if (FLAGS & 16) { acc[0] += ynext; ynext = yp[(long)(t + 1 < T ? t + 1 : t) * nw * 32]; }
         if (FLAGS & 8) { for (int s = 0; s < work; ++s) { for (int i = 0; i < 8; ++i) acc[i] = fma(acc[i], 1.0000001, 1e-9); } }
         else { for (int s = 0; s < work * 8; ++s) acc[0] = fma(acc[0], 1.0000001, 1e-9); }
         v2d val = {acc[0], acc[1]};
@@ -59,6 +62,8 @@ int main()
         run<8 | 4>("busy VALU + 2 scalar arrays", a0, a1, v0, v1, s0, s1, work);
         run<8 | 1 | 2>("busy VALU + blocks + vectors", a0, a1, v0, v1, s0, s1, work);
         run<8 | 1 | 2 | 4>("busy VALU + blocks + vectors + scalars", a0, a1, v0, v1, s0, s1, work);
+        run<8 | 16>("busy VALU + obs-like reads only", a0, a1, v0, v1, s0, s1, work);
+        run<8 | 1 | 16>("busy VALU + 2 block arrays + obs-like reads", a0, a1, v0, v1, s0, s1, work);
         run<0>("idle VALU (dependent chain), no stores", a0, a1, v0, v1, s0, s1, work);
         run<1 | 2 | 4>("idle VALU + blocks + vectors + scalars", a0, a1, v0, v1, s0, s1, work);
     }
