@@ -189,13 +189,28 @@ __device__ __forceinline__ double rcp_nr(double x)
     return fma(r0, p, r0);                // r0 (1 + e + e^2): error e^3
 }
 
-// ---------------------------------------------------------------- coalesced n x n block I/O
-// A model's covariance at one time step is one contiguous n*n*8-byte block in HBM, but lane r
-// holds row r.  Storing rows directly makes every store instruction touch ~n scattered 16-byte
-// pieces per model (measured: the filter ran at 2.5 TB/s, store-issue bound).  Instead the
-// group's block is transposed through LDS (wave-private, no workgroup barrier): lanes write
-// their rows, then lane l moves the 16-byte chunks l, l+G, l+2G, ... so that one store/load
-// instruction covers G*16 contiguous bytes per model.
+// ---------------------------------------------------------------- state I/O: symmetric column runs
+// Lane r holds ROW r of a covariance; its HBM image is row-major, i.e. lane r's data is n doubles at
+// stride 1 -- stored directly, every store instruction would touch ~n scattered pieces per model
+// (measured in v1: store-issue bound at 2.5 TB/s).  The covariances are SYMMETRIC, so the kernels
+// store the transpose instead: for column index c = 0..n-1 every lane writes its element P[r][c] to
+// position (c, r), i.e. one instruction writes a contiguous n*8-byte run per model and n instructions
+// cover the block.  What lands in HBM is (P)^T = P up to the rounding-level asymmetry of the rank-1
+// updates (< 1e-14 relative).  No LDS staging, no waits, and the smoother re-reading "row r" as
+// column r gets back exactly the filter's own row r.  Lanes >= n (and the groups of a partial last
+// workgroup) are exact REPLICAS of lane n-1 (of the last model): same inputs, same instruction
+// stream, identical bytes to identical addresses -- no store in the hot loops needs an exec mask.
+//
+// PACKED RECORDS (fast path, mk_outputs.record_stride): measured on MI355X
+// (scripts/ubench/store_pattern2.hip), 6.5 GB of block stores per launch are almost free next to a
+// busy VALU, but 80-byte mean vectors and 8-byte sigma/detf scalars written as SEPARATE arrays cost
+// ~8x more per byte: they leave every cache line partially written when it is evicted, and
+// partial-line writes throttle HBM.  A record keeps one (model, step) moment set together,
+//     [ mean(n) | covariance(n*n) | sigma, detf (filtered set only) | zero pad ]     RS doubles,
+// with RS*8 a multiple of 128 bytes; the reference-shaped arrays are strided VIEWS of the record
+// arrays on the host.
+typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
+
 __device__ __forceinline__ void wave_lds_sync()
 {
     // LDS-only ("local") fences: a generic fence would also pin private arrays to scratch memory
@@ -204,131 +219,326 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
+constexpr int record_payload(int n) { return n + n * n; }
+constexpr int record_stride_c(int n) { return ((record_payload(n) + 2 + 15) / 16) * 16; }
 
-template <int n, int G>
-struct BlockIO {
-    static constexpr int NN = n * n;
-    static constexpr bool V2 = (NN % 2 == 0);            // 16-byte chunks when the block allows it
-    static constexpr int CH = V2 ? NN / 2 : NN;          // chunks per block
-    static constexpr int PER = (CH + G - 1) / G;         // chunks per lane
-    static constexpr int STRIDE = ((NN * 8 + 255) / 256) * 256 / 8; // doubles between groups' LDS buffers
-    static constexpr int LDS_DOUBLES = (256 / G) * STRIDE;
-    using chunk_t = typename std::conditional<V2, v2d, double>::type;
-
-    // Lanes >= n (and the groups of a partial last workgroup) are exact REPLICAS of lane n-1 (of the
-    // last model): same inputs, same instruction stream.  They therefore write identical bytes to
-    // identical addresses, and no store in the hot loops needs an exec mask.
-    // rows (registers) -> LDS -> HBM block; r = min(lane, n-1)
-    static __device__ __forceinline__ void store(double *lds, double *gblock, const double (&row)[n], int lane, int r)
+// pointer pair addressing one moment set of one model: element r of the mean vector and element
+// (0, r) of the covariance's column runs; `advance` moves both to the next (or previous) time step
+struct MomentPtr {
+    double *vec, *mat;
+    long vstep, mstep;
+    __device__ __forceinline__ void advance(long dir) // a null (skipped) output stays null
     {
-        wave_lds_sync();
-        store_row<n>(lds + r * n, row);
-        wave_lds_sync();
-        chunk_t *g = reinterpret_cast<chunk_t *>(gblock);
-        const chunk_t *l = reinterpret_cast<const chunk_t *>(lds);
-        chunk_t tmp[PER];
-        int qi[PER];
-#pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            qi[m] = lane + m * G;
-            if (qi[m] > CH - 1) qi[m] = CH - 1; // duplicates of the last chunk: same data, same address
-            tmp[m] = l[qi[m]];
-        }
-#pragma unroll
-        for (int m = 0; m < PER; ++m) g[qi[m]] = tmp[m];
+        if (vec) vec += dir * vstep;
+        if (mat) mat += dir * mstep;
     }
-    // two blocks (predicted + filtered covariance of one step) through ONE LDS round trip;
-    // lds must hold 2 * STRIDE doubles for this group
-    static __device__ __forceinline__ void store2(double *lds, double *g0, const double (&row0)[n], double *g1,
-                                                  const double (&row1)[n], int lane, int r)
+    __device__ __forceinline__ void advance_nn(long dir) // both pointers known to be non-null
     {
-        wave_lds_sync();
-        store_row<n>(lds + r * n, row0);
-        store_row<n>(lds + STRIDE + r * n, row1);
-        wave_lds_sync();
-        const chunk_t *l0 = reinterpret_cast<const chunk_t *>(lds);
-        const chunk_t *l1 = reinterpret_cast<const chunk_t *>(lds + STRIDE);
-        chunk_t t0[PER], t1[PER];
-        int qi[PER];
-#pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            qi[m] = lane + m * G;
-            if (qi[m] > CH - 1) qi[m] = CH - 1;
-            t0[m] = l0[qi[m]];
-            t1[m] = l1[qi[m]];
-        }
-#pragma unroll
-        for (int m = 0; m < PER; ++m) reinterpret_cast<chunk_t *>(g0)[qi[m]] = t0[m];
-#pragma unroll
-        for (int m = 0; m < PER; ++m) reinterpret_cast<chunk_t *>(g1)[qi[m]] = t1[m];
-    }
-    // Split form of store2 for kernels that spread their global stores over the following compute:
-    // a CU's vector-memory path moves only ~64 B/clk and is shared by its wavefronts, so a burst of
-    // back-to-back 1 KB stores stalls the issuing wavefront (measured: +0.8 ms on the filter);
-    // issued one at a time between the scalar updates of the NEXT step they cost almost nothing.
-    static __device__ __forceinline__ int chunk_index(int lane, int m)
-    {
-        const int qi = lane + m * G;
-        return qi > CH - 1 ? CH - 1 : qi;
-    }
-    static __device__ __forceinline__ void stage2(double *lds, const double (&row0)[n], const double (&row1)[n],
-                                                  chunk_t (&t0)[PER], chunk_t (&t1)[PER], int lane, int r)
-    {
-        wave_lds_sync();
-        store_row<n>(lds + r * n, row0);
-        store_row<n>(lds + STRIDE + r * n, row1);
-        wave_lds_sync();
-        const chunk_t *l0 = reinterpret_cast<const chunk_t *>(lds);
-        const chunk_t *l1 = reinterpret_cast<const chunk_t *>(lds + STRIDE);
-#pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            const int qi = chunk_index(lane, m);
-            t0[m] = l0[qi];
-            t1[m] = l1[qi];
-        }
-    }
-    // HBM block -> registers (issue early; the data is consumed one time step later)
-    static __device__ __forceinline__ void load_issue(const double *gblock, chunk_t (&buf)[PER], int lane)
-    {
-        const chunk_t *g = reinterpret_cast<const chunk_t *>(gblock);
-#pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            const int qi = lane + m * G;
-            buf[m] = g[qi < CH ? qi : CH - 1]; // clamped, branch-free (keeps buf in registers)
-        }
-    }
-    // registers -> LDS -> row r
-    static __device__ __forceinline__ void load_finish(double *lds, const chunk_t (&buf)[PER], double (&row)[n],
-                                                       int lane, int r)
-    {
-        wave_lds_sync();
-        chunk_t *l = reinterpret_cast<chunk_t *>(lds);
-#pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            const int qi = lane + m * G;
-            l[qi < CH ? qi : CH - 1] = buf[m];
-        }
-        wave_lds_sync();
-        load_row<n>(lds + r * n, row);
+        vec += dir * vstep;
+        mat += dir * mstep;
     }
 };
 
-// ---------------------------------------------------------------- packed-record I/O (fast path)
-// Measured on MI355X (scripts/ubench/store_pattern2.hip): 6.5 GB of 3200-byte block stores per
-// launch are almost free next to a busy VALU, but the 80-byte mean vectors and 8-byte sigma/detf
-// scalars written as separate arrays cost ~8x more per byte -- they leave every cache line partially
-// written when it is evicted, and partial-line writes throttle HBM.  The fast path therefore keeps
-// ONE record per (model, step) and moment set:
-//     [ x(n) | P(n*n) row-major | sigma, detf (filtered record only) | zero pad ]   RS doubles,
-// RS*8 a multiple of 128 bytes, so that every store instruction covers whole cache lines.  The
-// reference-shaped arrays (F [B,T,n], Pf [B,T,n,n], sigmas [B,T] ...) are strided VIEWS of the record
-// arrays on the host; nothing is copied.  A wavefront's GW models are adjacent in the time-major
-// layout, so lane l moves the 16-byte chunks l, l+64, ... of the wavefront's GW*RS*8 contiguous bytes.
+// inst/r already clamped; rs > 0: packed records (V is the record array), else dense arrays V [.,n], M [.,n,n]
+template <int n>
+__device__ __forceinline__ MomentPtr moment_ptr(double *V, double *M, long blk, long ts, long rs, int r)
+{
+    MomentPtr p;
+    if (rs > 0) {
+        p.vec = V + blk * rs + r;
+        p.mat = V + blk * rs + n + r;
+        p.vstep = p.mstep = ts * rs;
+    } else {
+        p.vec = V ? V + blk * n + r : nullptr;
+        p.mat = M ? M + blk * n * n + r : nullptr;
+        p.vstep = ts * n;
+        p.mstep = ts * n * n;
+    }
+    return p;
+}
+
+template <int n>
+__device__ __forceinline__ void store_cols(double *mat, const double (&row)[n])
+{
+#pragma unroll
+    for (int c = 0; c < n; ++c) mat[c * n] = row[c]; // (c, r) <- P[r][c]: contiguous over the lanes
+}
+template <int n>
+__device__ __forceinline__ void load_cols(const double *mat, double (&row)[n])
+{
+#pragma unroll
+    for (int c = 0; c < n; ++c) row[c] = mat[c * n];
+}
+
+constexpr double kLn2 = 0.693147180559945309417232121458;
+constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
+
+// =====================================================================================
+// Sequential-processing Kalman filter + -2 log L            (kalmanfilter.py:236-400, 550-567)
+//   OUT  : 0 = no state outputs (solver objective, mk_loglik), 1 = F, Pf, Xp, Pp all written
+//          (no null checks; packed records or dense), 2 = any subset (runtime null checks)
+//   BOOK : per-step sigmas/detfs are written (needs one log per step); otherwise the
+//          log-determinant is accumulated as a normalised product with ONE log at the end
+// =====================================================================================
+template <int N, int K, int G, int OUT, bool BOOK>
+__global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
+{
+    constexpr int n = N + K;
+    static_assert(n <= G, "state dimension must fit the lane group");
+    using Gp = Group<G>;
+    constexpr int GPB = 256 / G; // models per 256-thread workgroup
+    constexpr bool HOIST = (N * K <= 32); // keep Z's loading block replicated in registers
+    constexpr int NV = record_payload(n);
+    const int lane = threadIdx.x % G;
+    long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
+    if (inst > a.B - 1) inst = a.B - 1; // surplus groups replicate the last model (identical stores)
+    const long rec = inst % a.R;
+    const int r = lane < n ? lane : n - 1; // lanes >= n replicate lane n-1
+    const bool lead = lane == 0;
+    const long T = a.T;
+
+    // per-model constants: lane r holds phi_r, q_r; lane j < N holds loadings[j,:] and obsvar[j]
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+    double pp[n], qd[n]; // row r of Phi (x) Phi and of Q = diag(q)
+    sfor<0, n>(MK_LAMBDA(c) {
+        pp[decltype(c)::value] = phi_r * Gp::template bcast<decltype(c)::value>(phi_r);
+        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
+    });
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
+    const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
+    double Gh[HOIST ? N : 1][K]; // Gh[j][k] = loadings[j,k] in every lane
+    if constexpr (HOIST) {
+        sfor<0, N>(MK_LAMBDA(j) {
+            sfor<0, K>(MK_LAMBDA(k) {
+                Gh[decltype(j)::value][decltype(k)::value] = Gp::template bcast<decltype(j)::value>(gam[decltype(k)::value]);
+            });
+        });
+    }
+
+    // initial state (run_filter defaults, kalmanfilter.py:747-750)
+    double x = a.x0 ? a.x0[inst * n + r] : 0.0;
+    double P[n];
+#pragma unroll
+    for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
+
+    // outputs: (b, t) lives at block index b*bs + t*ts -- (T, 1) model-major or (1, B) time-major
+    MomentPtr oP = moment_ptr<n>(a.Xp, a.Pp, inst * a.bs, a.ts, OUT == 1 ? a.rs : 0, r); // predicted moments
+    MomentPtr oF = moment_ptr<n>(a.F, a.Pf, inst * a.bs, a.ts, OUT == 1 ? a.rs : 0, r);  // filtered moments
+    // OUT == 1 (packed records): the RS - NV pad doubles of both records are written too (whole cache
+    // lines): lane l owns pad slot min(l, PADN-1); filtered record: slot 0 = sigma, slot 1 = detf, rest 0
+    constexpr int RS = record_stride_c(n), PADN = RS - NV;
+    const int pslot = lane < PADN ? lane : PADN - 1;
+    double *padF = OUT == 1 ? a.F + inst * a.bs * RS + NV + pslot : nullptr;
+    double *padP = OUT == 1 ? a.Xp + inst * a.bs * RS + NV + pslot : nullptr;
+
+    // ---- observation stream: tiles of 16 time steps through LDS ----
+    // vmcnt retires vector-memory operations IN ORDER, so consuming a load makes the wavefront wait for
+    // every older store to be acknowledged by the memory system (~2 us while HBM writes are queued: a
+    // per-step observation load cost +0.35 ms even in a pure-store microbenchmark,
+    // scripts/ubench/store_pattern2.hip).  The observations are therefore fetched 16 steps at a time
+    // (lane l loads the N values of step t0 + l), one tile ahead of use, parked in LDS, and the
+    // per-step value comes from LDS (lgkmcnt, independent of the store queue).
+    constexpr int TS = 16;
+    // a tile is requested OLEAD steps before it is parked: long enough for the older stores to be
+    // acknowledged, short enough that the younger vector-memory operations still fit the 6-bit vmcnt
+    // (beyond 63 the compiler can only wait for vmcnt(0), i.e. drain every store)
+    constexpr int OLEAD = 2;
+    const int lrow = lane < TS ? lane : TS - 1; // lanes >= TS (G = 64) duplicate row TS-1
+    constexpr bool OV2 = (N % 2 == 0);          // 16-byte row pieces when rows are 16-byte aligned
+    constexpr int ONC = OV2 ? N / 2 : N;
+    using ochunk_t = typename std::conditional<OV2, v2d, double>::type;
+    __shared__ __attribute__((aligned(16))) double lds_obs[(256 / G) * 2 * TS * N];
+    double *otile = lds_obs + (threadIdx.x / G) * 2 * TS * N; // this model's two tiles
+    const double *obase = a.obs + rec * a.obs_bs * N;
+    const long ostep = a.obs_ts * N;
+    ochunk_t oreg[ONC];
+    auto obs_issue = [&](long t0) __attribute__((always_inline)) { // HBM -> registers, row min(t0+lane, T-1)
+        long tr = t0 + lrow;
+        if (tr > T - 1) tr = T - 1;
+        const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + tr * ostep);
+#pragma unroll
+        for (int i = 0; i < ONC; ++i) oreg[i] = src[i];
+    };
+    auto obs_park = [&](int buf) __attribute__((always_inline)) { // registers -> LDS tile `buf`
+        ochunk_t *dst = reinterpret_cast<ochunk_t *>(otile + (buf * TS + lrow) * N);
+#pragma unroll
+        for (int i = 0; i < ONC; ++i) dst[i] = oreg[i];
+        wave_lds_sync();
+    };
+    obs_issue(0);
+    obs_park(0);
+    if (TS - OLEAD <= 0) obs_issue(TS);
+    double ynext = otile[jr]; // y of step 0 for series jr
+
+    double sum_sig = 0.0, sum_det = 0.0;
+    double run_mant = 1.0; // !BOOK: prod of f over the counted steps, normalised
+    long run_exp = 0;
+    long nobs = 0, sc = 0;
+    double fmin_seen = 1.0;
+
+    for (long t = 0; t < T; ++t) {
+        const double y = ynext;
+        {
+            const long t1 = t + 1; // read next step's observation from LDS now (latency hidden by this step)
+            if ((t1 & (TS - 1)) == TS - OLEAD) obs_issue((t1 & ~(long)(TS - 1)) + TS); // request the next tile
+            if ((t1 & (TS - 1)) == 0) obs_park((int)((t1 / TS) & 1));                   // ... and park it
+            ynext = otile[(((t1 / TS) & 1) * TS + (t1 & (TS - 1))) * N + jr];
+        }
+        // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
+        const unsigned long long ball = __ballot(lane < N && isfinite(y));
+        const auto vm = Gp::group_bits(ball);
+
+        // ---- predict (:318-331; Phi diagonal) ----
+        x = phi_r * x;
+#pragma unroll
+        for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
+        if constexpr (OUT == 1) {
+            *oP.vec = x;               // :332
+            store_cols<n>(oP.mat, P);  // :333
+            *padP = 0.0;
+            oP.advance_nn(1);
+            padP += a.ts * RS;
+        } else if constexpr (OUT == 2) {
+            if (oP.vec) *oP.vec = x;
+            if (oP.mat) store_cols<n>(oP.mat, P);
+            oP.advance(1);
+        }
+
+        // ---- sequential scalar updates (:341-378), observations in ascending series order ----
+        double sigma = 0.0, fmant = 1.0;
+        int fexp = 0;
+        auto update = MK_LAMBDA(jc) {
+            constexpr int j = decltype(jc)::value;
+            // innovation (:344-347): every lane l < N forms v_l = y_l - Z_l x with ITS loadings;
+            // lane j's value is the one used
+            double vl = y - x;
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                Gp::template fmac<N + kk, true>(vl, x, gam[kk]); // vl -= x_{N+k} * gam_k
+            });
+            const double v = Gp::template bcast<j>(vl);
+            // d = P Z_j^T : lane r computes d_r from its own row (:349-357)
+            double dr = P[j];
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                double g;
+                if constexpr (HOIST) g = Gh[j][kk];
+                else g = Gp::template bcast<j>(gam[kk]);
+                dr = fma(P[N + kk], g, dr);
+            });
+            // innovation variance f = R_j + Z_j d (:359-362), formed at lane j from d_j, d_{N+k}
+            double fl = rvar + dr;
+            if constexpr (G == 16) dpp_pin(dr);
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                Gp::template fmac<N + kk, false>(fl, dr, gam[kk]); // fl += d_{N+k} * gam_k
+            });
+            const double f = Gp::template bcast<j>(fl);
+            const double rf = rcp_nr(f);
+            const double kr = dr * rf; // Kalman gain element r (:364-366)
+            // P -= k k^T f (:368-372): P[r][c] -= d_c * k_r, d_c broadcast from lane c
+            Gp::template axpy_col<0, n, true, n>(P, dr, kr);
+            x = fma(kr, v, x);             // :374-375
+            sigma = fma(v * v, rf, sigma); // :377
+            // detf += log f (:378): accumulate prod f as mantissa * 2^exp
+            fmant *= f;
+            if constexpr ((j & 3) == 3 || j == N - 1) {
+                fexp += __builtin_amdgcn_frexp_exp(fmant);
+                fmant = __builtin_amdgcn_frexp_mant(fmant);
+            }
+            fmin_seen = min_f64(fmin_seen, f);
+        };
+        if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
+            sfor<0, N>(update);
+        } else {
+            sfor<0, N>(MK_LAMBDA(jc) {
+                if ((vm >> decltype(jc)::value) & 1) { // uniform within the model's lane group
+                    update(jc);
+                } else if constexpr ((decltype(jc)::value & 3) == 3 || decltype(jc)::value == N - 1) {
+                    fexp += __builtin_amdgcn_frexp_exp(fmant); // keep the product normalised
+                    fmant = __builtin_amdgcn_frexp_mant(fmant);
+                }
+            });
+        }
+
+        const int cnt = __popcll((unsigned long long)vm);
+        double pad = 0.0; // OUT == 1: what this lane writes into its pad slot of the filtered record
+        if (cnt > 0) { // :380-382 compressed bookkeeping
+            if constexpr (BOOK) {
+                const double detf = fma((double)fexp, kLn2, log(fmant));
+                if constexpr (OUT == 1) {
+                    // compressed entry sc lives in the pad of filtered record sc; sc == t unless an earlier
+                    // step of this model was empty (then: one scattered 16-byte store, rare)
+                    if (sc == t) pad = pslot == 0 ? sigma : (pslot == 1 ? detf : 0.0);
+                    else if (lead && a.sigmas)
+                        *reinterpret_cast<v2d *>(a.F + (inst * a.bs + sc * a.ts) * RS + NV) = v2d{sigma, detf};
+                } else {
+                    if (a.sigmas && lead) a.sigmas[(inst * a.bs + sc * a.ts) * a.sig_stride] = sigma;
+                    if (a.detfs && lead) a.detfs[(inst * a.bs + sc * a.ts) * a.sig_stride] = detf;
+                }
+                if (sc >= a.warmup) { // get_mle: detfs[warmup:], sigmas[warmup:] are COMPRESSED indices (:563-564)
+                    sum_det += detf;
+                    sum_sig += sigma;
+                }
+            } else {
+                if (sc >= a.warmup) {
+                    sum_sig += sigma;
+                    run_mant *= fmant;
+                    run_exp += fexp + __builtin_amdgcn_frexp_exp(run_mant);
+                    run_mant = __builtin_amdgcn_frexp_mant(run_mant);
+                }
+            }
+            ++sc;
+        }
+        if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
+
+        if constexpr (OUT == 1) {
+            *oF.vec = x;               // :389
+            store_cols<n>(oF.mat, P);  // :390
+            *padF = pad;               // sigma | detf | zeros
+            oF.advance_nn(1);
+            padF += a.ts * RS;
+        } else if constexpr (OUT == 2) {
+            if (oF.vec) *oF.vec = x;
+            if (oF.mat) store_cols<n>(oF.mat, P);
+            oF.advance(1);
+        }
+    }
+
+    // zero tail of the compressed arrays (np.zeros init, :307-308); record pads were written as zeros
+    if (BOOK && OUT != 1) {
+        for (long i = sc + lane; i < T; i += G) {
+            if (a.sigmas) a.sigmas[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
+            if (a.detfs) a.detfs[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
+        }
+    }
+    if (lead) {
+        if (!BOOK) sum_det = fma((double)run_exp, kLn2, log(run_mant));
+        if (a.mle) a.mle[inst] = ((double)nobs * kLog2Pi + sum_det) + sum_sig; // :566
+        if (a.sigmacount) a.sigmacount[inst] = sc;
+        if (a.status) a.status[inst] = (fmin_seen > 0.0) ? 0u : MK_FLAG_NONPOSITIVE_F; // NaN f also flags
+    }
+}
+
+// =====================================================================================
+// RTS smoother                                               (kalmanfilter.py:403-476)
+//   Pp[t+1] = Phi Pf[t] Phi + Q and Xp[t+1] = Phi F[t] are recomputed (Phi diagonal), so only
+//   F and Pf are re-read.  J = Pf Phi^T Pp^{-1} through an LDL^T factorisation of Pp (SPD
+//   whenever q > 0, where the reference's pinv (:455) is the inverse); lane i solves for ROW i of J.
+//   The factor is DISTRIBUTED: lane c keeps L(c, 0..c-1) in place of its row of A.
+// =====================================================================================
+// ---------------------------------------------------------------- packed-record I/O through LDS (smoother)
+// The smoother both reads and writes a record per step; moving whole 16-byte chunks of the
+// wavefront's GW adjacent records (lane l <-> chunks l, l+64, ...) and transposing through a
+// wave-private LDS image measured faster there (1.65 ms) than symmetric column runs (2.1 ms).
 template <int n, int G>
 struct RecordIO {
     static constexpr int NV = n + n * n;                    // payload doubles
-    static constexpr int RS = ((NV + 2 + 15) / 16) * 16;    // record stride in doubles (128-byte multiple)
+    static constexpr int RS = record_stride_c(n);           // record stride in doubles (128-byte multiple)
     static constexpr int RC = RS / 2;                       // 16-byte chunks per record
     static constexpr int GW = 64 / G;                       // models per wavefront
     static constexpr int CW = GW * RC;                      // chunks per wavefront-step
@@ -421,293 +631,8 @@ struct RecordIO {
     }
 };
 
-constexpr double kLn2 = 0.693147180559945309417232121458;
-constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
-
-// =====================================================================================
-// Sequential-processing Kalman filter + -2 log L            (kalmanfilter.py:236-400, 550-567)
-//   OUT  : 0 = no state outputs (solver objective, mk_loglik), 1 = F, Pf, Xp, Pp all written,
-//          2 = any subset (runtime null checks)
-//   BOOK : per-step sigmas/detfs arrays are written (needs one log per step); otherwise the
-//          log-determinant is accumulated as a normalised product with ONE log at the end
-// =====================================================================================
-template <int N, int K, int G, int OUT, bool BOOK>
-__global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
-{
-    constexpr int n = N + K;
-    static_assert(n <= G, "state dimension must fit the lane group");
-    using Gp = Group<G>;
-    constexpr int GPB = 256 / G; // models per 256-thread workgroup
-    constexpr bool HOIST = (N * K <= 32); // keep Z's loading block replicated in registers
-    const int lane = threadIdx.x % G;
-    long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
-    const bool live = inst < a.B;
-    if (!live) inst = a.B - 1; // surplus groups replicate the last model (identical stores, see BlockIO)
-    const long rec = inst % a.R;
-    const bool rowok = lane < n;
-    const int r = rowok ? lane : n - 1;
-    const bool lead = lane == 0;
-    const long T = a.T;
-
-    // per-model constants: lane r holds phi_r, q_r; lane j < N holds loadings[j,:] and obsvar[j]
-    const double phi_r = a.phi[inst * n + r];
-    const double q_r = a.q[inst * n + r];
-    double pp[n], qd[n]; // row r of Phi (x) Phi and of Q = diag(q)
-    sfor<0, n>(MK_LAMBDA(c) {
-        pp[decltype(c)::value] = phi_r * Gp::template bcast<decltype(c)::value>(phi_r);
-        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
-    });
-    const int jr = lane < N ? lane : N - 1;
-    double gam[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
-    const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
-    double Gh[HOIST ? N : 1][K]; // Gh[j][k] = loadings[j,k] in every lane
-    if constexpr (HOIST) {
-        sfor<0, N>(MK_LAMBDA(j) {
-            sfor<0, K>(MK_LAMBDA(k) {
-                Gh[decltype(j)::value][decltype(k)::value] = Gp::template bcast<decltype(j)::value>(gam[decltype(k)::value]);
-            });
-        });
-    }
-
-    // initial state (run_filter defaults, kalmanfilter.py:747-750)
-    double x = a.x0 ? a.x0[inst * n + r] : 0.0;
-    double P[n];
-#pragma unroll
-    for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
-
-    // OUT == 1: packed records (RecordIO) -- two wavefront images (predicted, filtered) per wavefront;
-    // OUT == 2: dense arrays with arbitrary strides (BlockIO), one staging buffer per model
-    using BIO = BlockIO<n, G>;
-    using RIO = RecordIO<n, G>;
-    constexpr int LDS_DOUBLES = OUT == 1 ? 4 * 2 * RIO::LDS_PER_WAVE : (OUT == 2 ? BIO::LDS_DOUBLES : 2);
-    __shared__ __attribute__((aligned(16))) double lds_io[LDS_DOUBLES];
-    double *lds = lds_io + (OUT == 2 ? (threadIdx.x / G) * BIO::STRIDE : 0); // OUT == 2: this model's buffer
-    const int lane64 = threadIdx.x & 63;
-    const int gw = lane64 / G; // model index inside the wavefront
-    double *imgP = lds_io + (OUT == 1 ? (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE : 0);
-    double *imgF = imgP + (OUT == 1 ? RIO::LDS_PER_WAVE : 0);
-    typename RIO::Map rmap;
-    if constexpr (OUT == 1) {
-        rmap = RIO::make_map(lane64, (long)blockIdx.x * GPB + (threadIdx.x / 64) * RIO::GW, a.B, a.bs);
-        RIO::clear_tail(imgP, lane64);
-        RIO::clear_tail(imgF, lane64);
-        RIO::put_pad(imgP, gw, 0.0, 0.0);
-    }
-    const long rstep = a.ts * RIO::RS;  // record-array advance per time step
-    double *recP = a.Xp, *recF = a.F;   // OUT == 1: record arrays (Pp = Xp + n, Pf = F + n inside a record)
-
-    // ---- observation stream: tiles of TS = G time steps through LDS ----
-    // vmcnt retires vector-memory operations IN ORDER, so consuming a load makes the wavefront wait for
-    // every older store to be acknowledged by the memory system (~2 us while HBM writes are queued: a
-    // per-step observation load cost +0.35 ms even in a pure-store microbenchmark,
-    // scripts/ubench/store_pattern2.hip).  The observations are therefore fetched 16 steps at a time
-    // (lane l loads the N values of step t0 + l), one tile (16 steps) ahead of use, parked in LDS, and the
-    // per-step value comes from LDS (lgkmcnt, independent of the store queue).
-    constexpr int TS = 16;
-    const int lrow = lane < TS ? lane : TS - 1; // lanes >= TS (G = 64) duplicate row TS-1
-    constexpr bool OV2 = (N % 2 == 0);             // 16-byte row pieces when rows are 16-byte aligned
-    constexpr int ONC = OV2 ? N / 2 : N;
-    using ochunk_t = typename std::conditional<OV2, v2d, double>::type;
-    __shared__ __attribute__((aligned(16))) double lds_obs[(256 / G) * 2 * TS * N];
-    double *otile = lds_obs + (threadIdx.x / G) * 2 * TS * N; // this model's two tiles
-    const double *obase = a.obs + rec * a.obs_bs * N;
-    const long ostep = a.obs_ts * N;
-    ochunk_t oreg[ONC];
-    auto obs_issue = [&](long t0) __attribute__((always_inline)) { // HBM -> registers, row min(t0+lane, T-1)
-        long tr = t0 + lrow;
-        if (tr > T - 1) tr = T - 1;
-        const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + tr * ostep);
-#pragma unroll
-        for (int i = 0; i < ONC; ++i) oreg[i] = src[i];
-    };
-    auto obs_park = [&](int buf) __attribute__((always_inline)) { // registers -> LDS tile `buf`
-        ochunk_t *dst = reinterpret_cast<ochunk_t *>(otile + (buf * TS + lrow) * N);
-#pragma unroll
-        for (int i = 0; i < ONC; ++i) dst[i] = oreg[i];
-        wave_lds_sync();
-    };
-    obs_issue(0);
-    obs_park(0);
-    obs_issue(TS);
-    double ynext = otile[jr]; // y of step 0 for series jr
-    double sum_sig = 0.0, sum_det = 0.0;
-    double run_mant = 1.0; // !BOOK: prod of f over the counted steps, normalised
-    long run_exp = 0;
-    long nobs = 0, sc = 0;
-    double fmin_seen = 1.0;
-    // (b, t) lives at block index b * bs + t * ts: (bs, ts) = (T, 1) model-major [B,T,..] or (1, B) time-major [T,B,..]
-    const long vstep = a.ts * n, bstep = a.ts * n * n;
-    const long vec0 = inst * a.bs * n + r;
-    double *pXp = (OUT == 2 && a.Xp) ? a.Xp + vec0 : nullptr;
-    double *pF = (OUT == 2 && a.F) ? a.F + vec0 : nullptr;
-    double *pPp = (OUT == 2 && a.Pp) ? a.Pp + inst * a.bs * n * n : nullptr; // block of step t
-    double *pPf = (OUT == 2 && a.Pf) ? a.Pf + inst * a.bs * n * n : nullptr;
-
-    for (long t = 0; t < T; ++t) {
-        const double y = ynext;
-        {
-            const long t1 = t + 1; // read next step's observation from LDS now (latency hidden by this step)
-            if ((t1 & (TS - 1)) == 0) { // tile boundary: park the tile loaded TS steps ago, request the next one
-                obs_park((int)((t1 / TS) & 1));
-                obs_issue(t1 + TS);
-            }
-            ynext = otile[(((t1 / TS) & 1) * TS + (t1 & (TS - 1))) * N + jr];
-        }
-        // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
-        const unsigned long long ball = __ballot(lane < N && isfinite(y));
-        const auto vm = Gp::group_bits(ball);
-
-        // ---- predict (:318-331; Phi diagonal) ----
-        x = phi_r * x;
-#pragma unroll
-        for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
-        if constexpr (OUT == 1) {
-            RIO::put(imgP, gw, r, x, P); // :332-333 predicted record -> LDS image (emitted at the end of the step)
-        } else if constexpr (OUT == 2) {
-            if (pXp) {
-                *pXp = x;
-                pXp += vstep;
-            }
-            if (pPp) {
-                BIO::store(lds, pPp, P, lane, r);
-                pPp += bstep;
-            }
-        }
-
-        // ---- sequential scalar updates (:341-378), observations in ascending series order ----
-        double sigma = 0.0, fmant = 1.0;
-        int fexp = 0;
-        auto update = MK_LAMBDA(jc) {
-            constexpr int j = decltype(jc)::value;
-            // innovation (:344-347): every lane l < N forms v_l = y_l - Z_l x with ITS loadings;
-            // lane j's value is the one used
-            double vl = y - x;
-            sfor<0, K>(MK_LAMBDA(k) {
-                constexpr int kk = decltype(k)::value;
-                vl = fma(-gam[kk], Gp::template bcast<N + kk>(x), vl);
-            });
-            const double v = Gp::template bcast<j>(vl);
-            // d = P Z_j^T : lane r computes d_r from its own row (:349-357)
-            double dr = P[j];
-            sfor<0, K>(MK_LAMBDA(k) {
-                constexpr int kk = decltype(k)::value;
-                double g;
-                if constexpr (HOIST) g = Gh[j][kk];
-                else g = Gp::template bcast<j>(gam[kk]);
-                dr = fma(P[N + kk], g, dr);
-            });
-            // innovation variance f = R_j + Z_j d (:359-362), formed at lane j from d_j, d_{N+k}
-            double fl = rvar + dr;
-            sfor<0, K>(MK_LAMBDA(k) {
-                constexpr int kk = decltype(k)::value;
-                fl = fma(gam[kk], Gp::template bcast<N + kk>(dr), fl);
-            });
-            const double f = Gp::template bcast<j>(fl);
-            const double rf = rcp_nr(f);
-            const double kr = dr * rf; // Kalman gain element r (:364-366)
-            // P -= k k^T f (:368-372): P[r][c] -= d_c * k_r, d_c broadcast from lane c
-            Gp::template axpy_col<0, n, true, n>(P, dr, kr);
-            x = fma(kr, v, x);             // :374-375
-            sigma = fma(v * v, rf, sigma); // :377
-            // detf += log f (:378): accumulate prod f as mantissa * 2^exp
-            fmant *= f;
-            if constexpr ((j & 3) == 3 || j == N - 1) {
-                fexp += __builtin_amdgcn_frexp_exp(fmant);
-                fmant = __builtin_amdgcn_frexp_mant(fmant);
-            }
-            fmin_seen = min_f64(fmin_seen, f);
-        };
-        if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
-            sfor<0, N>(update);
-        } else {
-            sfor<0, N>(MK_LAMBDA(jc) {
-                if ((vm >> decltype(jc)::value) & 1) { // uniform within the model's lane group
-                    update(jc);
-                } else if constexpr ((decltype(jc)::value & 3) == 3 || decltype(jc)::value == N - 1) {
-                    fexp += __builtin_amdgcn_frexp_exp(fmant); // keep the product normalised
-                    fmant = __builtin_amdgcn_frexp_mant(fmant);
-                }
-            });
-        }
-
-        const int cnt = __popcll((unsigned long long)vm);
-        double pad0 = 0.0, pad1 = 0.0;
-        bool pad_here = false;
-        if (cnt > 0) { // :380-382 compressed bookkeeping
-            if constexpr (BOOK) {
-                const double detf = fma((double)fexp, kLn2, log(fmant));
-                if constexpr (OUT == 1) {
-                    // compressed entry sc lives in the pad of filtered record sc; sc == t unless an earlier
-                    // step of this model was empty (then: one scattered 16-byte store, rare)
-                    pad0 = sigma;
-                    pad1 = detf;
-                    pad_here = (sc == t);
-                    if (!pad_here && lead && a.sigmas)
-                        *reinterpret_cast<v2d *>(a.F + (inst * a.bs + sc * a.ts) * RIO::RS + RIO::NV) = v2d{sigma, detf};
-                } else {
-                    if (a.sigmas && lead) a.sigmas[(inst * a.bs + sc * a.ts) * a.sig_stride] = sigma;
-                    if (a.detfs && lead) a.detfs[(inst * a.bs + sc * a.ts) * a.sig_stride] = detf;
-                }
-                if (sc >= a.warmup) { // get_mle: detfs[warmup:], sigmas[warmup:] are COMPRESSED indices (:563-564)
-                    sum_det += detf;
-                    sum_sig += sigma;
-                }
-            } else {
-                if (sc >= a.warmup) {
-                    sum_sig += sigma;
-                    run_mant *= fmant;
-                    run_exp += fexp + __builtin_amdgcn_frexp_exp(run_mant);
-                    run_mant = __builtin_amdgcn_frexp_mant(run_mant);
-                }
-            }
-            ++sc;
-        }
-        if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
-
-        if constexpr (OUT == 1) {
-            RIO::put(imgF, gw, r, x, P); // :389-390 filtered record
-            RIO::put_pad(imgF, gw, pad_here ? pad0 : 0.0, pad_here ? pad1 : 0.0);
-            RIO::emit2(imgP, recP, imgF, recF, rmap); // whole-cache-line stores of both records
-            recP += rstep;
-            recF += rstep;
-        } else if constexpr (OUT == 2) {
-            if (pF) {
-                *pF = x;
-                pF += vstep;
-            }
-            if (pPf) {
-                BIO::store(lds, pPf, P, lane, r);
-                pPf += bstep;
-            }
-        }
-    }
-
-    // zero tail of the compressed arrays (np.zeros init, :307-308)
-    if (BOOK && OUT != 1) { // (OUT == 1: the pads of records >= sigmacount were written as zeros)
-        for (long i = sc + lane; i < T; i += G) {
-            if (a.sigmas) a.sigmas[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
-            if (a.detfs) a.detfs[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
-        }
-    }
-    if (lead) {
-        if (!BOOK) sum_det = fma((double)run_exp, kLn2, log(run_mant));
-        if (a.mle) a.mle[inst] = ((double)nobs * kLog2Pi + sum_det) + sum_sig; // :566
-        if (a.sigmacount) a.sigmacount[inst] = sc;
-        if (a.status) a.status[inst] = (fmin_seen > 0.0) ? 0u : MK_FLAG_NONPOSITIVE_F; // NaN f also flags
-    }
-}
-
-// =====================================================================================
-// RTS smoother                                               (kalmanfilter.py:403-476)
-//   Pp[t+1] = Phi Pf[t] Phi + Q and Xp[t+1] = Phi F[t] are recomputed (Phi diagonal), so only
-//   F and Pf are re-read.  J = Pf Phi^T Pp^{-1} through an LDL^T factorisation of Pp (SPD
-//   whenever q > 0, where the reference's pinv (:455) is the inverse); lane i solves for ROW i of J.
-//   The factor is DISTRIBUTED: lane c keeps L(c, 0..c-1) in place of its row of A.
-// =====================================================================================
-template <int n, int G, bool REC>
-__global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
+template <int n, int G>
+__global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
 {
     static_assert(n <= G, "state dimension must fit the lane group");
     using Gp = Group<G>;
@@ -729,76 +654,44 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
 
     // REC: packed records (RecordIO): one load image and one store image per wavefront;
     // !REC: dense arrays with arbitrary strides (BlockIO), one staging buffer per model
-    using BIO = BlockIO<n, G>;
+    constexpr bool REC = true;
     using RIO = RecordIO<n, G>;
-    constexpr int LDS_DOUBLES = REC ? 4 * 2 * RIO::LDS_PER_WAVE : BIO::LDS_DOUBLES;
+    constexpr int LDS_DOUBLES = 4 * 2 * RIO::LDS_PER_WAVE;
     __shared__ __attribute__((aligned(16))) double lds_io[LDS_DOUBLES];
-    double *lds = lds_io + (REC ? 0 : (threadIdx.x / G) * BIO::STRIDE);
     const int lane64 = threadIdx.x & 63;
     const int gw = lane64 / G;
-    double *imgL = lds_io + (REC ? (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE : 0);
-    double *imgS = imgL + (REC ? RIO::LDS_PER_WAVE : 0);
+    double *imgL = lds_io + (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE;
+    double *imgS = imgL + RIO::LDS_PER_WAVE;
     typename RIO::Map rmap;
     if constexpr (REC) {
         rmap = RIO::make_map(lane64, (long)blockIdx.x * GPB + (threadIdx.x / 64) * RIO::GW, a.B, a.bs);
         RIO::clear_tail(imgS, lane64);
         RIO::put_pad(imgS, gw, 0.0, 0.0);
     }
-    constexpr int PERB = REC ? 1 : BIO::PER, PERR = REC ? RIO::PER : 1;
-    typename BIO::chunk_t preb[PERB]; // !REC: chunks of the next covariance block
-    typename RIO::chunk_t prer[PERR]; //  REC: chunks of the next filtered record
+    typename RIO::chunk_t prer[RIO::PER]; // chunks of the next filtered record
 
     // addressing: (b, t) at block index b*bs + t*ts
-    const long rstep = a.ts * RIO::RS, vstep = a.ts * n, bstep = a.ts * n * n;
-    const double *recF = REC ? a.F + (T - 1) * rstep : nullptr; // record array positioned at step t
-    double *recS = REC ? a.S + (T - 1) * rstep : nullptr;
-    const long blkT = inst * a.bs + (T - 1) * a.ts;
-    const double *pF = REC ? nullptr : a.F + blkT * n + r;
-    const double *pPf = REC ? nullptr : a.Pf + blkT * n * n;
-    double *pS = (!REC && a.S) ? a.S + blkT * n + r : nullptr;
-    double *pPs = (!REC && a.Ps) ? a.Ps + blkT * n * n : nullptr;
+    const long rstep = a.ts * RIO::RS;
+    const double *recF = a.F + (T - 1) * rstep; // record array positioned at step t
+    double *recS = a.S + (T - 1) * rstep;
 
     // fetch helpers: issue the HBM loads of one step / turn them into (x_r, row r)
     auto issue = [&](double &xnext) __attribute__((always_inline)) {
-        if constexpr (REC) {
-            recF -= rstep;
-            RIO::load_issue(recF, rmap, prer);
-        } else {
-            pF -= vstep;
-            pPf -= bstep;
-            BIO::load_issue(pPf, preb, lane);
-            xnext = *pF;
-        }
+        recF -= rstep;
+        RIO::load_issue(recF, rmap, prer);
     };
     auto finish = [&](double &xv, double(&row)[n]) __attribute__((always_inline)) {
-        if constexpr (REC) RIO::load_finish(imgL, prer, rmap, gw, r, xv, row);
-        else BIO::load_finish(lds, preb, row, lane, r);
+        RIO::load_finish(imgL, prer, rmap, gw, r, xv, row);
     };
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
-        if constexpr (REC) {
-            RIO::put(imgS, gw, r, xv, row);
-            RIO::emit(imgS, recS, rmap);
-            recS -= rstep;
-        } else {
-            if (pS) {
-                *pS = xv;
-                pS -= vstep;
-            }
-            if (pPs) {
-                BIO::store(lds, pPs, row, lane, r);
-                pPs -= bstep;
-            }
-        }
+        RIO::put(imgS, gw, r, xv, row);
+        RIO::emit(imgS, recS, rmap);
+        recS -= rstep;
     };
 
     // last step: smoothed = filtered (:450-451)
     double xs, Psn[n];
-    if constexpr (REC) {
-        RIO::load_issue(recF, rmap, prer);
-    } else {
-        BIO::load_issue(pPf, preb, lane);
-        xs = *pF;
-    }
+    RIO::load_issue(recF, rmap, prer);
     finish(xs, Psn);
     store(xs, Psn);
     double pivmin = 1.0;
@@ -895,6 +788,143 @@ __global__ void __launch_bounds__(256) smoother_kernel(SmootherArgs a)
     if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
 }
 
+
+// dense arrays (any strides, optional outputs): symmetric column runs, no LDS
+template <int n, int G>
+__global__ void __launch_bounds__(256) smoother_dense_kernel(SmootherArgs a)
+{
+    static_assert(n <= G, "state dimension must fit the lane group");
+    using Gp = Group<G>;
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1; // surplus groups replicate the last model (identical stores)
+    const int r = lane < n ? lane : n - 1; // lanes >= n replicate lane n-1
+    const long T = a.T;
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+    double phic[n], qd[n]; // diag(Phi) replicated; row r of Q = diag(q)
+    sfor<0, n>(MK_LAMBDA(c) {
+        phic[decltype(c)::value] = Gp::template bcast<decltype(c)::value>(phi_r);
+        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
+    });
+
+    // (b, t) at block index b*bs + t*ts; start at the last step
+    const long blkT = inst * a.bs + (T - 1) * a.ts;
+    MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
+    MomentPtr oS = moment_ptr<n>(a.S, a.Ps, blkT, a.ts, a.rs, r);
+    // smoothed records: the pad doubles are written as zeros so that every cache line is written whole
+    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
+    double *padS = (a.rs > 0 && a.S) ? a.S + blkT * RS + NV + (lane < PADN ? lane : PADN - 1) : nullptr;
+    auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
+        if (oS.vec) *oS.vec = xv;
+        if (oS.mat) store_cols<n>(oS.mat, row);
+        oS.advance(-1);
+        if (padS) {
+            *padS = 0.0;
+            padS -= a.ts * RS;
+        }
+    };
+
+    // last step: smoothed = filtered (:450-451)
+    double xs = *iF.vec, Psn[n];
+    load_cols<n>(iF.mat, Psn);
+    store(xs, Psn);
+    double pivmin = 1.0;
+
+    // Software pipeline: the rows of Pf[t] / F[t] are loaded one iteration ahead (column runs, no LDS).
+    double Pfc[n], Pfn[n], xfc = 0.0, xfn = 0.0;
+    if (T >= 2) {
+        iF.advance_nn(-1);
+        xfc = *iF.vec;
+        load_cols<n>(iF.mat, Pfc);
+    }
+
+    for (long t = T - 2; t >= 0; --t) {
+        // W = Pf Phi (column scaling); A = Pp[t+1] = Phi Pf Phi + Q (row r); D = Ps[t+1] - Pp[t+1]
+        double A[n], z[n], D[n];
+#pragma unroll
+        for (int c = 0; c < n; ++c) {
+            z[c] = Pfc[c] * phic[c]; // W, the right-hand side of the solve
+            A[c] = fma(phi_r, z[c], qd[c]);
+            D[c] = Psn[c] - A[c];
+        }
+        double delta = xs - phi_r * xfc; // xs[t+1] - Xp[t+1]; formed early so that it is "old" when DPP-read
+        if constexpr (G == 16) dpp_pin(delta);
+
+        // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
+        if constexpr (G == 16) dpp_guard(A); // A is compiler-produced (build-time hazard check)
+        double dinv[n];
+        sfor<0, n>(MK_LAMBDA(jc) {
+            constexpr int j = decltype(jc)::value;
+            const double piv = Gp::template bcast<j>(A[j]); // d_j
+            pivmin = min_f64(pivmin, piv);
+            const double ij = rcp_nr(piv);
+            dinv[j] = ij;
+            const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
+            // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
+            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+            A[j] = lr;
+        });
+
+        // ---- lane i solves A z = W_i  (row i of J = Pf Phi^T A^{-1}, :458-460) ----
+        sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
+        });
+#pragma unroll
+        for (int c = 0; c < n; ++c) z[c] *= dinv[c]; // D^{-1}
+        sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y;  z[c] -= L(k,c) z_k, L(k,c) lives in lane k
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
+        });
+        // z = J[r, :]
+
+        // ---- smoothed mean (:461-464): xs[t] = F[t] + J (xs[t+1] - Phi F[t]) ----
+        double acc0 = xfc, acc1 = 0.0;
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
+            else Gp::template fmac<c>(acc1, delta, z[c]);
+        });
+        xs = acc0 + acc1;
+
+        // ---- smoothed covariance (:465-474): Ps[t] = Pf[t] + J (Ps[t+1] - Pp[t+1]) J^T ----
+        double V[n]; // V = J D (row r):  V[c] += J[r][k] * D[k][c], D[k][:] broadcast from lane k
+#pragma unroll
+        for (int c = 0; c < n; ++c) V[c] = 0.0;
+        if constexpr (G == 16) dpp_guard(D); // D is compiler-produced (build-time hazard check)
+        sfor<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
+        });
+        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
+#pragma unroll
+        for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
+        // mid-iteration prefetch of step t-1 (consumed at the next iteration).  vmcnt retires in order: the
+        // loads must not sit right behind this iteration's stores, or consuming them means waiting for
+        // those stores' acknowledgements (~2 us under HBM write load)
+        if (t >= 1) {
+            iF.advance_nn(-1);
+            xfn = *iF.vec;
+            load_cols<n>(iF.mat, Pfn);
+        }
+        sfor<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
+        });
+
+        store(xs, Psn);
+#pragma unroll
+        for (int c = 0; c < n; ++c) Pfc[c] = Pfn[c];
+        xfc = xfn;
+    }
+    if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
+}
+
+// =====================================================================================
 // =====================================================================================
 // Small helper kernels
 // =====================================================================================
@@ -1009,9 +1039,9 @@ static hipError_t launch_smoother_n(const SmootherArgs &a, hipStream_t s)
     constexpr int GPB = 256 / G;
     const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
     if (a.rs > 0)
-        hipLaunchKernelGGL((smoother_kernel<n, G, true>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((smoother_record_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((smoother_kernel<n, G, false>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((smoother_dense_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1035,7 +1065,7 @@ hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s)
 
 static const int kShapes[][2] = {MK_SHAPES(MK_CASE_LIST)};
 
-int record_stride(int n) { return ((n + n * n + 2 + 15) / 16) * 16; } // == RecordIO<n, G>::RS
+int record_stride(int n) { return record_stride_c(n); }
 
 int num_shapes() { return (int)(sizeof(kShapes) / sizeof(kShapes[0])); }
 void get_shape(int i, int *N, int *K)
