@@ -34,6 +34,28 @@ def algorithmic_bytes(N, K, T):
     return filt, smooth
 
 
+def pmc_traffic(kernel_key, B, N, K, T, layout):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/<round>/pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE is doubled
+    as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; units KiB).  None when no
+    profile of the same workload is committed."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("batch"), w.get("series"), w.get("factors"), w.get("T"), w.get("layout")) != (B, N, K, T, layout):
+            continue
+        for name, c in d.get("kernels", {}).items():
+            if kernel_key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                best = {"GB": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / 1e9, "source": os.path.relpath(f, ROOT)}
+    return best
+
+
 def cpu_baseline(d_host, gpu_mle, target_seconds=15.0):
     """Reference algorithm (oracle/kalman_oracle.c = C port of the numba/numpy path) on the host
     cores of this box, on a bounded sample of the same workload."""
@@ -165,14 +187,21 @@ def main():
         kernels = {"filter_kernel": {"ms": f_avg, "algorithmic_GB": fb * B / 1e9,
                                      "GBps": fb * B / 1e9 / (f_avg / 1e3)}}
         if not args.loglik_only:
-            kernels["smoother_kernel"] = {"ms": s_avg, "algorithmic_GB": sb * B / 1e9,
+            kernels["smoother_record_kernel"] = {"ms": s_avg, "algorithmic_GB": sb * B / 1e9,
                                           "GBps": sb * B / 1e9 / (s_avg / 1e3)}
+        for kname in kernels:
+            tr = pmc_traffic(kname, B, N, K, T, args.layout)
+            kernels[kname]["traffic_GB"] = tr["GB"] if tr else None
+            if tr:
+                kernels[kname]["traffic_source"] = tr["source"]
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         if args.loglik_only:
             kernels["filter_kernel"]["algorithmic_GB"] = 8 * T * N * B / 1e9
             kernels["filter_kernel"]["GBps"] = 8 * T * N * B / 1e9 / (f_avg / 1e3)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
+                    "traffic": (kernels[dom]["traffic_GB"] * 1e9 if kernels[dom].get("traffic_GB") else None),
+                    "algorithmic_bytes": kernels[dom]["algorithmic_GB"] * 1e9,
                     "avg_launch_ms": kernels[dom]["ms"], "kernels": kernels,
                     "path_achieved_GBps": (fb + sb) * B / 1e9 / ((f_avg + s_avg) / 1e3) if not args.loglik_only else None}
         res = {

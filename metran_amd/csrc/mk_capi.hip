@@ -6,7 +6,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <cstdlib>
 #include <new>
 
 #include "mk_internal.h"
@@ -245,7 +244,6 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.warmup = p->warmup;
     a.bs = o->time_major ? 1 : p->T;
     a.ts = o->time_major ? p->n_instances : 1;
-    if (getenv("MK_DEBUG_TS0")) a.ts = 0; // dev experiment: every step overwrites the same block (L2-resident)
     a.obs_bs = p->obs_time_major ? 1 : p->T;
     a.obs_ts = p->obs_time_major ? p->n_records : 1;
     a.obs = p->d_obs;
