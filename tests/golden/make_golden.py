@@ -175,6 +175,28 @@ def g1_real():
     print("g1_real", mle_star, mle_star_np, mle_10, data["masked_mle_star"])
 
 
+def g1_solve():
+    """Full Metran.solve() on examples/data (stored obj 2332.33, nfev 77, AIC 2344.33,
+    examples/metran_practical_example.ipynb:142-155): the reference's ScipySolve (L-BFGS-B, 2-point finite
+    differences, metran/solver.py:222-288) with the numpy engine."""
+    d = os.path.join(_refshim.REFERENCE_ROOT, "examples", "data")
+    series = []
+    for i in range(1, 6):
+        s = pd.read_csv(f"{d}/B21B021400{i}_res.csv", index_col=0, parse_dates=True).squeeze()
+        s.name = f"B21B021400{i}"
+        series.append(s)
+    mt = metran.Metran(series, name="B21B0214")
+    mt.solve(report=False, engine="numpy")
+    np.savez_compressed(
+        os.path.join(HERE, "g1_solve.npz"),
+        optimal=mt.parameters["optimal"].values.astype(float),
+        stderr=mt.parameters["stderr"].values.astype(float),
+        obj=np.float64(mt.fit.obj_func), nfev=np.int64(mt.fit.nfev), aic=np.float64(mt.fit.aic),
+        pcov=mt.fit.pcov.values.astype(float), names=np.array(list(mt.parameters.index)),
+        initial=mt.parameters["initial"].values.astype(float), pmin=mt.parameters["pmin"].values.astype(float))
+    print("g1_solve", mt.fit.obj_func, mt.fit.nfev)
+
+
 def g2_seeded():
     """examples/dynamic_factor_model.ipynb cell 7: seeded 2-series synthetic."""
     np.random.seed(20210505)
@@ -237,6 +259,7 @@ def edge_nan(i, y):
 
 if __name__ == "__main__":
     g1_real()
+    g1_solve()
     g2_seeded()
     # C2 shape (8 series / 2 factors), small T: every array, every step
     synthetic_case("c2_small.npz", 8, 2, 48, seed=2000, models=[0, 1, 2])
