@@ -120,6 +120,11 @@ MK_API int mk_set_stream(mk_context *ctx, void *hip_stream);
 MK_API int mk_sync(mk_context *ctx);
 /* 1 if a kernel for (N,K) is compiled into the library. */
 MK_API int mk_shape_supported(int64_t N, int64_t K);
+/* Register a run-time shape module: a shared object built from metran_amd/csrc/mk_kernels.hip with
+ * -DMK_SHAPE_MODULE '-DMK_SHAPES(X)=X(N,K)' (hipcc --offload-arch=gfx950).  The kernels are fully
+ * unrolled over the state dimension, so a model shape outside the ahead-of-time list gets its own
+ * specialised kernels this way (metran_amd/jit.py compiles, hazard-checks and caches them). */
+MK_API int mk_register_shape_module(const char *path);
 /* Doubles per packed record (see mk_outputs.record_stride) for state dimension n = N + K. */
 MK_API int64_t mk_record_stride(int64_t n);
 /* Writes up to `cap` supported (N,K) pairs into shapes[2*i], shapes[2*i+1]; returns the count. */

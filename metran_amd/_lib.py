@@ -75,6 +75,7 @@ API = {
     "mk_set_stream": (c_int, [c_void_p, c_void_p]),
     "mk_sync": (c_int, [c_void_p]),
     "mk_shape_supported": (c_int, [c_int64, c_int64]),
+    "mk_register_shape_module": (c_int, [c_char_p]),
     "mk_record_stride": (c_int64, [c_int64]),
     "mk_supported_shapes": (c_int, [c_i64p, c_int]),
     "mk_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),

@@ -6,6 +6,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <vector>
 #include <new>
 
 #include "mk_internal.h"
@@ -39,7 +42,89 @@ static int fail(int code, const char *fmt, ...)
     if (!(ctx)) return fail(MK_ERR_INVALID, "null mk_context"); \
     MK_HIP(hipSetDevice((ctx)->device))
 
+// ---- run-time shape modules (see the MK_SHAPE_MODULE block of mk_kernels.hip and metran_amd/jit.py) ----
+namespace {
+struct ShapeModule {
+    int N, K;
+    void *handle;
+    int (*launch_filter)(const mk::FilterArgs *, void *);
+    int (*launch_smoother)(const mk::SmootherArgs *, void *);
+};
+std::vector<ShapeModule> g_modules;
+std::mutex g_modules_mutex;
+
+const ShapeModule *find_module(int64_t N, int64_t K, bool by_n_only = false)
+{
+    std::lock_guard<std::mutex> lock(g_modules_mutex);
+    for (const auto &m : g_modules)
+        if ((m.N == N && m.K == K) || (by_n_only && m.N + m.K == N + K)) return &m;
+    return nullptr;
+}
+bool aot_shape(int64_t N, int64_t K)
+{
+    for (int i = 0; i < mk::num_shapes(); ++i) {
+        int n_, k_;
+        mk::get_shape(i, &n_, &k_);
+        if (n_ == N && k_ == K) return true;
+    }
+    return false;
+}
+bool aot_state_dim(int64_t n)
+{
+    for (int i = 0; i < mk::num_shapes(); ++i) {
+        int n_, k_;
+        mk::get_shape(i, &n_, &k_);
+        if (n_ + k_ == n) return true;
+    }
+    return false;
+}
+hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s)
+{
+    if (aot_shape(N, K)) return mk::launch_filter(N, K, a, s);
+    if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_filter(&a, (void *)s);
+    return hipErrorInvalidValue;
+}
+hipError_t dispatch_smoother(int N, int K, const mk::SmootherArgs &a, hipStream_t s)
+{
+    if (aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
+    if (const ShapeModule *m = find_module(N, K, true)) return (hipError_t)m->launch_smoother(&a, (void *)s);
+    return hipErrorInvalidValue;
+}
+} // namespace
+
 extern "C" {
+
+MK_API int mk_register_shape_module(const char *path)
+{
+    if (!path) return fail(MK_ERR_INVALID, "null module path");
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(MK_ERR_INVALID, "dlopen(%s): %s", path, dlerror());
+    auto abi = (int (*)(void))dlsym(h, "mkmod_abi");
+    auto shape = (int (*)(int *, int *))dlsym(h, "mkmod_shape");
+    auto lf = (int (*)(const mk::FilterArgs *, void *))dlsym(h, "mkmod_launch_filter");
+    auto ls = (int (*)(const mk::SmootherArgs *, void *))dlsym(h, "mkmod_launch_smoother");
+    if (!abi || !shape || !lf || !ls) {
+        dlclose(h);
+        return fail(MK_ERR_INVALID, "%s is not a metran_hip shape module", path);
+    }
+    if (abi() != (int)(sizeof(mk::FilterArgs) * 1000 + sizeof(mk::SmootherArgs))) {
+        dlclose(h);
+        return fail(MK_ERR_INVALID, "%s was built against different kernel-argument structs (stale cache)", path);
+    }
+    int N = 0, K = 0;
+    if (shape(&N, &K) != 1) {
+        dlclose(h);
+        return fail(MK_ERR_INVALID, "%s must contain exactly one (N,K) shape", path);
+    }
+    std::lock_guard<std::mutex> lock(g_modules_mutex);
+    for (const auto &m : g_modules)
+        if (m.N == N && m.K == K) {
+            dlclose(h);
+            return MK_OK; // already registered
+        }
+    g_modules.push_back(ShapeModule{N, K, h, lf, ls});
+    return MK_OK;
+}
 
 MK_API int mk_abi_version(void) { return MK_ABI_VERSION; }
 MK_API const char *mk_last_error(void) { return g_err; }
@@ -112,24 +197,27 @@ MK_API int mk_sync(mk_context *ctx)
 
 MK_API int mk_shape_supported(int64_t N, int64_t K)
 {
-    for (int i = 0; i < mk::num_shapes(); ++i) {
-        int n_, k_;
-        mk::get_shape(i, &n_, &k_);
-        if (n_ == N && k_ == K) return 1;
-    }
-    return 0;
+    return (aot_shape(N, K) || find_module(N, K)) ? 1 : 0;
 }
 
 MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
 
 MK_API int mk_supported_shapes(int64_t *shapes, int cap)
 {
-    const int cnt = mk::num_shapes();
+    int cnt = mk::num_shapes();
     for (int i = 0; i < cnt && i < cap && shapes; ++i) {
         int n_, k_;
         mk::get_shape(i, &n_, &k_);
         shapes[2 * i] = n_;
         shapes[2 * i + 1] = k_;
+    }
+    std::lock_guard<std::mutex> lock(g_modules_mutex);
+    for (const auto &m : g_modules) {
+        if (cnt < cap && shapes) {
+            shapes[2 * cnt] = m.N;
+            shapes[2 * cnt + 1] = m.K;
+        }
+        ++cnt;
     }
     return cnt;
 }
@@ -204,8 +292,8 @@ static int check_problem(const mk_problem *p)
     if (p->warmup < 0) return fail(MK_ERR_INVALID, "warmup must be >= 0");
     if (!mk_shape_supported(p->N, p->K))
         return fail(MK_ERR_SHAPE,
-                    "no kernel compiled for (N=%lld series, K=%lld factors); add X(%lld, %lld) to MK_SHAPES in "
-                    "metran_amd/csrc/mk_internal.h and rebuild",
+                    "no kernel for (N=%lld series, K=%lld factors): build a shape module (metran_amd.jit.ensure_shape, "
+                    "mk_register_shape_module) or add X(%lld, %lld) to MK_SHAPES in metran_amd/csrc/mk_internal.h",
                     (long long)p->N, (long long)p->K, (long long)p->N, (long long)p->K);
     if (!p->d_phi || !p->d_q) return fail(MK_ERR_INVALID, "d_phi and d_q are required");
     return MK_OK;
@@ -263,7 +351,7 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.Pp = o->d_Pp;
     a.status = o->d_status;
     if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    MK_HIP(mk::launch_filter((int)p->N, (int)p->K, a, ctx->stream));
+    MK_HIP(dispatch_filter((int)p->N, (int)p->K, a, ctx->stream));
     if (ctx->timing) {
         MK_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->have_filter_time = true;
@@ -297,7 +385,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.Ps = o->d_Ps;
     a.status = o->d_status;
     if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    MK_HIP(mk::launch_smoother((int)p->N, (int)p->K, a, ctx->stream));
+    MK_HIP(dispatch_smoother((int)p->N, (int)p->K, a, ctx->stream));
     if (ctx->timing) {
         MK_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         ctx->have_smooth_time = true;

@@ -1063,6 +1063,38 @@ hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+int num_shapes();
+void get_shape(int i, int *N, int *K);
+
+#ifdef MK_SHAPE_MODULE
+// ---------------------------------------------------------------------------------------------
+// Shape module: this same translation unit compiled at run time for ONE (N, K) that is not in the
+// ahead-of-time list (metran_amd/jit.py drives hipcc, runs the DPP hazard check on the assembly and
+// registers the module with mk_register_shape_module).  The kernels are fully unrolled over n, so
+// specialising per shape is what makes them fast; this is how an arbitrary Metran model gets one.
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+MK_API int mkmod_abi(void) { return (int)(sizeof(FilterArgs) * 1000 + sizeof(SmootherArgs)); }
+MK_API int mkmod_shape(int *N, int *K)
+{
+    get_shape(0, N, K);
+    return num_shapes();
+}
+MK_API int mkmod_launch_filter(const FilterArgs *a, void *stream)
+{
+    int N, K;
+    get_shape(0, &N, &K);
+    return (int)launch_filter(N, K, *a, (hipStream_t)stream);
+}
+MK_API int mkmod_launch_smoother(const SmootherArgs *a, void *stream)
+{
+    int N, K;
+    get_shape(0, &N, &K);
+    return (int)launch_smoother(N, K, *a, (hipStream_t)stream);
+}
+}
+#endif
+
 static const int kShapes[][2] = {MK_SHAPES(MK_CASE_LIST)};
 
 int record_stride(int n) { return record_stride_c(n); }

@@ -150,12 +150,9 @@ class BatchedKalman:
             raise ValueError("loadings must be [R=%d,N=%d,K], got %s" % (self.R, self.N, tuple(self.loadings.shape)))
         self.K = int(self.loadings.shape[2])
         if not self._L.mk_shape_supported(self.N, self.K):
-            shapes = (ctypes.c_int64 * 128)()
-            cnt = self._L.mk_supported_shapes(shapes, 64)
-            have = [(shapes[2 * i], shapes[2 * i + 1]) for i in range(min(cnt, 64))]
-            raise MetranHipError(
-                "no HIP kernel compiled for (N=%d series, K=%d factors); compiled shapes: %s. Add X(%d, %d) to "
-                "MK_SHAPES in metran_amd/csrc/mk_internal.h and rebuild." % (self.N, self.K, have, self.N, self.K))
+            from . import jit
+
+            jit.ensure_shape(self.N, self.K)  # builds + registers a specialised kernel module (cached)
         if obsvar is not None:
             if not isinstance(obsvar, torch.Tensor):
                 obsvar = np.asarray(obsvar, dtype=np.float64)

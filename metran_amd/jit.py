@@ -1,0 +1,97 @@
+"""Run-time shape specialisation: kernels for an (N series, K factors) pair that is not in the
+ahead-of-time list are compiled on demand from the SAME source (``csrc/mk_kernels.hip``) by hipcc,
+statically checked for DPP hazards (``scripts/check_dpp_hazards.py``; the fused ``v_fmac_f64_dpp`` is
+inline asm that hipcc does not pad) and registered with the library (``mk_register_shape_module``).
+Built modules are cached by a hash of the sources under ``$METRAN_HIP_CACHE`` (default
+``~/.cache/metran_amd``).  Set ``METRAN_HIP_JIT=0`` to forbid compilation (unsupported shapes raise).
+"""
+import hashlib
+import logging
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+from . import _lib
+from ._lib import MetranHipError
+
+logger = logging.getLogger(__name__)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SOURCES = [os.path.join(_HERE, "csrc", "mk_kernels.hip"), os.path.join(_HERE, "csrc", "mk_internal.h"),
+            os.path.join(_ROOT, "include", "metran_hip.h")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise MetranHipError("hipcc not found: cannot build a kernel module for this model shape")
+
+
+def cache_dir():
+    d = os.environ.get("METRAN_HIP_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "metran_amd")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _source_hash():
+    h = hashlib.sha256()
+    for f in _SOURCES:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def module_path(N, K):
+    return os.path.join(cache_dir(), "mk_shape_%d_%d_%s.so" % (N, K, _source_hash()))
+
+
+def build_shape_module(N, K):
+    """Compile, hazard-check and cache the shape module for (N, K); returns its path."""
+    out = module_path(N, K)
+    if os.path.exists(out):
+        return out
+    if os.environ.get("METRAN_HIP_JIT", "1") == "0":
+        raise MetranHipError("no kernel for (N=%d, K=%d) and METRAN_HIP_JIT=0 forbids building one" % (N, K))
+    n = N + K
+    if N < 1 or K < 1 or n > 64:
+        raise MetranHipError("unsupported model shape N=%d, K=%d (need N, K >= 1 and N + K <= 64)" % (N, K))
+    logger.info("building HIP kernels for a %d-series / %d-factor model (one-off, cached)", N, K)
+    tmp = tempfile.mkdtemp(prefix="mkjit_")
+    try:
+        obj = os.path.join(tmp, "mod.o")
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+               "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-DMK_SHAPE_MODULE",
+               "-DMK_SHAPES(X)=X(%d,%d)" % (N, K), "-save-temps=obj", "-Wno-unused-command-line-argument", "-c",
+               _SOURCES[0], "-o", obj]
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise MetranHipError("hipcc failed for shape (%d,%d):\n%s" % (N, K, r.stderr[-2000:]))
+        asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
+        checker = os.path.join(_ROOT, "scripts", "check_dpp_hazards.py")
+        if asm and os.path.exists(checker):
+            c = subprocess.run([sys.executable, checker, os.path.join(tmp, asm[0])], capture_output=True, text=True)
+            if c.returncode != 0:
+                raise MetranHipError("DPP hazard check failed for shape (%d,%d):\n%s" % (N, K, c.stdout[-2000:]))
+        so = os.path.join(tmp, "mod.so")
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise MetranHipError("link failed for shape (%d,%d):\n%s" % (N, K, r.stderr[-2000:]))
+        os.replace(so, out) if os.path.dirname(out) == tmp else shutil.move(so, out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def ensure_shape(N, K):
+    """Make kernels for (N, K) available in the loaded library (no-op for ahead-of-time shapes)."""
+    L = _lib.lib()
+    if L.mk_shape_supported(N, K):
+        return False
+    path = build_shape_module(int(N), int(K))
+    _lib.check(L.mk_register_shape_module(path.encode()))
+    if not L.mk_shape_supported(N, K):
+        raise MetranHipError("shape module %s did not register (N=%d, K=%d)" % (path, N, K))
+    return True

@@ -96,3 +96,20 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
                 assert "kalman_oracle" not in txt, f
+
+
+def test_shape_module_builds_and_passes_hazard_check(tmp_path, monkeypatch):
+    """Run-time specialisation for a shape outside the ahead-of-time list: hipcc cross-compiles the
+    module here (no GPU needed), the DPP hazard check runs on its assembly, and it exports the module ABI."""
+    monkeypatch.setenv("METRAN_HIP_CACHE", str(tmp_path))
+    from metran_amd import jit
+
+    path = jit.build_shape_module(7, 3)
+    assert os.path.exists(path) and path == jit.module_path(7, 3)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    for sym in ("mkmod_abi", "mkmod_shape", "mkmod_launch_filter", "mkmod_launch_smoother"):
+        assert sym in out
+    assert "filter_kernelILi7ELi3ELi16" in out and "smoother_record_kernelILi10ELi16" in out
+    monkeypatch.setenv("METRAN_HIP_JIT", "0")
+    with pytest.raises(jit.MetranHipError):
+        jit.build_shape_module(6, 3)

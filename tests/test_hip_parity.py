@@ -203,3 +203,22 @@ def test_full_size_properties(kf):
     assert float((r["Ps"] - r["Ps"].transpose(-1, -2)).abs().max()) < 1e-12
     zx = r["F"][..., :N] + torch.einsum("bnk,btk->btn", d["loadings"], r["F"][..., N:])
     assert float((zx - d["obs"]).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize("N,K", [(7, 2), (11, 3), (20, 2)])
+def test_runtime_specialised_shapes(kf, N, K, tmp_path_factory, monkeypatch):
+    """Shapes outside the ahead-of-time list get kernels built at run time (metran_amd/jit.py:
+    hipcc + DPP hazard check + mk_register_shape_module); same parity bar."""
+    import os
+
+    monkeypatch.setenv("METRAN_HIP_CACHE", os.environ.get("METRAN_HIP_CACHE", str(tmp_path_factory.getbasetemp() / "mkjit")))
+    B, T = 9, 60
+    d = make_dfm_batch(B, N, K, T, seed=300 + N, missing=0.2, first_step="random")
+    ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    assert (N, K) in kf.supported_shapes()
+    r = kf.filter_smooth(d["phi"], d["q"])
+    assert rel_err(_np(r["mle"]), ref["mle"]) < MLE_RTOL
+    for k, tol in (("F", FILT_ATOL), ("Pf", FILT_ATOL), ("Xp", FILT_ATOL), ("Pp", FILT_ATOL), ("S", SMOOTH_ATOL),
+                   ("Ps", SMOOTH_ATOL), ("sigmas", 1e-10), ("detfs", 1e-10)):
+        np.testing.assert_allclose(_np(r[k]), ref[k], rtol=0, atol=tol, err_msg=k)
