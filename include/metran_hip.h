@@ -75,6 +75,10 @@ typedef struct mk_problem {
     const double *d_x0;        /* [B,n] or NULL = zeros       (kalmanfilter.py:747-748) */
     const double *d_P0;        /* [B,n,n] or NULL = identity  (kalmanfilter.py:749-750) */
     int64_t obs_time_major;    /* 0: d_obs is [R,T,N] (reference layout); 1: d_obs is [T,R,N] */
+    const double *d_scale;     /* [R,N] or NULL = ones: series standard deviations (Metran.oseries_std); with
+                                  d_offset the scaled observation matrix of get_scaled_observation_matrix
+                                  (metran.py:944-961) for the fused projection outputs d_sim_means/d_sim_vars */
+    const double *d_offset;    /* [R,N] or NULL = zeros: series means (metran.py:788-793)              */
 } mk_problem;
 
 /* Outputs; any pointer may be NULL (that output is skipped and costs no HBM traffic).
@@ -96,6 +100,13 @@ typedef struct mk_outputs {
                               axis); 1: they are [T,B,...] -- all models' step-t blocks contiguous, the
                               HBM-friendly layout (a [B,T,...] strided view of it costs nothing).
                               Applies to d_sigmas, d_detfs, d_F, d_Pf, d_Xp, d_Pp, d_S, d_Ps.        */
+    double *d_sim_means;   /* [B,T,N] fused projection epilogue of the smoother (mk_smooth /          */
+    double *d_sim_vars;    /* [B,T,N] mk_filter_smooth, record layout): SPKalmanFilter.simulate
+                              (kalmanfilter.py:569-603) of the SMOOTHED moments with Z~ = diag(scale)
+                              [I | loadings] (+ offset on the means) -- what Metran.get_simulation consumes
+                              (metran.py:831-883).  With these set, d_S / d_Ps (and d_Xp / d_Pp) may be
+                              NULL: the smoothed states are then never written (7x less output at n = 10,
+                              40x at n = 36).  time_major applies.  NULL = not computed.              */
     int64_t record_stride; /* 0: every array above is dense.  RS = mk_record_stride(n): PACKED RECORDS, the
                               fast path.  Each moment set is ONE array of RS doubles per (model, step):
                                 [ mean(n) | covariance(n*n) | sigma, detf (filtered set only) | zero pad ]

@@ -42,6 +42,8 @@ class Problem(Structure):
         ("d_x0", c_void_p),
         ("d_P0", c_void_p),
         ("obs_time_major", c_int64),
+        ("d_scale", c_void_p),
+        ("d_offset", c_void_p),
     ]
 
 
@@ -61,6 +63,8 @@ class Outputs(Structure):
         ("d_Ps", c_void_p),
         ("d_status", c_void_p),
         ("time_major", c_int64),
+        ("d_sim_means", c_void_p),
+        ("d_sim_vars", c_void_p),
         ("record_stride", c_int64),
     ]
 

@@ -86,8 +86,10 @@ hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s)
 }
 hipError_t dispatch_smoother(int N, int K, const mk::SmootherArgs &a, hipStream_t s)
 {
-    if (aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
-    if (const ShapeModule *m = find_module(N, K, true)) return (hipError_t)m->launch_smoother(&a, (void *)s);
+    // the plain smoother depends on n = N + K only; the projecting one needs the exact (N, K)
+    const bool proj = a.sim_means || a.sim_vars;
+    if (proj ? aot_shape(N, K) : aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
+    if (const ShapeModule *m = find_module(N, K, !proj)) return (hipError_t)m->launch_smoother(&a, (void *)s);
     return hipErrorInvalidValue;
 }
 } // namespace
@@ -309,8 +311,10 @@ static int records_filter(const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_INVALID, "record_stride must be mk_record_stride(n) = %d doubles", mk::record_stride((int)n));
     const bool any = o->d_F || o->d_Pf || o->d_Xp || o->d_Pp;
     if (!any) return 0; // bookkeeping-only / loglik launches do not touch state arrays
-    if (!(o->d_F && o->d_Xp && o->d_Pf == o->d_F + n && o->d_Pp == o->d_Xp + n))
-        return fail(MK_ERR_INVALID, "record layout needs d_Xp, d_F record arrays with d_Pp = d_Xp + n, d_Pf = d_F + n");
+    if (!(o->d_F && o->d_Pf == o->d_F + n))
+        return fail(MK_ERR_INVALID, "record layout needs a filtered record array d_F with d_Pf = d_F + n");
+    if ((o->d_Xp || o->d_Pp) && !(o->d_Xp && o->d_Pp == o->d_Xp + n))
+        return fail(MK_ERR_INVALID, "record layout needs d_Pp = d_Xp + n (or both NULL: filtered record only)");
     if (o->d_sigmas || o->d_detfs)
         if (o->d_sigmas != o->d_F + nv || (o->d_detfs && o->d_detfs != o->d_sigmas + 1))
             return fail(MK_ERR_INVALID, "record layout needs d_sigmas = d_F + n + n*n and d_detfs = d_sigmas + 1");
@@ -369,10 +373,23 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
         const int64_t n = p->N + p->K;
         if (o->record_stride != mk::record_stride((int)n))
             return fail(MK_ERR_INVALID, "record_stride must be mk_record_stride(n) = %d doubles", mk::record_stride((int)n));
-        if (!(o->d_Pf == o->d_F + n && o->d_S && o->d_Ps == o->d_S + n))
-            return fail(MK_ERR_INVALID, "record layout needs d_Pf = d_F + n and a smoothed record array d_S with d_Ps = d_S + n");
+        const bool proj = o->d_sim_means || o->d_sim_vars;
+        if (o->d_Pf != o->d_F + n) return fail(MK_ERR_INVALID, "record layout needs d_Pf = d_F + n");
+        if ((o->d_S || o->d_Ps) && !(o->d_S && o->d_Ps == o->d_S + n))
+            return fail(MK_ERR_INVALID, "record layout needs a smoothed record array d_S with d_Ps = d_S + n");
+        if (!o->d_S && !proj)
+            return fail(MK_ERR_INVALID, "nothing to write: give d_S/d_Ps records or d_sim_means/d_sim_vars");
+        if (proj && !p->d_loadings) return fail(MK_ERR_INVALID, "the projection outputs need d_loadings");
         a.rs = o->record_stride;
+    } else if (o->d_sim_means || o->d_sim_vars) {
+        return fail(MK_ERR_INVALID, "d_sim_means / d_sim_vars need the record layout (record_stride = mk_record_stride(n))");
     }
+    a.R = p->n_records;
+    a.loadings = p->d_loadings;
+    a.scale = p->d_scale;
+    a.offset = p->d_offset;
+    a.sim_means = o->d_sim_means;
+    a.sim_vars = o->d_sim_vars;
     a.B = p->n_instances;
     a.T = p->T;
     a.bs = o->time_major ? 1 : p->T;

@@ -38,6 +38,9 @@ struct SmootherArgs {
     long B, T;
     long bs, ts;
     long rs;             // > 0: F and S are packed-record arrays (Pf = F + n, Ps = S + n)
+    long R;              // observation records (loadings / scale / offset are per record)
+    const double *loadings, *scale, *offset; // fused projection epilogue (record kernel, optional)
+    double *sim_means, *sim_vars;            // [.,N] per (b,t), same (bs, ts) addressing
     const double *phi, *q;
     const double *F, *Pf;
     double *S, *Ps;

@@ -270,13 +270,47 @@ __device__ __forceinline__ void load_cols(const double *mat, double (&row)[n])
     for (int c = 0; c < n; ++c) row[c] = mat[c * n];
 }
 
+// ---------------------------------------------------------------- fused projection epilogue
+// SPKalmanFilter.simulate (kalmanfilter.py:569-603) for Metran's scaled observation matrix
+// Z~ = diag(s) [I | loadings] (metran/metran.py:944-961), evaluated on the moments a kernel holds
+// in registers: lane j < N returns  mean_j = s_j (x_j + sum_k g_jk x_{N+k}) + offset_j  and
+// var_j = max(s_j^2 (P_jj + 2 sum_k g_jk P_j,N+k + sum_kl g_jk g_jl P_N+k,N+l), 0).
+// Writing these 2N doubles instead of the n + n^2 state moments is what Metran.get_simulation
+// needs (metran/metran.py:831-883) and cuts the smoother's output traffic ~7x at n = 10, ~40x at n = 36.
+template <int N, int K, int G>
+__device__ __forceinline__ void project(double x, const double (&P)[N + K], const double (&gam)[K], double scale,
+                                        double offset, int lane, double &mean, double &var)
+{
+    using Gp = Group<G>;
+    double m = x, t = 0.0, diag = 0.0;
+    double pf[K][K]; // factor block of the covariance, replicated
+    sfor<0, K>(MK_LAMBDA(k) {
+        constexpr int kk = decltype(k)::value;
+        m = fma(gam[kk], Gp::template bcast<N + kk>(x), m);
+        sfor<kk, K>(MK_LAMBDA(l) {
+            constexpr int ll = decltype(l)::value;
+            pf[kk][ll] = pf[ll][kk] = Gp::template bcast<N + kk>(P[N + ll]);
+        });
+    });
+    sfor<0, N>(MK_LAMBDA(c) { diag = (decltype(c)::value == lane) ? P[decltype(c)::value] : diag; });
+    sfor<0, K>(MK_LAMBDA(k) {
+        constexpr int kk = decltype(k)::value;
+        double u = 2.0 * P[N + kk];
+        sfor<0, K>(MK_LAMBDA(l) { u = fma(gam[decltype(l)::value], pf[kk][decltype(l)::value], u); });
+        t = fma(gam[kk], u, t);
+    });
+    mean = fma(scale, m, offset);
+    const double v = scale * scale * (diag + t);
+    var = v > 0.0 ? v : 0.0; // :601-602
+}
+
 constexpr double kLn2 = 0.693147180559945309417232121458;
 constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 
 // =====================================================================================
 // Sequential-processing Kalman filter + -2 log L            (kalmanfilter.py:236-400, 550-567)
-//   OUT  : 0 = no state outputs (solver objective, mk_loglik), 1 = F, Pf, Xp, Pp all written
-//          (no null checks; packed records or dense), 2 = any subset (runtime null checks)
+//   OUT  : 0 = no state outputs (solver objective, mk_loglik), 1 = predicted + filtered packed records,
+//          3 = filtered packed record only (input of a projecting smoother), 2 = any dense subset
 //   BOOK : per-step sigmas/detfs are written (needs one log per step); otherwise the
 //          log-determinant is accumulated as a normalised product with ONE log at the end
 // =====================================================================================
@@ -326,13 +360,14 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
 
     // outputs: (b, t) lives at block index b*bs + t*ts -- (T, 1) model-major or (1, B) time-major
+    constexpr bool RECF = (OUT == 1 || OUT == 3); // filtered moments go to packed records
     MomentPtr oP = moment_ptr<n>(a.Xp, a.Pp, inst * a.bs, a.ts, OUT == 1 ? a.rs : 0, r); // predicted moments
-    MomentPtr oF = moment_ptr<n>(a.F, a.Pf, inst * a.bs, a.ts, OUT == 1 ? a.rs : 0, r);  // filtered moments
+    MomentPtr oF = moment_ptr<n>(a.F, a.Pf, inst * a.bs, a.ts, RECF ? a.rs : 0, r);      // filtered moments
     // OUT == 1 (packed records): the RS - NV pad doubles of both records are written too (whole cache
     // lines): lane l owns pad slot min(l, PADN-1); filtered record: slot 0 = sigma, slot 1 = detf, rest 0
     constexpr int RS = record_stride_c(n), PADN = RS - NV;
     const int pslot = lane < PADN ? lane : PADN - 1;
-    double *padF = OUT == 1 ? a.F + inst * a.bs * RS + NV + pslot : nullptr;
+    double *padF = RECF ? a.F + inst * a.bs * RS + NV + pslot : nullptr;
     double *padP = OUT == 1 ? a.Xp + inst * a.bs * RS + NV + pslot : nullptr;
 
     // ---- observation stream: tiles of 16 time steps through LDS ----
@@ -466,11 +501,11 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         }
 
         const int cnt = __popcll((unsigned long long)vm);
-        double pad = 0.0; // OUT == 1: what this lane writes into its pad slot of the filtered record
+        double pad = 0.0; // records: what this lane writes into its pad slot of the filtered record
         if (cnt > 0) { // :380-382 compressed bookkeeping
             if constexpr (BOOK) {
                 const double detf = fma((double)fexp, kLn2, log(fmant));
-                if constexpr (OUT == 1) {
+                if constexpr (RECF) {
                     // compressed entry sc lives in the pad of filtered record sc; sc == t unless an earlier
                     // step of this model was empty (then: one scattered 16-byte store, rare)
                     if (sc == t) pad = pslot == 0 ? sigma : (pslot == 1 ? detf : 0.0);
@@ -496,7 +531,7 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
         }
         if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
 
-        if constexpr (OUT == 1) {
+        if constexpr (RECF) {
             *oF.vec = x;               // :389
             store_cols<n>(oF.mat, P);  // :390
             *padF = pad;               // sigma | detf | zeros
@@ -510,7 +545,7 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     }
 
     // zero tail of the compressed arrays (np.zeros init, :307-308); record pads were written as zeros
-    if (BOOK && OUT != 1) {
+    if (BOOK && !RECF) {
         for (long i = sc + lane; i < T; i += G) {
             if (a.sigmas) a.sigmas[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
             if (a.detfs) a.detfs[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
@@ -631,9 +666,10 @@ struct RecordIO {
     }
 };
 
-template <int n, int G>
+template <int N, int K, int G, bool PROJ>
 __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
 {
+    constexpr int n = N + K;
     static_assert(n <= G, "state dimension must fit the lane group");
     using Gp = Group<G>;
     constexpr int GPB = 256 / G;
@@ -673,7 +709,22 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
     // addressing: (b, t) at block index b*bs + t*ts
     const long rstep = a.ts * RIO::RS;
     const double *recF = a.F + (T - 1) * rstep; // record array positioned at step t
-    double *recS = a.S + (T - 1) * rstep;
+    double *recS = a.S ? a.S + (T - 1) * rstep : nullptr; // smoothed records are optional when projecting
+
+    // PROJ: fused projection epilogue (simulate) of the smoothed moments, lanes j < N
+    const long rec_id = inst % a.R;
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K], pscale = 1.0, poffset = 0.0;
+    double *pM = nullptr, *pV = nullptr;
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
+        if (a.scale) pscale = a.scale[rec_id * N + jr];
+        if (a.offset) poffset = a.offset[rec_id * N + jr];
+        const long pidx = (inst * a.bs + (T - 1) * a.ts) * N + jr;
+        pM = a.sim_means ? a.sim_means + pidx : nullptr;
+        pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
+    }
 
     // fetch helpers: issue the HBM loads of one step / turn them into (x_r, row r)
     auto issue = [&](double &xnext) __attribute__((always_inline)) {
@@ -684,9 +735,21 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
         RIO::load_finish(imgL, prer, rmap, gw, r, xv, row);
     };
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
-        RIO::put(imgS, gw, r, xv, row);
-        RIO::emit(imgS, recS, rmap);
-        recS -= rstep;
+        if (recS) {
+            RIO::put(imgS, gw, r, xv, row);
+            RIO::emit(imgS, recS, rmap);
+            recS -= rstep;
+        }
+        if constexpr (PROJ) {
+            double mean, var;
+            project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
+            if (lane < N && live) { // factor rows hold other values: mask (one exec region per step)
+                if (pM) *pM = mean;
+                if (pV) *pV = var;
+            }
+            if (pM) pM -= a.ts * N;
+            if (pV) pV -= a.ts * N;
+        }
     };
 
     // last step: smoothed = filtered (:450-451)
@@ -1025,21 +1088,26 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
         hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false>), dim3(grid), dim3(256), 0, s, a);
     else if (!any)
         hipLaunchKernelGGL((filter_kernel<N, K, G, 0, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.rs > 0) // packed records (validated by the C ABI): whole-cache-line stores
+    else if (a.rs > 0 && a.Xp) // packed records (validated by the C ABI): whole-cache-line stores
         hipLaunchKernelGGL((filter_kernel<N, K, G, 1, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rs > 0) // filtered record only
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 3, true>), dim3(grid), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((filter_kernel<N, K, G, 2, true>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-template <int n>
-static hipError_t launch_smoother_n(const SmootherArgs &a, hipStream_t s)
+template <int N, int K>
+static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
 {
+    constexpr int n = N + K;
     constexpr int G = n <= 16 ? 16 : 64;
     constexpr int GPB = 256 / G;
     const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
-    if (a.rs > 0)
-        hipLaunchKernelGGL((smoother_record_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
+    if (a.rs > 0 && (a.sim_means || a.sim_vars))
+        hipLaunchKernelGGL((smoother_record_kernel<N, K, G, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rs > 0)
+        hipLaunchKernelGGL((smoother_record_kernel<N, K, G, false>), dim3(grid), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((smoother_dense_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -1048,7 +1116,10 @@ static hipError_t launch_smoother_n(const SmootherArgs &a, hipStream_t s)
 #define MK_CASE_FILTER(NN, KK) \
     if (N == NN && K == KK) return launch_filter_nk<NN, KK>(a, s);
 #define MK_CASE_SMOOTH(NN, KK) \
-    if (N + K == NN + KK) return launch_smoother_n<NN + KK>(a, s);
+    if (N == NN && K == KK) return launch_smoother_nk<NN, KK>(a, s);
+// without projection the smoother depends on n only: any compiled shape of the same state dimension serves
+#define MK_CASE_SMOOTH_N(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_smoother_nk<NN, KK>(a, s);
 #define MK_CASE_LIST(NN, KK) {NN, KK},
 
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s)
@@ -1060,6 +1131,7 @@ hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s)
 hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s)
 {
     MK_SHAPES(MK_CASE_SMOOTH)
+    MK_SHAPES(MK_CASE_SMOOTH_N)
     return hipErrorInvalidValue;
 }
 

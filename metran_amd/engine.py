@@ -68,6 +68,8 @@ class BatchedKalman:
         self.obs = None
         self.loadings = None
         self.obsvar = None
+        self.scale = None
+        self.offset = None
         self.R = self.T = self.N = self.K = None
         self._timing = False
 
@@ -201,7 +203,7 @@ class BatchedKalman:
         P0 = self._dev(P0, (B, self.n, self.n), "P0") if P0 is not None else None
         prob = Problem(B, self.R, self.T, self.N, self.K, int(warmup), self._p(self.obs), self._p(phi), self._p(q),
                        self._p(self.loadings), self._p(self.obsvar), self._p(x0), self._p(P0),
-                       1 if self.time_major else 0)
+                       1 if self.time_major else 0, self._p(self.scale), self._p(self.offset))
         keep = (phi, q, x0, P0)
         return prob, keep, B
 
@@ -265,7 +267,8 @@ class BatchedKalman:
         g = res.get
         return Outputs(self._p(g("mle")), self._p(g("sigmas")), self._p(g("detfs")), self._p(g("sigmacount")),
                        self._p(g("F")), self._p(g("Pf")), self._p(g("Xp")), self._p(g("Pp")), self._p(g("S")),
-                       self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0, int(g("_rs", 0)))
+                       self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0,
+                       self._p(g("sim_means")), self._p(g("sim_vars")), int(g("_rs", 0)))
 
     def filter(self, phi, q, warmup=1, x0=None, P0=None, outputs=("F", "Pf", "Xp", "Pp"), buffers=None):
         """``run_filter`` for B instances (kalmanfilter.py:696-778).  Returns a dict of device tensors."""
@@ -283,6 +286,40 @@ class BatchedKalman:
             want |= {"S", "Ps"}  # full output set -> packed records for all three moment sets
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         res = buffers if buffers is not None else self._alloc_outputs(B, [k for k in _STATE_OUTPUTS if k in want])
+        o = self._outputs_struct(res)
+        self._bind_stream()
+        check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
+        return res
+
+    def set_scaling(self, scale=None, offset=None):
+        """Series standard deviations / means ``[R,N]`` for the fused projection (``Metran.oseries_std`` /
+        ``oseries_mean``; the scaled observation matrix of metran/metran.py:944-961).  None = 1 / 0."""
+        def prep(a):
+            if a is None:
+                return None
+            torch = _torch()
+            if not isinstance(a, torch.Tensor):
+                a = np.asarray(a, dtype=np.float64)
+            if a.ndim == 1:
+                a = a[None]
+            return self._dev(a, (self.R, self.N), "scale/offset")
+        self.scale, self.offset = prep(scale), prep(offset)
+        return self
+
+    def simulate_smoothed(self, phi, q, warmup=1, x0=None, P0=None):
+        """``Metran.get_simulated_means/variances(method="smoother")`` for B instances in two launches
+        WITHOUT materialising the smoothed states: the filter writes only the filtered records, the
+        smoother reads them and writes the projected means/variances ``[B,T,N]`` (fused epilogue,
+        kalmanfilter.py:569-603 with the scaling set by ``set_scaling``).  Returns a dict with
+        ``sim_means, sim_vars, mle, sigmacount, status`` (and the filtered views ``F, Pf``)."""
+        torch = _torch()
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        res = {"mle": torch.empty(B, dtype=torch.float64, device=self.device),
+               "status": torch.zeros(B, dtype=torch.int32, device=self.device),
+               "sigmacount": torch.empty(B, dtype=torch.int64, device=self.device), "_rs": self.record_stride()}
+        res["_rec_filt"], res["F"], res["Pf"], res["sigmas"], res["detfs"] = self._alloc_records(B)
+        res["sim_means"] = self._empty_bt(B, self.T, self.N)
+        res["sim_vars"] = self._empty_bt(B, self.T, self.N)
         o = self._outputs_struct(res)
         self._bind_stream()
         check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
@@ -308,7 +345,7 @@ class BatchedKalman:
         if not shape:
             raise MetranHipError("no HIP smoother kernel compiled for state dimension n=%d" % n)
         N, K = shape[0]
-        prob = Problem(B, 1, T, N, K, 1, None, self._p(phi), self._p(q), None, None, None, None, 0)
+        prob = Problem(B, 1, T, N, K, 1, None, self._p(phi), self._p(q), None, None, None, None, 0, None, None)
         torch = _torch()
         res = {"F": F, "Pf": Pf, "status": torch.zeros(B, dtype=torch.int32, device=self.device)}
         if "S" in outputs:

@@ -29,3 +29,10 @@ run("Pf,Pp", ("Pf", "Pp"))
 run("full + smoother S,Ps", ("F", "Pf", "Xp", "Pp", "S", "Ps"), smooth=True)
 run("F,Pf + smoother S only", ("F", "Pf", "S"), smooth=True)
 run("F,Pf + smoother (no out)", ("F", "Pf"), smooth=True)
+# fused projection path (row f2): filtered records only + projecting smoother
+fs, ss = [], []
+for i in range(6):
+    r = kf.simulate_smoothed(d["phi"], d["q"])
+    f, s = kf.last_kernel_ms()
+    if i >= 2: fs.append(f); ss.append(s)
+print("%-28s filter %.3f ms  smoother %.3f ms" % ("simulate_smoothed (f2)", sum(fs)/len(fs), sum(ss)/len(ss)))

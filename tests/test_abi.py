@@ -109,7 +109,7 @@ def test_shape_module_builds_and_passes_hazard_check(tmp_path, monkeypatch):
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     for sym in ("mkmod_abi", "mkmod_shape", "mkmod_launch_filter", "mkmod_launch_smoother"):
         assert sym in out
-    assert "filter_kernelILi7ELi3ELi16" in out and "smoother_record_kernelILi10ELi16" in out
+    assert "filter_kernelILi7ELi3ELi16" in out and "smoother_record_kernelILi7ELi3ELi16" in out
     monkeypatch.setenv("METRAN_HIP_JIT", "0")
     with pytest.raises(jit.MetranHipError):
         jit.build_shape_module(6, 3)

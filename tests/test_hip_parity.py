@@ -222,3 +222,32 @@ def test_runtime_specialised_shapes(kf, N, K, tmp_path_factory, monkeypatch):
     for k, tol in (("F", FILT_ATOL), ("Pf", FILT_ATOL), ("Xp", FILT_ATOL), ("Pp", FILT_ATOL), ("S", SMOOTH_ATOL),
                    ("Ps", SMOOTH_ATOL), ("sigmas", 1e-10), ("detfs", 1e-10)):
         np.testing.assert_allclose(_np(r[k]), ref[k], rtol=0, atol=tol, err_msg=k)
+
+
+def test_fused_projection_epilogue(kf, g1):
+    """Row f2: the smoother's fused simulate() epilogue (no smoothed states materialised) equals the
+    reference's get_simulated_means/variances on examples/data and mk_simulate on the full states."""
+    kf.set_observations(g1["obs"][None]).set_loadings(g1["loadings"][None])
+    kf.set_scaling(g1["oseries_std"], g1["oseries_mean"])
+    r = kf.simulate_smoothed(g1["phi"][None], g1["q"][None])
+    assert abs(float(_np(r["mle"])[0]) - 2332.327069381027) <= MLE_RTOL * 2332.0
+    np.testing.assert_allclose(_np(r["sim_means"])[0], g1["sim_means"] + g1["oseries_mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(_np(r["sim_vars"])[0], g1["sim_vars"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(_np(r["F"])[0], g1["F"], rtol=0, atol=FILT_ATOL)
+    kf.set_scaling(None, None)
+    # batched, missing data, vs oracle states projected by the oracle
+    from metran_amd.params import observation_matrix
+
+    for (N, K, B, T) in [(8, 2, 21, 80), (32, 4, 3, 30)]:
+        d = make_dfm_batch(B, N, K, T, seed=77 + N, missing=0.25, first_step="random")
+        rng = np.random.default_rng(N)
+        scale, offset = rng.uniform(0.5, 3.0, (B, N)), rng.normal(size=(B, N))
+        kf.set_observations(d["obs"]).set_loadings(d["loadings"]).set_scaling(scale, offset)
+        r = kf.simulate_smoothed(d["phi"], d["q"])
+        ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
+        for b in range(B):
+            Zs = observation_matrix(d["loadings"][b]) * scale[b][:, None]
+            sm, sv = oracle.simulate(Zs, ref["S"][b], ref["Ps"][b])
+            np.testing.assert_allclose(_np(r["sim_means"])[b], sm + offset[b], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(_np(r["sim_vars"])[b], sv, rtol=0, atol=1e-9)
+        kf.set_scaling(None, None)
