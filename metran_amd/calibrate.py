@@ -1,0 +1,134 @@
+"""Batched calibration driver: maximum-likelihood estimation of the
+alpha parameters of MANY independent Metran models at once.
+
+The reference calibrates one model per ``Metran.solve()`` call: scipy L-BFGS-B drives
+``BaseSolver.objfunction -> Metran.get_mle`` (metran/solver.py:42-63, 222-288), and every gradient is
+P+1 sequential filter runs (2-point finite differences, no analytic jac).  Here R models advance in
+lock-step: one kernel launch evaluates the objective of every model at its current point AND at its P
+forward-difference points ((P+1)*R filter instances sharing the R uploaded records), a bound-projected
+L-BFGS update is computed for all models with batched tensor algebra on the device, and the Armijo
+back-tracking line search evaluates one trial point per still-searching model per launch.
+
+The iteration is not scipy's L-BFGS-B code path (that is ``metran_amd.solver.HipSolve``, which keeps
+scipy on the host and reproduces the reference's trajectory for ONE model); it minimises the same
+objective -2 log L(alpha) under the same bounds alpha >= pmin (metran/metran.py:439-462) and reaches the
+same optimum.  With torch.distributed initialised, the models are simply sharded over the ranks
+(``distributed.shard_range``): per-model parameters need no collective.
+"""
+import numpy as np
+
+__all__ = ["calibrate_batch", "CalibrationResult"]
+
+
+class CalibrationResult(dict):
+    """``alpha [R,P]``, ``obj [R]`` (-2 log L), ``grad [R,P]``, ``converged [R]`` (bool), ``nit``,
+    ``nfev`` (filter instances evaluated in total), ``launches``, ``aic [R]`` (= 2P + obj, solver.py:280)."""
+
+    __getattr__ = dict.__getitem__
+
+
+def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
+                    ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False):
+    """Calibrate every record held by ``kf`` (observations + loadings already set).
+
+    Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
+    ``ftol = factr*epsmch`` with factr 1e7, ``gtol = pgtol`` on the projected gradient, ``history = m``);
+    ``alpha0`` and ``pmin`` are Metran's initial value and lower bound (metran/metran.py:446-462).
+    """
+    import torch
+
+    R, n = kf.R, kf.n
+    dev = kf.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    x = torch.full((R, n), float(alpha0), **f64) if np.isscalar(alpha0) else kf._dev(alpha0, (R, n), "alpha0").clone()
+    lo = torch.full((R, n), float(pmin), **f64) if np.isscalar(pmin) else kf._dev(pmin, (R, n), "pmin")
+    x = torch.maximum(x, lo)
+    nfev = launches = 0
+    eye = torch.eye(n, **f64) * eps
+
+    def value_and_grad(xc):
+        """f and forward-difference gradient of all R models: ONE launch of (n+1)*R instances."""
+        nonlocal nfev, launches
+        pts = torch.cat([xc[None], xc[None] + eye[:, None, :]], 0).reshape((n + 1) * R, n)  # instance s*R + r
+        phi, q = kf.params_from_alpha(pts, dt=dt)
+        f = kf.loglik(phi, q, warmup=warmup).reshape(n + 1, R)
+        nfev += (n + 1) * R
+        launches += 1
+        return f[0].clone(), ((f[1:] - f[0:1]) / eps).transpose(0, 1).contiguous()
+
+    def value(xc):
+        nonlocal nfev, launches
+        phi, q = kf.params_from_alpha(xc, dt=dt)
+        nfev += R
+        launches += 1
+        return kf.loglik(phi, q, warmup=warmup).clone()
+
+    def proj_grad(xc, g):  # gradient with the components pushing into an active bound removed
+        return torch.where((xc <= lo) & (g > 0), torch.zeros_like(g), g)
+
+    f, g = value_and_grad(x)
+    S, Y, rho = [], [], []            # L-BFGS history, each [R,n] / [R]
+    active = torch.ones(R, dtype=torch.bool, device=dev)
+    nit = 0
+    for nit in range(1, maxiter + 1):
+        pg = proj_grad(x, g)
+        active &= pg.abs().amax(1) > gtol
+        if not bool(active.any()):
+            break
+        # two-loop recursion, all models at once
+        qv = pg.clone()
+        al = []
+        for s_, y_, r_ in zip(reversed(S), reversed(Y), reversed(rho)):
+            a_ = r_ * (s_ * qv).sum(1)
+            al.append(a_)
+            qv = qv - a_[:, None] * y_
+        if S:
+            gamma = (S[-1] * Y[-1]).sum(1) / (Y[-1] * Y[-1]).sum(1).clamp_min(1e-300)
+            qv = qv * gamma[:, None]
+        for (s_, y_, r_), a_ in zip(zip(S, Y, rho), reversed(al)):
+            b_ = r_ * (y_ * qv).sum(1)
+            qv = qv + (a_ - b_)[:, None] * s_
+        d = -qv
+        # fall back to steepest descent where the direction is not a descent direction
+        bad = (d * pg).sum(1) >= 0
+        d = torch.where(bad[:, None], -pg, d)
+        if not S:
+            d = d / pg.abs().amax(1, keepdim=True).clamp_min(1e-300)  # first step: unit-scale move
+        d = torch.where(active[:, None], d, torch.zeros_like(d))
+        # Armijo back-tracking on the projected path, one trial per searching model per launch
+        step = torch.ones(R, **f64)
+        searching = active.clone()
+        x_new, f_new = x.clone(), f.clone()
+        for _ in range(max_backtracks):
+            xt = torch.maximum(x + step[:, None] * d, lo)
+            ft = value(torch.where(searching[:, None], xt, x))
+            ok = searching & (ft <= f + 1e-4 * (pg * (xt - x)).sum(1)) & torch.isfinite(ft)
+            x_new = torch.where(ok[:, None], xt, x_new)
+            f_new = torch.where(ok, ft, f_new)
+            searching &= ~ok
+            if not bool(searching.any()):
+                break
+            step = torch.where(searching, step * 0.5, step)
+        active &= ~searching  # no acceptable step: this model is done (at numerical precision)
+        f_prev = f
+        g_prev = g
+        f_tmp, g_new = value_and_grad(x_new)
+        s_ = x_new - x
+        y_ = g_new - g_prev
+        sy = (s_ * y_).sum(1)
+        good = sy > 1e-10 * (y_ * y_).sum(1).clamp_min(1e-300)
+        if bool(good.any()):
+            S.append(torch.where(good[:, None], s_, torch.zeros_like(s_)))
+            Y.append(torch.where(good[:, None], y_, torch.zeros_like(y_)))
+            rho.append(torch.where(good, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy)))
+            if len(S) > history:
+                S.pop(0), Y.pop(0), rho.pop(0)
+        x, f, g = x_new, f_tmp, g_new
+        # scipy's relative-reduction test: (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol
+        rel = (f_prev - f) / torch.maximum(torch.maximum(f_prev.abs(), f.abs()), torch.ones_like(f))
+        active &= rel > ftol
+        if verbose:
+            print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
+    pg = proj_grad(x, g)
+    return CalibrationResult(alpha=x, obj=f, grad=g, converged=~active, nit=nit, nfev=nfev, launches=launches,
+                             aic=2 * n + f, pgnorm=pg.abs().amax(1))
