@@ -139,13 +139,15 @@ struct Group<64> {
     static constexpr unsigned long long full_mask(int N) { return N >= 64 ? ~0ull : (1ull << N) - 1ull; }
 };
 
+typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
+
 template <int n>
 __device__ __forceinline__ void store_row(double *dst, const double (&row)[n])
 {
     if constexpr (n % 2 == 0) {
-        double2 *d2 = reinterpret_cast<double2 *>(dst); // row offset is a multiple of 16 B
+        v2d *d2 = reinterpret_cast<v2d *>(dst); // row offset is a multiple of 16 B
 #pragma unroll
-        for (int c = 0; c < n / 2; ++c) d2[c] = make_double2(row[2 * c], row[2 * c + 1]);
+        for (int c = 0; c < n / 2; ++c) d2[c] = v2d{row[2 * c], row[2 * c + 1]};
     } else {
 #pragma unroll
         for (int c = 0; c < n; ++c) dst[c] = row[c];
@@ -156,10 +158,10 @@ template <int n>
 __device__ __forceinline__ void load_row(const double *src, double (&row)[n])
 {
     if constexpr (n % 2 == 0) {
-        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+        const v2d *s2 = reinterpret_cast<const v2d *>(src);
 #pragma unroll
         for (int c = 0; c < n / 2; ++c) {
-            double2 v = s2[c];
+            const v2d v = s2[c];
             row[2 * c] = v.x;
             row[2 * c + 1] = v.y;
         }
@@ -209,8 +211,6 @@ __device__ __forceinline__ double rcp_nr(double x)
 //     [ mean(n) | covariance(n*n) | sigma, detf (filtered set only) | zero pad ]     RS doubles,
 // with RS*8 a multiple of 128 bytes; the reference-shaped arrays are strided VIEWS of the record
 // arrays on the host.
-typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
-
 __device__ __forceinline__ void wave_lds_sync()
 {
     // LDS-only ("local") fences: a generic fence would also pin private arrays to scratch memory
@@ -245,8 +245,8 @@ __device__ __forceinline__ MomentPtr moment_ptr(double *V, double *M, long blk, 
 {
     MomentPtr p;
     if (rs > 0) {
-        p.vec = V + blk * rs + r;
-        p.mat = V + blk * rs + n + r;
+        p.vec = V ? V + blk * rs + r : nullptr; // projection-only smoothing has no smoothed record array
+        p.mat = V ? V + blk * rs + n + r : nullptr;
         p.vstep = p.mstep = ts * rs;
     } else {
         p.vec = V ? V + blk * n + r : nullptr;
@@ -988,6 +988,177 @@ __global__ void __launch_bounds__(256) smoother_dense_kernel(SmootherArgs a)
 }
 
 // =====================================================================================
+// one model per wavefront (16 < n <= 64): the row-per-lane arrays of the kernels above would need
+// ~10 x n doubles per lane and spill (measured at n = 36: 1433 spilled VGPRs, 8x slower than the
+// filter).  Here D = Ps[t+1] - Pp[t+1], the rows of Pf[t] and the gain J live in a wave-private LDS
+// block; the two n^3 sweeps (V = J D, Ps = Pf + V J^T) are RUN-TIME loops whose operand rows are read
+// from LDS at wavefront-uniform addresses (LDS broadcast, no v_readlane), so the scheduler cannot
+// hoist n*n loads across the factorisation (it did, and spilled them, when the sweeps were unrolled)
+// and the code stays inside the instruction cache.  <= 3 row arrays are live at any time.
+template <int n>
+constexpr int wave_kernel_wpb() // wavefronts per workgroup: 3 n x n matrices each within 160 KB of LDS
+{
+    return 4 * 3 * n * n * 8 <= 160 * 1024 ? 4 : (2 * 3 * n * n * 8 <= 160 * 1024 ? 2 : 1);
+}
+
+template <int N, int K, bool PROJ>
+__global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_kernel(SmootherArgs a)
+{
+    constexpr int n = N + K, G = 64, WPB = wave_kernel_wpb<n>();
+    static_assert(n <= G, "state dimension must fit the wavefront");
+    using Gp = Group<G>;
+    const int lane = threadIdx.x % G;
+    long inst = (long)blockIdx.x * WPB + threadIdx.x / G;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1;
+    const int r = lane < n ? lane : n - 1;
+    const long T = a.T;
+    __shared__ __attribute__((aligned(16))) double lds_m[WPB * 3 * n * n];
+    double *Dm = lds_m + (threadIdx.x / G) * 3 * n * n; // D, row-major
+    double *Pm = Dm + n * n;                            // rows of Pf[t], then of Ps[t]
+    double *Jm = Pm + n * n;                            // rows of the smoother gain J
+    double *Pr = Pm + r * n;
+    const double *Jr = Jm + r * n;
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+
+    const long blkT = inst * a.bs + (T - 1) * a.ts;
+    MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
+    MomentPtr oS = moment_ptr<n>(a.S, a.Ps, blkT, a.ts, a.rs, r);
+    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
+    double *padS = (a.rs > 0 && a.S) ? a.S + blkT * RS + NV + (lane < PADN ? lane : PADN - 1) : nullptr;
+
+    const long rec_id = inst % a.R;
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K], pscale = 1.0, poffset = 0.0;
+    double *pM = nullptr, *pV = nullptr;
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
+        if (a.scale) pscale = a.scale[rec_id * N + jr];
+        if (a.offset) poffset = a.offset[rec_id * N + jr];
+        const long pidx = blkT * N + jr;
+        pM = a.sim_means ? a.sim_means + pidx : nullptr;
+        pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
+    }
+    auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
+        if (oS.vec) *oS.vec = xv;
+        if (oS.mat) store_cols<n>(oS.mat, row);
+        oS.advance(-1);
+        if (padS) {
+            *padS = 0.0;
+            padS -= a.ts * RS;
+        }
+        if constexpr (PROJ) {
+            double mean, var;
+            project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
+            if (lane < N && live) {
+                if (pM) *pM = mean;
+                if (pV) *pV = var;
+            }
+            if (pM) pM -= a.ts * N;
+            if (pV) pV -= a.ts * N;
+        }
+    };
+
+    // last step: smoothed = filtered (:450-451)
+    double xs = *iF.vec, Psn[n];
+    load_cols<n>(iF.mat, Psn);
+    store(xs, Psn);
+    double pivmin = 1.0;
+
+    for (long t = T - 2; t >= 0; --t) {
+        iF.advance_nn(-1);
+        const double xfc = *iF.vec;
+        double A[n], z[n];
+        {
+            double Pfc[n], D[n];
+            load_cols<n>(iF.mat, Pfc);
+            sfor<0, n>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;
+                z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
+                A[c] = fma(phi_r, z[c], c == r ? q_r : 0.0); // Pp[t+1] row
+                D[c] = Psn[c] - A[c];
+            });
+            wave_lds_sync(); // previous iteration's reads of Dm / Pm / Jm are complete
+            store_row<n>(Dm + r * n, D);
+            store_row<n>(Pr, Pfc);
+        }
+        const double delta = xs - phi_r * xfc;
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- A = L D L^T (rows distributed over the lanes), as in the group kernels ----
+        double dinv[n];
+        sfor<0, n>(MK_LAMBDA(jc) {
+            constexpr int j = decltype(jc)::value;
+            const double piv = Gp::template bcast<j>(A[j]);
+            pivmin = min_f64(pivmin, piv);
+            const double ij = rcp_nr(piv);
+            dinv[j] = ij;
+            const double lr = A[j] * ij;
+            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+            A[j] = lr;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        sfor<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int c = 0; c < n; ++c) z[c] *= dinv[c];
+        sfor_down<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+            Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        store_row<n>(Jm + r * n, z); // lane r now holds row r of J = W Pp^-1
+
+        double acc0 = xfc, acc1 = 0.0;
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
+            else Gp::template fmac<c>(acc1, delta, z[c]);
+        });
+        xs = acc0 + acc1;
+        wave_lds_sync(); // Dm, Pm, Jm visible to the whole wavefront
+        __builtin_amdgcn_sched_barrier(0);
+
+        // V = J D: V[r][:] += J[r][k] * D[k][:], D row k broadcast from LDS
+        double V[n];
+#pragma unroll
+        for (int c = 0; c < n; ++c) V[c] = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < n; ++k) {
+            const double zk = Jr[k];
+            double Dk[n];
+            load_row<n>(Dm + k * n, Dk);
+#pragma unroll
+            for (int c = 0; c < n; ++c) V[c] = fma(zk, Dk[c], V[c]);
+        }
+        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J row c broadcast from LDS; result back into Pm
+#pragma unroll 1
+        for (int c = 0; c < n; ++c) {
+            double Jc[n];
+            load_row<n>(Jm + c * n, Jc);
+            double s0 = Pr[c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                if (k % 4 == 0) s0 = fma(V[k], Jc[k], s0);
+                else if (k % 4 == 1) s1 = fma(V[k], Jc[k], s1);
+                else if (k % 4 == 2) s2 = fma(V[k], Jc[k], s2);
+                else s3 = fma(V[k], Jc[k], s3);
+            }
+            Pr[c] = (s0 + s1) + (s2 + s3);
+        }
+        wave_lds_sync(); // orders the scalar stores above before the vector loads of the same row
+        load_row<n>(Pr, Psn);
+        store(xs, Psn);
+    }
+    if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
+}
+
 // =====================================================================================
 // Small helper kernels
 // =====================================================================================
@@ -1102,14 +1273,23 @@ static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
 {
     constexpr int n = N + K;
     constexpr int G = n <= 16 ? 16 : 64;
-    constexpr int GPB = 256 / G;
-    const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
-    if (a.rs > 0 && (a.sim_means || a.sim_vars))
-        hipLaunchKernelGGL((smoother_record_kernel<N, K, G, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.rs > 0)
-        hipLaunchKernelGGL((smoother_record_kernel<N, K, G, false>), dim3(grid), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((smoother_dense_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
+    if constexpr (G == 64) { // one model per wavefront: LDS-resident matrices, any addressing
+        constexpr int WPB = wave_kernel_wpb<n>();
+        const unsigned wgrid = (unsigned)((a.B + WPB - 1) / WPB);
+        if (a.sim_means || a.sim_vars)
+            hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(wgrid), dim3(64 * WPB), 0, s, a);
+        else
+            hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(wgrid), dim3(64 * WPB), 0, s, a);
+    } else {
+        constexpr int GPB = 256 / G;
+        const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
+        if (a.rs > 0 && (a.sim_means || a.sim_vars))
+            hipLaunchKernelGGL((smoother_record_kernel<N, K, G, true>), dim3(grid), dim3(256), 0, s, a);
+        else if (a.rs > 0)
+            hipLaunchKernelGGL((smoother_record_kernel<N, K, G, false>), dim3(grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((smoother_dense_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 
