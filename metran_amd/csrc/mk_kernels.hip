@@ -125,15 +125,42 @@ struct Group<64> {
     {
         acc = fma(NEG ? -bcast<J>(src) : bcast<J>(src), mul, acc);
     }
+    // A broadcast is two v_readlane_b32 into an SGPR pair that the FMA reads as a constant, with 2 wait
+    // states between them: issued one after the other every FMA pays an `s_nop 1` (~9 cycles for a lone
+    // wavefront).  The sweeps therefore run in batches of BATCH elements, all broadcasts of a batch first
+    // (source order is what the scheduler keeps), then the FMAs; the scheduling fence after each batch
+    // bounds the live SGPRs at 2*BATCH -- left alone the compiler hoists every readlane of a sweep to
+    // its top and spills the SGPRs into VGPR lanes and those VGPRs into scratch (measured at n = 36).
+    static constexpr int BATCH = 6;
     template <int J, int C0, int C1, bool NEG, int n>
     static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
     {
-        sfor<C0, C1>(MK_LAMBDA(c) { fmac<J, NEG>(acc[decltype(c)::value], src[decltype(c)::value], mul); });
+        if constexpr (C0 < C1) {
+            constexpr int CE = C0 + BATCH < C1 ? C0 + BATCH : C1;
+            double b[CE - C0];
+            sfor<C0, CE>(MK_LAMBDA(c) { b[decltype(c)::value - C0] = bcast<J>(src[decltype(c)::value]); });
+            sfor<C0, CE>(MK_LAMBDA(c) {
+                constexpr int cc = decltype(c)::value;
+                acc[cc] = fma(NEG ? -b[cc - C0] : b[cc - C0], mul, acc[cc]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            axpy_lane<J, CE, C1, NEG, n>(acc, src, mul);
+        }
     }
     template <int C0, int C1, bool NEG, int n>
     static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
     {
-        sfor<C0, C1>(MK_LAMBDA(c) { fmac<decltype(c)::value, NEG>(acc[decltype(c)::value], src, mul); });
+        if constexpr (C0 < C1) {
+            constexpr int CE = C0 + BATCH < C1 ? C0 + BATCH : C1;
+            double b[CE - C0];
+            sfor<C0, CE>(MK_LAMBDA(c) { b[decltype(c)::value - C0] = bcast<decltype(c)::value>(src); });
+            sfor<C0, CE>(MK_LAMBDA(c) {
+                constexpr int cc = decltype(c)::value;
+                acc[cc] = fma(NEG ? -b[cc - C0] : b[cc - C0], mul, acc[cc]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            axpy_col<CE, C1, NEG, n>(acc, src, mul);
+        }
     }
     static __device__ __forceinline__ unsigned long long group_bits(unsigned long long m) { return m; }
     static constexpr unsigned long long full_mask(int N) { return N >= 64 ? ~0ull : (1ull << N) - 1ull; }
@@ -315,7 +342,7 @@ constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 //          log-determinant is accumulated as a normalised product with ONE log at the end
 // =====================================================================================
 template <int N, int K, int G, int OUT, bool BOOK>
-__global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 ? 2 : 1))) filter_kernel(FilterArgs a)
 {
     constexpr int n = N + K;
     static_assert(n <= G, "state dimension must fit the lane group");
@@ -334,11 +361,22 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
     // per-model constants: lane r holds phi_r, q_r; lane j < N holds loadings[j,:] and obsvar[j]
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
-    double pp[n], qd[n]; // row r of Phi (x) Phi and of Q = diag(q)
-    sfor<0, n>(MK_LAMBDA(c) {
-        pp[decltype(c)::value] = phi_r * Gp::template bcast<decltype(c)::value>(phi_r);
-        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
-    });
+    // row r of Phi (x) Phi and of Q = diag(q) in registers -- except for one model per wavefront
+    // (n > 16), where those 4n VGPRs are what stands between one and two resident wavefronts per SIMD:
+    // there diag(Phi) is read back from LDS every step (wavefront-uniform address) and Q's row is re-selected
+    constexpr bool WIDE = (G == 64);
+    double pp[WIDE ? 1 : n], qd[WIDE ? 1 : n];
+    __shared__ __attribute__((aligned(16))) double lds_phi[WIDE ? (256 / G) * (n + (n & 1)) : 1];
+    const double *phim = lds_phi + (WIDE ? (threadIdx.x / G) * (n + (n & 1)) : 0);
+    if constexpr (WIDE) {
+        lds_phi[(threadIdx.x / G) * (n + (n & 1)) + r] = phi_r;
+        wave_lds_sync();
+    } else {
+        sfor<0, n>(MK_LAMBDA(c) {
+            pp[decltype(c)::value] = phi_r * Gp::template bcast<decltype(c)::value>(phi_r);
+            qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
+        });
+    }
     const int jr = lane < N ? lane : N - 1;
     double gam[K];
 #pragma unroll
@@ -429,8 +467,18 @@ __global__ void __launch_bounds__(256) filter_kernel(FilterArgs a)
 
         // ---- predict (:318-331; Phi diagonal) ----
         x = phi_r * x;
+        if constexpr (WIDE) {
+            int rv = r; // opaque copies: keeps the n selects inside the loop (hoisted, they are 2n VGPRs)
+            double qv = q_r;
+            asm volatile("" : "+v"(rv), "+v"(qv));
+            double phc[n];
+            load_row<n>(phim, phc);
 #pragma unroll
-        for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
+            for (int c = 0; c < n; ++c) P[c] = fma(P[c] * phi_r, phc[c], c == rv ? qv : 0.0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
+        }
         if constexpr (OUT == 1) {
             *oP.vec = x;               // :332
             store_cols<n>(oP.mat, P);  // :333
@@ -996,13 +1044,14 @@ __global__ void __launch_bounds__(256) smoother_dense_kernel(SmootherArgs a)
 // hoist n*n loads across the factorisation (it did, and spilled them, when the sweeps were unrolled)
 // and the code stays inside the instruction cache.  <= 3 row arrays are live at any time.
 template <int n>
-constexpr int wave_kernel_wpb() // wavefronts per workgroup: 3 n x n matrices each within 160 KB of LDS
-{
-    return 4 * 3 * n * n * 8 <= 160 * 1024 ? 4 : (2 * 3 * n * n * 8 <= 160 * 1024 ? 2 : 1);
+constexpr int wave_kernel_wpb() // wavefronts per workgroup: one, so that LDS (2 n x n matrices per wavefront)
+{                               // is handed out at wavefront granularity: 7 resident wavefronts per CU at n = 36
+    return 1;
 }
 
 template <int N, int K, bool PROJ>
-__global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_kernel(SmootherArgs a)
+__global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) __attribute__((amdgpu_waves_per_eu(2, 2)))
+smoother_wave_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, G = 64, WPB = wave_kernel_wpb<n>();
     static_assert(n <= G, "state dimension must fit the wavefront");
@@ -1013,11 +1062,10 @@ __global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_k
     if (!live) inst = a.B - 1;
     const int r = lane < n ? lane : n - 1;
     const long T = a.T;
-    __shared__ __attribute__((aligned(16))) double lds_m[WPB * 3 * n * n];
-    double *Dm = lds_m + (threadIdx.x / G) * 3 * n * n; // D, row-major
-    double *Pm = Dm + n * n;                            // rows of Pf[t], then of Ps[t]
-    double *Jm = Pm + n * n;                            // rows of the smoother gain J
-    double *Pr = Pm + r * n;
+    __shared__ __attribute__((aligned(16))) double lds_m[WPB * 2 * n * n];
+    double *Dm = lds_m + (threadIdx.x / G) * 2 * n * n; // D row-major; after the V sweep: rows of V J^T
+    double *Jm = Dm + n * n;                            // rows of the smoother gain J
+    double *Dr = Dm + r * n;
     const double *Jr = Jm + r * n;
 
     const double phi_r = a.phi[inst * n + r];
@@ -1073,43 +1121,63 @@ __global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_k
         const double xfc = *iF.vec;
         double A[n], z[n];
         {
-            double Pfc[n], D[n];
+            double Pfc[n];
             load_cols<n>(iF.mat, Pfc);
+            wave_lds_sync(); // previous iteration's reads of Dm / Jm are complete
+            // element by element, D streamed to LDS in 16-byte pieces: Pf, Ps[t+1], W, Pp and D rows
+            // all live at once would be 5n doubles per lane
+            double dprev = 0.0;
+            // (opaque copies: the n loop-invariant selects "c == r ? q : 0" would otherwise be hoisted out
+            // of the time loop and spilled -- 2n VGPRs that are not there)
+            int rv = r;
+            double qv = q_r;
+            asm volatile("" : "+v"(rv), "+v"(qv));
             sfor<0, n>(MK_LAMBDA(cc) {
                 constexpr int c = decltype(cc)::value;
                 z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
-                A[c] = fma(phi_r, z[c], c == r ? q_r : 0.0); // Pp[t+1] row
-                D[c] = Psn[c] - A[c];
+                A[c] = fma(phi_r, z[c], c == rv ? qv : 0.0);   // Pp[t+1] row
+                const double d = Psn[c] - A[c];
+                if constexpr (n % 2 == 0) {
+                    if constexpr (c % 2 == 1) *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{dprev, d};
+                    else dprev = d;
+                } else {
+                    Dr[c] = d;
+                }
+                if constexpr (c % 8 == 7) __builtin_amdgcn_sched_barrier(0);
             });
-            wave_lds_sync(); // previous iteration's reads of Dm / Pm / Jm are complete
-            store_row<n>(Dm + r * n, D);
-            store_row<n>(Pr, Pfc);
         }
         const double delta = xs - phi_r * xfc;
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- A = L D L^T (rows distributed over the lanes), as in the group kernels ----
-        double dinv[n];
+        // (the unused diagonal slot of lane j, L(j,j) = 1, keeps 1/d_j: no separate dinv[] array)
         sfor<0, n>(MK_LAMBDA(jc) {
             constexpr int j = decltype(jc)::value;
             const double piv = Gp::template bcast<j>(A[j]);
             pivmin = min_f64(pivmin, piv);
             const double ij = rcp_nr(piv);
-            dinv[j] = ij;
             const double lr = A[j] * ij;
             Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
-            A[j] = lr;
+            A[j] = j == lane ? ij : lr;
             __builtin_amdgcn_sched_barrier(0);
         });
+        // the broadcast operands of the two substitutions are all known once the factorisation is done;
+        // tying each stage's operand to that stage's pivot element (empty asm, no instruction) keeps the
+        // compiler from running the n^2/2 readlanes ahead of the FMAs that consume them
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
+            asm volatile("" : "+v"(A[k]) : "v"(z[k]));
             Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
             __builtin_amdgcn_sched_barrier(0);
         });
-#pragma unroll
-        for (int c = 0; c < n; ++c) z[c] *= dinv[c];
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            z[c] *= Gp::template bcast<c>(A[c]);
+        });
         sfor_down<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
+#pragma unroll
+            for (int c = 0; c < k; ++c) asm volatile("" : "+v"(A[c]) : "v"(z[k]));
             Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -1122,8 +1190,11 @@ __global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_k
             else Gp::template fmac<c>(acc1, delta, z[c]);
         });
         xs = acc0 + acc1;
-        wave_lds_sync(); // Dm, Pm, Jm visible to the whole wavefront
+        wave_lds_sync(); // Dm, Jm visible to the whole wavefront
         __builtin_amdgcn_sched_barrier(0);
+        // Pf[t] again (L2-resident; its registers were needed by the factorisation): lands during the sweeps
+        double Pfc[n];
+        load_cols<n>(iF.mat, Pfc);
 
         // V = J D: V[r][:] += J[r][k] * D[k][:], D row k broadcast from LDS
         double V[n];
@@ -1137,12 +1208,15 @@ __global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_k
 #pragma unroll
             for (int c = 0; c < n; ++c) V[c] = fma(zk, Dk[c], V[c]);
         }
-        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J row c broadcast from LDS; result back into Pm
+        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J row c broadcast from LDS.  c is a run-time index, so
+        // the sums go back into this lane's row of Dm (every lane is past the V sweep: the wavefront runs
+        // in lock-step and LDS operations of one wavefront complete in order)
+        wave_lds_sync();
 #pragma unroll 1
         for (int c = 0; c < n; ++c) {
             double Jc[n];
             load_row<n>(Jm + c * n, Jc);
-            double s0 = Pr[c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
             for (int k = 0; k < n; ++k) {
                 if (k % 4 == 0) s0 = fma(V[k], Jc[k], s0);
@@ -1150,10 +1224,12 @@ __global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) smoother_wave_k
                 else if (k % 4 == 2) s2 = fma(V[k], Jc[k], s2);
                 else s3 = fma(V[k], Jc[k], s3);
             }
-            Pr[c] = (s0 + s1) + (s2 + s3);
+            Dr[c] = (s0 + s1) + (s2 + s3);
         }
         wave_lds_sync(); // orders the scalar stores above before the vector loads of the same row
-        load_row<n>(Pr, Psn);
+        load_row<n>(Dr, Psn);
+#pragma unroll
+        for (int c = 0; c < n; ++c) Psn[c] += Pfc[c];
         store(xs, Psn);
     }
     if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
