@@ -366,10 +366,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     // there diag(Phi) is read back from LDS every step (wavefront-uniform address) and Q's row is re-selected
     constexpr bool WIDE = (G == 64);
     double pp[WIDE ? 1 : n], qd[WIDE ? 1 : n];
-    __shared__ __attribute__((aligned(16))) double lds_phi[WIDE ? (256 / G) * (n + (n & 1)) : 1];
-    const double *phim = lds_phi + (WIDE ? (threadIdx.x / G) * (n + (n & 1)) : 0);
+    constexpr int NP = n + (n & 1); // even: rows of 16-byte pieces
+    __shared__ __attribute__((aligned(16))) double lds_phi[WIDE ? (256 / G) * 2 * NP : 1];
+    double *phim = lds_phi + (WIDE ? (threadIdx.x / G) * 2 * NP : 0); // diag(Phi)
+    double *dvec = phim + (WIDE ? NP : 0);                             // d = P Z_j^T of the current update
     if constexpr (WIDE) {
-        lds_phi[(threadIdx.x / G) * (n + (n & 1)) + r] = phi_r;
+        phim[r] = phi_r;
         wave_lds_sync();
     } else {
         sfor<0, n>(MK_LAMBDA(c) {
@@ -428,18 +430,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     double *otile = lds_obs + (threadIdx.x / G) * 2 * TS * N; // this model's two tiles
     const double *obase = a.obs + rec * a.obs_bs * N;
     const long ostep = a.obs_ts * N;
-    ochunk_t oreg[ONC];
+    ochunk_t oreg[WIDE ? 1 : ONC];
+    // WIDE (one model per wavefront): a step takes ~10 us, the once-per-tile wait for the store queue is
+    // noise, and the N staging registers held across two steps are not: fetch and park in one go
+    long otr = 0;
     auto obs_issue = [&](long t0) __attribute__((always_inline)) { // HBM -> registers, row min(t0+lane, T-1)
         long tr = t0 + lrow;
         if (tr > T - 1) tr = T - 1;
-        const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + tr * ostep);
+        if constexpr (WIDE) {
+            otr = tr;
+        } else {
+            const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + tr * ostep);
 #pragma unroll
-        for (int i = 0; i < ONC; ++i) oreg[i] = src[i];
+            for (int i = 0; i < ONC; ++i) oreg[i] = src[i];
+        }
     };
     auto obs_park = [&](int buf) __attribute__((always_inline)) { // registers -> LDS tile `buf`
         ochunk_t *dst = reinterpret_cast<ochunk_t *>(otile + (buf * TS + lrow) * N);
+        if constexpr (WIDE) {
+            const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + otr * ostep);
 #pragma unroll
-        for (int i = 0; i < ONC; ++i) dst[i] = oreg[i];
+            for (int i = 0; i < ONC; ++i) dst[i] = src[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ONC; ++i) dst[i] = oreg[i];
+        }
         wave_lds_sync();
     };
     obs_issue(0);
@@ -524,7 +539,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             const double rf = rcp_nr(f);
             const double kr = dr * rf; // Kalman gain element r (:364-366)
             // P -= k k^T f (:368-372): P[r][c] -= d_c * k_r, d_c broadcast from lane c
-            Gp::template axpy_col<0, n, true, n>(P, dr, kr);
+            if constexpr (WIDE) {
+                // n broadcasts through readlane are 2n VALU + n FMA issues; through LDS (every lane stores
+                // its d_r, then reads the whole vector at a wavefront-uniform address) the VALU sees only
+                // the n FMAs -- these kernels are VALU-issue bound (one f64 wave instruction per 4 cycles)
+                dvec[r] = dr;
+                wave_lds_sync();
+                double dc[n];
+                load_row<n>(dvec, dc);
+#pragma unroll
+                for (int c = 0; c < n; ++c) P[c] = fma(-dc[c], kr, P[c]);
+            } else {
+                Gp::template axpy_col<0, n, true, n>(P, dr, kr);
+            }
             x = fma(kr, v, x);             // :374-375
             sigma = fma(v * v, rf, sigma); // :377
             // detf += log f (:378): accumulate prod f as mantissa * 2^exp

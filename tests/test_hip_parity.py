@@ -205,6 +205,42 @@ def test_full_size_properties(kf):
     assert float((zx - d["obs"]).abs().max()) < 1e-9
 
 
+def test_full_size_c4_projection(kf):
+    """BASELINE configs[3] size (B=4096, 32 series / 4 factors, 30 % missing, T=2000).  Three full state
+    records per step would be 264 GB; the fused projection path keeps one (88 GB) and emits what
+    get_simulation consumes.  Checks: a sub-sample equals the oracle (loglik, projected means/variances),
+    every model's status is clean, variances are non-negative and, where a series is observed, the
+    smoothed projection reproduces the observation (R = 0) with zero variance."""
+    import torch
+
+    from metran_amd.params import observation_matrix
+    from metran_amd.synthetic import make_dfm_batch_torch
+
+    B, N, K, T = 4096, 32, 4, 2000
+    free, _ = torch.cuda.mem_get_info(kf.device)
+    if free < 120e9:
+        pytest.skip("needs ~100 GB of free HBM")
+    d = make_dfm_batch_torch(B, N, K, T, seed=4000, device=kf.device, missing=0.3)
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"]).set_scaling(None, None)
+    r = kf.simulate_smoothed(d["phi"], d["q"])
+    torch.cuda.synchronize()
+    assert not r["status"].any()
+    idx = [0, 1777, 4095]
+    sub = {k: _np(d[k][idx]) for k in ("obs", "phi", "q", "loadings")}
+    ref = oracle.dfm_batch(sub["obs"], sub["phi"], sub["q"], sub["loadings"])
+    assert rel_err(_np(r["mle"][idx]), ref["mle"]) < MLE_RTOL
+    for i, b in enumerate(idx):
+        sm, sv = oracle.simulate(observation_matrix(sub["loadings"][i]), ref["S"][i], ref["Ps"][i])
+        np.testing.assert_allclose(_np(r["sim_means"][b]), sm, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(_np(r["sim_vars"][b]), sv, rtol=0, atol=1e-9)
+    assert bool((r["sim_vars"] >= 0).all())
+    seen = torch.isfinite(d["obs"])
+    assert float((r["sim_means"] - torch.nan_to_num(d["obs"]))[seen].abs().max()) < 1e-8
+    assert float(r["sim_vars"][seen].abs().max()) < 1e-8
+    del r, d
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("N,K", [(7, 2), (11, 3), (20, 2)])
 def test_runtime_specialised_shapes(kf, N, K, tmp_path_factory, monkeypatch):
     """Shapes outside the ahead-of-time list get kernels built at run time (metran_amd/jit.py:
