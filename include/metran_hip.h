@@ -191,6 +191,28 @@ MK_API int mk_decompose(mk_context *ctx, int64_t B, int64_t RZ, int64_t T, int64
  * objective fed back to the solver; the cross-GPU all-reduce is done by the host with RCCL. */
 MK_API int mk_sum(mk_context *ctx, int64_t count, const double *d_values, double *d_result /* [1] */);
 
+/* ---- observation ingestion (what precedes the filter; batched) ------------------------------ */
+/* Metran.standardize (metran/metran.py:102-121) for R models: per series, subtract the mean and
+ * divide by the standard deviation (pandas semantics: NaN skipped, ddof = 1).  d_in / d_out are
+ * [R,T,N] (or [T,R,N] when time_major != 0); d_out may equal d_in or be NULL (statistics only);
+ * d_mean / d_std [R,N] may be NULL.  N <= 64. */
+MK_API int mk_standardize(mk_context *ctx, int64_t R, int64_t T, int64_t N, int time_major,
+                          const double *d_in, double *d_out, double *d_mean, double *d_std);
+
+/* Metran.mask_observations (metran/metran.py:464-494): d_out[i] = d_mask[i] ? NaN : d_obs[i] for
+ * `count` observations in whatever layout d_obs has (d_mask: one byte each, non-zero = hide).
+ * Unmasking is re-running the filter on the untouched d_obs: no re-upload. */
+MK_API int mk_mask_observations(mk_context *ctx, int64_t count, const double *d_obs,
+                                const unsigned char *d_mask, double *d_out);
+
+/* SPKalmanFilter.set_observations (metran/kalmanfilter.py:646-674) for R models: the reference's
+ * packed arrays from NaN-encoded observations d_obs [R,T,N] (model-major): d_observations [R,T,N]
+ * (missing -> 0.0), d_indices [R,T,N] (doubles holding ints, left-packed), d_count [R,T] (int64).
+ * Any output may be NULL.  The filter kernels read d_obs directly; this exists for callers that
+ * want the reference's representation (the 9-argument engine callable). */
+MK_API int mk_pack_observations(mk_context *ctx, int64_t R, int64_t T, int64_t N, const double *d_obs,
+                                double *d_observations, double *d_indices, int64_t *d_count);
+
 /* ---- instrumentation --------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
 MK_API int mk_enable_timing(mk_context *ctx, int enable);

@@ -98,6 +98,9 @@ API = {
     "mk_decompose": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "mk_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mk_mask_observations": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mk_pack_observations": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_enable_timing": (c_int, [c_void_p, c_int]),
     "mk_last_kernel_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
 }

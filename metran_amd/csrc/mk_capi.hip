@@ -474,6 +474,34 @@ MK_API int mk_sum(mk_context *ctx, int64_t count, const double *v, double *out)
     return MK_OK;
 }
 
+MK_API int mk_standardize(mk_context *ctx, int64_t R, int64_t T, int64_t N, int time_major, const double *in,
+                          double *out, double *mean, double *stdev)
+{
+    MK_CTX(ctx);
+    if (R <= 0 || T <= 0 || N <= 0 || N > 64 || !in) return fail(MK_ERR_INVALID, "mk_standardize: bad argument (1 <= N <= 64)");
+    MK_HIP(mk::launch_standardize(R, T, (int)N, time_major, in, out, mean, stdev, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_mask_observations(mk_context *ctx, int64_t count, const double *obs, const unsigned char *mask,
+                                double *out)
+{
+    MK_CTX(ctx);
+    if (count <= 0 || !obs || !mask || !out) return fail(MK_ERR_INVALID, "mk_mask_observations: bad argument");
+    MK_HIP(mk::launch_mask(count, obs, mask, out, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_pack_observations(mk_context *ctx, int64_t R, int64_t T, int64_t N, const double *obs,
+                                double *observations, double *indices, int64_t *count)
+{
+    MK_CTX(ctx);
+    if (R <= 0 || T <= 0 || N <= 0 || !obs) return fail(MK_ERR_INVALID, "mk_pack_observations: bad argument");
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    MK_HIP(mk::launch_pack(R * T, (int)N, obs, observations, indices, reinterpret_cast<long *>(count), ctx->stream));
+    return MK_OK;
+}
+
 MK_API int mk_enable_timing(mk_context *ctx, int enable)
 {
     MK_CTX(ctx);

@@ -59,5 +59,11 @@ hipError_t launch_simulate(long B, long RZ, long T, int N, int n, const double *
 hipError_t launch_decompose(long B, long RZ, long T, int N, int n, const double *Z, const double *means,
                             double *sdf, double *cdf, hipStream_t s);
 hipError_t launch_sum(long count, const double *v, double *out, hipStream_t s);
+// mk_ingest.hip
+hipError_t launch_standardize(long R, long T, int N, int time_major, const double *in, double *out, double *mean,
+                              double *stdev, hipStream_t s);
+hipError_t launch_mask(long count, const double *obs, const unsigned char *mask, double *out, hipStream_t s);
+hipError_t launch_pack(long RT, int N, const double *obs, double *observations, double *indices, long *count,
+                       hipStream_t s);
 
 } // namespace mk

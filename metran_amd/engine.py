@@ -119,8 +119,77 @@ class BatchedKalman:
         if obs.ndim != 3:
             raise ValueError("observations must be [R,T,N] or [T,N]")
         self.obs = self._layout(self._dev(obs))
+        self._obs_unmasked = None
         self.R, self.T, self.N = (int(s) for s in self.obs.shape)
         return self
+
+    # ------------------------------------------------------------------ ingestion
+    def standardize(self, obs=None):
+        """``Metran.standardize`` (metran/metran.py:102-121) for every record on the device: per series,
+        subtract the mean and divide by the standard deviation (NaN skipped, ddof = 1).  ``obs`` are raw
+        series ``[R,T,N]`` (default: the records already set).  The standardised records become the
+        engine's observations and ``(std, mean)`` its scaling (``set_scaling``), so that
+        ``simulate_smoothed`` returns values in the original units; returns ``(mean, std)`` ``[R,N]``."""
+        torch = _torch()
+        if obs is not None:
+            self.set_observations(obs)
+        if self.obs is None:
+            raise MetranHipError("call set_observations first")
+        if self.N > 64:
+            raise MetranHipError("standardize supports N <= 64 series per model")
+        mean = torch.empty((self.R, self.N), dtype=torch.float64, device=self.device)
+        std = torch.empty_like(mean)
+        self._bind_stream()
+        check(self._L.mk_standardize(self._ctx, self.R, self.T, self.N, int(self.time_major), self._p(self.obs),
+                                     self._p(self.obs), self._p(mean), self._p(std)))
+        self._obs_unmasked = None
+        self.scale, self.offset = std, mean
+        return mean, std
+
+    def mask_observations(self, mask):
+        """``Metran.mask_observations`` (metran/metran.py:464-494): hide the observations where ``mask``
+        ``[R,T,N]`` is non-zero.  The unmasked records stay on the device; ``unmask_observations`` is free."""
+        torch = _torch()
+        if self.obs is None:
+            raise MetranHipError("call set_observations first")
+        base = self._obs_unmasked if getattr(self, "_obs_unmasked", None) is not None else self.obs
+        if not isinstance(mask, torch.Tensor):
+            mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask) != 0).view(np.uint8))
+        mask = (mask != 0).to(device=self.device, dtype=torch.uint8)
+        if mask.ndim == 2:
+            mask = mask[None]
+        if tuple(mask.shape) != (self.R, self.T, self.N):
+            raise ValueError("Dimensions of mask %s do not equal dimensions of series %s"
+                             % (tuple(mask.shape), (self.R, self.T, self.N)))  # metran.py:484-491
+        mask = self._layout(mask)
+        out = torch.empty_like(base)
+        self._bind_stream()
+        check(self._L.mk_mask_observations(self._ctx, int(base.numel()), self._p(base), self._p(mask), self._p(out)))
+        self._obs_unmasked = base
+        self.obs = out
+        return self
+
+    def unmask_observations(self):
+        """``Metran.unmask_observations`` (metran/metran.py:496-506)."""
+        if getattr(self, "_obs_unmasked", None) is not None:
+            self.obs = self._obs_unmasked
+            self._obs_unmasked = None
+        return self
+
+    def pack_observations(self):
+        """``SPKalmanFilter.set_observations`` (metran/kalmanfilter.py:646-674) for every record:
+        ``(observations [R,T,N], observation_indices [R,T,N] float64, observation_count [R,T] int64)``."""
+        torch = _torch()
+        if self.obs is None:
+            raise MetranHipError("call set_observations first")
+        observations = torch.empty_like(self.obs)
+        indices = torch.empty_like(self.obs)
+        count = self._empty_bt(self.R, self.T, dtype=torch.int64)
+        # the kernel walks the R*T rows in memory order, whichever layout that is
+        self._bind_stream()
+        check(self._L.mk_pack_observations(self._ctx, self.R * self.T, 1, self.N, self._p(self.obs),
+                                           self._p(observations), self._p(indices), self._p(count)))
+        return observations, indices, count
 
     def _layout(self, t):
         """Logical ``[B,T,...]`` tensor whose memory follows the engine's layout."""

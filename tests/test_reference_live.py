@@ -57,3 +57,24 @@ def test_install_patches_the_plug_points(metran):
     finally:
         hip.uninstall(metran)
     assert (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother) == orig
+
+
+def test_ingest_matches_reference_metran(metran):
+    """Row f3: metran_amd.ingest on the example CSV files == what Metran.__init__ builds from them
+    (oseries on the daily grid, standardisation, cross-section test)."""
+    import glob
+
+    from metran_amd import ingest
+
+    files = sorted(glob.glob("/root/reference/examples/data/B21B02140*_res.csv"))
+    assert len(files) == 5
+    series = [ingest.read_series_csv(f, name=os.path.basename(f)[:11]) for f in files]
+    mt = metran.Metran([s.copy() for s in series], name="B21B0214")
+    frame, names = ingest.combine_series(series)
+    assert list(names) == list(mt.snames)
+    assert (frame.index == mt.oseries.index).all()
+    sf, std, mean = ingest.standardize(frame)
+    np.testing.assert_array_equal(std, mt.oseries_std)
+    np.testing.assert_array_equal(mean, mt.oseries_mean)
+    np.testing.assert_array_equal(sf.values, mt.oseries.values)
+    assert list(ingest.cross_section_pairs(frame).values) == [343, 332, 332, 332, 331]
