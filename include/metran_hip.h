@@ -164,6 +164,21 @@ MK_API int mk_filter(mk_context *ctx, const mk_problem *prob, const mk_outputs *
  * Metran.get_mle, metran/metran.py:605-622).  d_mle [B] required. */
 MK_API int mk_loglik(mk_context *ctx, const mk_problem *prob, double *d_mle);
 
+/* Objective AND its gradient in two launches (the reference has no gradient: scipy differences P+1
+ * objective evaluations, metran/solver.py:248-255).  Forward: mk_filter writing only the filtered
+ * records into d_work (n_instances*T*mk_record_stride(n) doubles; time_major as in mk_outputs);
+ * backward: the adjoint kernel re-reads them once.  d_gphi / d_gq [B,n] receive
+ * d(-2 log L)/d diag(Phi) and /d diag(Q); d_mle [B], d_sigmacount [B] as in mk_filter; d_status may be
+ * NULL.  N+K <= 16 (MK_ERR_SHAPE otherwise: difference mk_loglik instead). */
+MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *prob, double *d_work, int time_major,
+                          double *d_mle, int64_t *d_sigmacount, double *d_gphi, double *d_gq,
+                          uint32_t *d_status);
+/* Chain rule of mk_params_from_alpha: d/dalpha = (gphi - 2 phi c gq) phi dt / alpha^2, c = 1 - sum_k
+ * loadings^2 for the series, 1 for the factors (metran/metran.py:246-322). */
+MK_API int mk_alpha_grad(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K,
+                         const double *d_alpha /* [B,n] */, const double *d_loadings /* [R,N,K] */,
+                         double dt, const double *d_gphi, const double *d_gq, double *d_galpha /* [B,n] */);
+
 /* kalmansmoother for B instances (kalmanfilter.py:403-476).  Reads out->d_F and out->d_Pf
  * (as written by mk_filter); predicted moments are recomputed from them (Phi diagonal), so
  * d_Xp/d_Pp are not read.  Writes d_S, d_Ps (either may be NULL), d_status. */

@@ -98,6 +98,9 @@ API = {
     "mk_decompose": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "mk_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mk_loglik_grad": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mk_alpha_grad": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double, c_void_p,
+                              c_void_p, c_void_p]),
     "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_mask_observations": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mk_pack_observations": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -28,12 +28,15 @@ class CalibrationResult(dict):
 
 
 def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
-                    ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False):
+                    ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto"):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
     ``ftol = factr*epsmch`` with factr 1e7, ``gtol = pgtol`` on the projected gradient, ``history = m``);
     ``alpha0`` and ``pmin`` are Metran's initial value and lower bound (metran/metran.py:446-462).
+    ``gradient``: "fd" = the reference's forward differences ((n+1)*R filter instances per gradient),
+    "adjoint" = ``BatchedKalman.loglik_grad_alpha`` (one forward + one backward launch over R instances,
+    exact to rounding; state dimension <= 16), "auto" = adjoint where available.
     """
     import torch
 
@@ -46,9 +49,20 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     nfev = launches = 0
     eye = torch.eye(n, **f64) * eps
 
+    if gradient == "auto":
+        gradient = "adjoint" if n <= 16 else "fd"
+    if gradient not in ("fd", "adjoint"):
+        raise ValueError("gradient must be 'auto', 'fd' or 'adjoint'")
+
     def value_and_grad(xc):
-        """f and forward-difference gradient of all R models: ONE launch of (n+1)*R instances."""
+        """f and gradient of all R models: ONE launch of (n+1)*R instances (forward differences) or a
+        forward + a backward launch of R instances (adjoint)."""
         nonlocal nfev, launches
+        if gradient == "adjoint":
+            f, g = kf.loglik_grad_alpha(xc, dt=dt, warmup=warmup)
+            nfev += R
+            launches += 2
+            return f, g
         pts = torch.cat([xc[None], xc[None] + eye[:, None, :]], 0).reshape((n + 1) * R, n)  # instance s*R + r
         phi, q = kf.params_from_alpha(pts, dt=dt)
         f = kf.loglik(phi, q, warmup=warmup).reshape(n + 1, R)

@@ -49,6 +49,7 @@ struct ShapeModule {
     void *handle;
     int (*launch_filter)(const mk::FilterArgs *, void *);
     int (*launch_smoother)(const mk::SmootherArgs *, void *);
+    int (*launch_adjoint)(const mk::AdjointArgs *, void *);
 };
 std::vector<ShapeModule> g_modules;
 std::mutex g_modules_mutex;
@@ -84,6 +85,12 @@ hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s)
     if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_filter(&a, (void *)s);
     return hipErrorInvalidValue;
 }
+hipError_t dispatch_adjoint(int N, int K, const mk::AdjointArgs &a, hipStream_t s)
+{
+    if (aot_shape(N, K)) return mk::launch_adjoint(N, K, a, s);
+    if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_adjoint(&a, (void *)s);
+    return hipErrorInvalidValue;
+}
 hipError_t dispatch_smoother(int N, int K, const mk::SmootherArgs &a, hipStream_t s)
 {
     // the plain smoother depends on n = N + K only; the projecting one needs the exact (N, K)
@@ -105,11 +112,12 @@ MK_API int mk_register_shape_module(const char *path)
     auto shape = (int (*)(int *, int *))dlsym(h, "mkmod_shape");
     auto lf = (int (*)(const mk::FilterArgs *, void *))dlsym(h, "mkmod_launch_filter");
     auto ls = (int (*)(const mk::SmootherArgs *, void *))dlsym(h, "mkmod_launch_smoother");
-    if (!abi || !shape || !lf || !ls) {
+    auto la = (int (*)(const mk::AdjointArgs *, void *))dlsym(h, "mkmod_launch_adjoint");
+    if (!abi || !shape || !lf || !ls || !la) {
         dlclose(h);
         return fail(MK_ERR_INVALID, "%s is not a metran_hip shape module", path);
     }
-    if (abi() != (int)(sizeof(mk::FilterArgs) * 1000 + sizeof(mk::SmootherArgs))) {
+    if (abi() != (int)(sizeof(mk::FilterArgs) * 1000 + sizeof(mk::SmootherArgs) + sizeof(mk::AdjointArgs))) {
         dlclose(h);
         return fail(MK_ERR_INVALID, "%s was built against different kernel-argument structs (stale cache)", path);
     }
@@ -124,7 +132,7 @@ MK_API int mk_register_shape_module(const char *path)
             dlclose(h);
             return MK_OK; // already registered
         }
-    g_modules.push_back(ShapeModule{N, K, h, lf, ls});
+    g_modules.push_back(ShapeModule{N, K, h, lf, ls, la});
     return MK_OK;
 }
 
@@ -471,6 +479,70 @@ MK_API int mk_sum(mk_context *ctx, int64_t count, const double *v, double *out)
     MK_CTX(ctx);
     if (count <= 0 || !v || !out) return fail(MK_ERR_INVALID, "mk_sum: bad argument");
     MK_HIP(mk::launch_sum(count, v, out, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *p, double *d_work, int time_major, double *d_mle,
+                          int64_t *d_sigmacount, double *d_gphi, double *d_gq, uint32_t *d_status)
+{
+    MK_CTX(ctx);
+    if (int rc = check_problem(p)) return rc;
+    if (!d_work || !d_mle || !d_sigmacount || !d_gphi || !d_gq)
+        return fail(MK_ERR_INVALID, "mk_loglik_grad: d_work, d_mle, d_sigmacount, d_gphi and d_gq are required");
+    const int64_t n = p->N + p->K;
+    if (n > 16)
+        return fail(MK_ERR_SHAPE, "mk_loglik_grad: the adjoint kernel covers N+K <= 16 (got %lld); use finite "
+                                        "differences over mk_loglik for wider models", (long long)n);
+    // forward pass: filtered records only (+ per-step bookkeeping in the record pads), objective, step count
+    mk_outputs o;
+    memset(&o, 0, sizeof(o));
+    o.d_mle = d_mle;
+    o.d_sigmacount = d_sigmacount;
+    o.d_status = d_status;
+    o.d_F = d_work;
+    o.d_Pf = d_work + n;
+    o.d_sigmas = d_work + n + n * n;
+    o.d_detfs = o.d_sigmas + 1;
+    o.time_major = time_major;
+    o.record_stride = mk::record_stride((int)n);
+    if (int rc = do_filter(ctx, p, &o)) return rc;
+    mk::AdjointArgs a;
+    a.B = p->n_instances;
+    a.R = p->n_records;
+    a.T = p->T;
+    a.warmup = p->warmup;
+    a.bs = time_major ? 1 : p->T;
+    a.ts = time_major ? p->n_instances : 1;
+    a.rs = o.record_stride;
+    a.obs_bs = p->obs_time_major ? 1 : p->T;
+    a.obs_ts = p->obs_time_major ? p->n_records : 1;
+    a.obs = p->d_obs;
+    a.phi = p->d_phi;
+    a.q = p->d_q;
+    a.loadings = p->d_loadings;
+    a.obsvar = p->d_obsvar;
+    a.x0 = p->d_x0;
+    a.P0 = p->d_P0;
+    a.F = d_work;
+    a.sigmacount = (const long long *)d_sigmacount;
+    a.gphi = d_gphi;
+    a.gq = d_gq;
+    if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    MK_HIP(dispatch_adjoint((int)p->N, (int)p->K, a, ctx->stream));
+    if (ctx->timing) {
+        MK_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->have_smooth_time = true; // reported in the smoother slot of mk_last_kernel_ms
+    }
+    return MK_OK;
+}
+
+MK_API int mk_alpha_grad(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K, const double *alpha,
+                         const double *loadings, double dt, const double *gphi, const double *gq, double *galpha)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || R <= 0 || N <= 0 || K < 0 || !alpha || !loadings || !gphi || !gq || !galpha)
+        return fail(MK_ERR_INVALID, "mk_alpha_grad: bad argument");
+    MK_HIP(mk::launch_alpha_grad(B, R, (int)N, (int)K, alpha, loadings, dt, gphi, gq, galpha, ctx->stream));
     return MK_OK;
 }
 

@@ -47,7 +47,20 @@ struct SmootherArgs {
     unsigned *status;
 };
 
+struct AdjointArgs {
+    long B, R, T, warmup;
+    long bs, ts, rs;     // filtered records: (b, t) at (b*bs + t*ts)*rs doubles, rs = record_stride(n)
+    long obs_bs, obs_ts;
+    const double *obs, *phi, *q, *loadings, *obsvar, *x0, *P0;
+    const double *F;                 // filtered record array written by the forward filter
+    const long long *sigmacount;     // [B] observed steps per instance (forward filter)
+    double *gphi, *gq;               // [B,n] gradient of -2 log L w.r.t. diag(Phi), diag(Q)
+};
+
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);
+hipError_t launch_adjoint(int N, int K, const AdjointArgs &a, hipStream_t s);
+hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,
+                             const double *gphi, const double *gq, double *galpha, hipStream_t s);
 hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s);
 int record_stride(int n); // doubles per packed record for state dimension n
 int num_shapes();

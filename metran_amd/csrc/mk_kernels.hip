@@ -71,6 +71,11 @@ __device__ __forceinline__ void dpp_guard(double (&arr)[n])
     asm volatile("s_nop 1");
 }
 __device__ __forceinline__ void dpp_pin(double &v) { asm volatile("" : "+v"(v)); }
+// two wait states before DPP reads of one or two freshly produced scalars
+__device__ __forceinline__ void dpp_guard1(double &u, double &v)
+{
+    asm volatile("s_nop 1" : "+v"(u), "+v"(v));
+}
 
 template <>
 struct Group<16> {
@@ -1294,6 +1299,208 @@ smoother_wave_kernel(SmootherArgs a)
 }
 
 // =====================================================================================
+// Reverse-mode (adjoint) gradient of the objective -2 log L with respect to diag(Phi) and diag(Q)
+//                                                     ("analytic/adjoint gradient")
+//   The reference gives scipy no gradient (metran/solver.py:248-255): every gradient is P+1 filter runs.
+//   This kernel walks the filter BACKWARDS once.  Per step it re-reads the filtered moments of step t-1
+//   (the packed records written by filter_kernel, OUT = 3), recomputes the prediction and the scalar
+//   updates of step t keeping (d, 1/f, v) of every update, and pulls the adjoints (xb, Pb) of the filtered
+//   state back through them:
+//       update  x' = x + d v/f, P' = P - d d^T/f, l += w (log f + v^2/f), d = P z, f = z^T d + R, v = y - z^T x
+//         a = xb.d   b = Pb d   c = d.b
+//         vb = (2 w v + a)/f      fb = (w (1 - v^2/f) - a v/f + c/f)/f
+//         db = xb v/f - 2 b/f + fb z      xb -= vb z      Pb += (db z^T + z db^T)/2
+//       predict x = phi x-, P = (phi phi^T) o P- + diag(q)
+//         gq += diag(Pb)   gphi_r += xb_r x-_r + 2 sum_c Pb[r][c] P-[r][c] phi_c
+//         xb = phi o xb    Pb = (phi phi^T) o Pb
+//   Lane r owns row r of P and Pb and accumulates the gradient of ITS parameters; the three cross-lane
+//   sums per update and the two matrix-vector products are fused DPP broadcast-FMAs.  One model per
+//   16-lane group (n <= 16); wider models keep the finite-difference path.
+//   Checked against central differences of the oracle and a numpy restatement (tests/adjoint_ref.py).
+// =====================================================================================
+template <int N, int K, int G>
+__global__ void __launch_bounds__(256) adjoint_kernel(AdjointArgs a)
+{
+    constexpr int n = N + K;
+    static_assert(G == 16 && n <= 16, "adjoint kernel: one model per 16-lane group");
+    using Gp = Group<G>;
+    constexpr int GPB = 256 / G;
+    constexpr bool HOIST = (N * K <= 32);
+    const int lane = threadIdx.x % G;
+    long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1;
+    const long rec = inst % a.R;
+    const int r = lane < n ? lane : n - 1;
+    const long T = a.T;
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+    double pp[n]; // row r of Phi (x) Phi
+    sfor<0, n>(MK_LAMBDA(c) { pp[decltype(c)::value] = phi_r * Gp::template bcast<decltype(c)::value>(phi_r); });
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
+    const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
+    double Gh[HOIST ? N : 1][K];
+    if constexpr (HOIST) {
+        sfor<0, N>(MK_LAMBDA(j) {
+            sfor<0, K>(MK_LAMBDA(k) {
+                Gh[decltype(j)::value][decltype(k)::value] = Gp::template bcast<decltype(j)::value>(gam[decltype(k)::value]);
+            });
+        });
+    }
+    const long sctot = a.sigmacount[inst]; // observed steps in total (written by the forward filter)
+    long rem = 0;                          // observed steps already walked (from the end)
+    const double one = 1.0;
+
+    const long RS = a.rs;
+    const double *recbase = a.F + inst * a.bs * RS;
+    const long rstep = a.ts * RS;
+    const double *obase = a.obs + rec * a.obs_bs * N + jr;
+    const long ostep = a.obs_ts * N;
+
+    auto load_prev = [&](long t, double &xv, double(&row)[n]) __attribute__((always_inline)) {
+        if (t > 0) { // filtered moments of step t-1: vector at [r], matrix as column runs
+            const double *p = recbase + (t - 1) * rstep;
+            xv = p[r];
+            load_cols<n>(p + n + r, row);
+        } else { // run_filter defaults (kalmanfilter.py:747-750) or the caller's initial state
+            xv = a.x0 ? a.x0[inst * n + r] : 0.0;
+#pragma unroll
+            for (int c = 0; c < n; ++c) row[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
+        }
+    };
+
+    double xb = 0.0, Pb[n], gphi = 0.0, gq = 0.0;
+#pragma unroll
+    for (int c = 0; c < n; ++c) Pb[c] = 0.0;
+    double xnext, Pnext[n], ynext;
+    load_prev(T - 1, xnext, Pnext);
+    ynext = obase[(T - 1) * ostep];
+
+    for (long t = T - 1; t >= 0; --t) {
+        const double xprev = xnext, y = ynext;
+        double Pprev[n];
+#pragma unroll
+        for (int c = 0; c < n; ++c) Pprev[c] = Pnext[c];
+        if (t > 0) { // one step ahead; this loop stores nothing, so the loads never queue behind stores
+            load_prev(t - 1, xnext, Pnext);
+            ynext = obase[(t - 1) * ostep];
+        }
+        const unsigned long long ball = __ballot(lane < N && isfinite(y));
+        const auto vm = Gp::group_bits(ball);
+
+        if (vm != 0) { // uniform within the lane group
+            const double w = (sctot - rem - 1 >= a.warmup) ? 1.0 : 0.0; // compressed index of this step (:563-564)
+            ++rem;
+            // ---- forward: prediction and scalar updates of step t, as filter_kernel ----
+            double x = phi_r * xprev, P[n];
+            int rv = r; // opaque copies: the n selects stay inside the loop instead of 2n hoisted VGPRs
+            double qv = q_r;
+            asm volatile("" : "+v"(rv), "+v"(qv));
+#pragma unroll
+            for (int c = 0; c < n; ++c) P[c] = fma(Pprev[c], pp[c], c == rv ? qv : 0.0);
+            double dS[N], rfS[N], vS[N];
+            sfor<0, N>(MK_LAMBDA(jc) {
+                constexpr int j = decltype(jc)::value;
+                dS[j] = rfS[j] = vS[j] = 0.0;
+                if ((vm >> j) & 1) {
+                    double vl = y - x;
+                    sfor<0, K>(MK_LAMBDA(k) { Gp::template fmac<N + decltype(k)::value, true>(vl, x, gam[decltype(k)::value]); });
+                    const double v = Gp::template bcast<j>(vl);
+                    double dr = P[j];
+                    sfor<0, K>(MK_LAMBDA(k) {
+                        constexpr int kk = decltype(k)::value;
+                        double g;
+                        if constexpr (HOIST) g = Gh[j][kk];
+                        else g = Gp::template bcast<j>(gam[kk]);
+                        dr = fma(P[N + kk], g, dr);
+                    });
+                    double fl = rvar + dr;
+                    dpp_pin(dr);
+                    sfor<0, K>(MK_LAMBDA(k) { Gp::template fmac<N + decltype(k)::value, false>(fl, dr, gam[decltype(k)::value]); });
+                    const double f = Gp::template bcast<j>(fl);
+                    const double rf = rcp_nr(f);
+                    const double kr = dr * rf;
+                    Gp::template axpy_col<0, n, true, n>(P, dr, kr);
+                    x = fma(kr, v, x);
+                    dS[j] = dr;
+                    rfS[j] = rf;
+                    vS[j] = v;
+                }
+            });
+            // ---- reverse: adjoints back through the updates, last observation first ----
+            sfor_down<0, N>(MK_LAMBDA(jc) {
+                constexpr int j = decltype(jc)::value;
+                if ((vm >> j) & 1) {
+                    double dr = dS[j];
+                    const double rf = rfS[j], v = vS[j];
+                    double pa = xb * dr;
+                    dpp_guard1(pa, dr);
+                    double asum = 0.0, b0 = 0.0, b1 = 0.0;
+                    sfor<0, n>(MK_LAMBDA(cc) {
+                        constexpr int c = decltype(cc)::value;
+                        Gp::template fmac<c, false>(asum, pa, one);                    // a = sum_r xb_r d_r
+                        if constexpr (c % 2 == 0) Gp::template fmac<c, false>(b0, dr, Pb[c]); // b_r = sum_c Pb[r][c] d_c
+                        else Gp::template fmac<c, false>(b1, dr, Pb[c]);
+                    });
+                    const double b = b0 + b1;
+                    double ps = dr * b;
+                    dpp_guard1(ps, ps);
+                    double csum = 0.0;
+                    sfor<0, n>(MK_LAMBDA(cc) { Gp::template fmac<decltype(cc)::value, false>(csum, ps, one); });
+                    const double vrf = v * rf;
+                    const double vbar = fma(2.0 * w, v, asum) * rf;
+                    const double fbar = (fma(-w * v, vrf, w) - asum * vrf + csum * rf) * rf;
+                    double zr = (r == j) ? 1.0 : 0.0; // element r of Z_j = e_j + sum_k loadings[j,k] e_{N+k}
+                    sfor<0, K>(MK_LAMBDA(k) {
+                        constexpr int kk = decltype(k)::value;
+                        double g;
+                        if constexpr (HOIST) g = Gh[j][kk];
+                        else g = Gp::template bcast<j>(gam[kk]);
+                        zr = (r == N + kk) ? g : zr;
+                    });
+                    double dbar = fma(xb, vrf, fma(-2.0 * rf, b, fbar * zr));
+                    xb = fma(-vbar, zr, xb);
+                    const double hd = 0.5 * dbar, hz = 0.5 * zr;
+                    Pb[j] += hd;
+                    sfor<0, K>(MK_LAMBDA(k) {
+                        constexpr int kk = decltype(k)::value;
+                        double g;
+                        if constexpr (HOIST) g = Gh[j][kk];
+                        else g = Gp::template bcast<j>(gam[kk]);
+                        Pb[N + kk] = fma(hd, g, Pb[N + kk]);
+                    });
+                    dpp_guard1(dbar, dbar);
+                    Gp::template axpy_col<0, n, false, n>(Pb, dbar, hz); // Pb[r][c] += z_r db_c / 2
+                }
+            });
+        }
+        // ---- prediction adjoint ----
+        double diag = 0.0, ts0 = 0.0, ts1 = 0.0;
+        double phv = phi_r;
+        dpp_pin(phv);
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            diag = (c == r) ? Pb[c] : diag;
+            const double pbp = Pb[c] * Pprev[c];
+            if constexpr (c % 2 == 0) Gp::template fmac<c, false>(ts0, phv, pbp); // += phi_c Pb[r][c] P-[r][c]
+            else Gp::template fmac<c, false>(ts1, phv, pbp);
+            Pb[c] *= pp[c];
+        });
+        gq += diag;
+        gphi = fma(xb, xprev, fma(2.0, ts0 + ts1, gphi));
+        xb *= phi_r;
+    }
+    if (live && lane < n) {
+        if (a.gphi) a.gphi[inst * n + lane] = gphi;
+        if (a.gq) a.gq[inst * n + lane] = gq;
+    }
+}
+
+// =====================================================================================
 // Small helper kernels
 // =====================================================================================
 // Metran._phi / get_transition_matrix / get_transition_covariance diagonals (metran.py:246-322)
@@ -1460,7 +1667,13 @@ void get_shape(int i, int *N, int *K);
 // specialising per shape is what makes them fast; this is how an arbitrary Metran model gets one.
 // ---------------------------------------------------------------------------------------------
 extern "C" {
-MK_API int mkmod_abi(void) { return (int)(sizeof(FilterArgs) * 1000 + sizeof(SmootherArgs)); }
+MK_API int mkmod_abi(void) { return (int)(sizeof(FilterArgs) * 1000 + sizeof(SmootherArgs) + sizeof(AdjointArgs)); }
+MK_API int mkmod_launch_adjoint(const AdjointArgs *a, void *stream)
+{
+    int N, K;
+    get_shape(0, &N, &K);
+    return (int)launch_adjoint(N, K, *a, (hipStream_t)stream);
+}
 MK_API int mkmod_shape(int *N, int *K)
 {
     get_shape(0, N, K);
@@ -1516,6 +1729,53 @@ hipError_t launch_decompose(long B, long RZ, long T, int N, int n, const double 
     const long tot = B * T * N;
     hipLaunchKernelGGL(decompose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, B, RZ, T, N, n, Z,
                        means, sdf, cdf);
+    return hipGetLastError();
+}
+
+template <int N, int K>
+static hipError_t launch_adjoint_nk(const AdjointArgs &a, hipStream_t s)
+{
+    constexpr int n = N + K;
+    if constexpr (n <= 16) {
+        constexpr int GPB = 256 / 16;
+        hipLaunchKernelGGL((adjoint_kernel<N, K, 16>), dim3((unsigned)((a.B + GPB - 1) / GPB)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported; // wide models keep the finite-difference gradient
+    }
+}
+#define MK_CASE_ADJOINT(NN, KK) \
+    if (N == NN && K == KK) return launch_adjoint_nk<NN, KK>(a, s);
+hipError_t launch_adjoint(int N, int K, const AdjointArgs &a, hipStream_t s)
+{
+    MK_SHAPES(MK_CASE_ADJOINT)
+    return hipErrorInvalidValue;
+}
+
+// chain rule of Metran._phi / get_transition_covariance (metran.py:246-322):
+//   phi = exp(-dt/alpha), q = (1 - phi^2) c  =>  d/dalpha = (gphi - 2 phi c gq) phi dt / alpha^2
+__global__ void alpha_grad_kernel(long B, long R, int N, int K, const double *alpha, const double *loadings,
+                                  double dt, const double *gphi, const double *gq, double *galpha)
+{
+    const int n = N + K;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n) return;
+    const long b = i / n;
+    const int s = (int)(i % n);
+    const double al = alpha[i], ph = exp(-dt / al);
+    double c = 1.0;
+    if (s < N) {
+        const double *g = loadings + ((b % R) * N + s) * K;
+        for (int k = 0; k < K; ++k) c -= g[k] * g[k];
+    }
+    galpha[i] = (gphi[i] - 2.0 * ph * c * gq[i]) * ph * dt / (al * al);
+}
+hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,
+                             const double *gphi, const double *gq, double *galpha, hipStream_t s)
+{
+    const long tot = B * (N + K);
+    hipLaunchKernelGGL(alpha_grad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, B, R, N, K, alpha,
+                       loadings, dt, gphi, gq, galpha);
     return hipGetLastError();
 }
 

@@ -286,6 +286,41 @@ class BatchedKalman:
         check(self._L.mk_loglik(self._ctx, ctypes.byref(prob), self._p(mle)))
         return mle
 
+    def loglik_grad(self, phi, q, warmup=1, x0=None, P0=None):
+        """Objective and its ADJOINT gradient: ``(mle [B], gphi [B,n], gq [B,n])`` with
+        ``gphi = d(-2 log L)/d phi``, ``gq = d(-2 log L)/d q`` in two launches (forward filter writing the
+        filtered records into a workspace that is kept between calls, then the backward adjoint kernel).
+        The reference has no gradient (metran/solver.py:248-255 leaves scipy to difference P+1 runs).
+        State dimension n <= 16; wider models raise (difference ``loglik`` instead)."""
+        torch = _torch()
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        need = B * self.T * self.record_stride()
+        work = getattr(self, "_grad_work", None)
+        if work is None or work.numel() < need:
+            self._grad_work = work = torch.empty(need, dtype=torch.float64, device=self.device)
+        mle = torch.empty(B, dtype=torch.float64, device=self.device)
+        sc = torch.empty(B, dtype=torch.int64, device=self.device)
+        gphi = torch.empty((B, self.n), dtype=torch.float64, device=self.device)
+        gq = torch.empty_like(gphi)
+        self._bind_stream()
+        check(self._L.mk_loglik_grad(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
+                                     self._p(mle), self._p(sc), self._p(gphi), self._p(gq), None))
+        return mle, gphi, gq
+
+    def loglik_grad_alpha(self, alpha, dt=1.0, warmup=1):
+        """``(mle [B], d mle / d alpha [B,n])`` for Metran's parametrisation (``params_from_alpha`` forward,
+        ``mk_alpha_grad`` chain rule backward)."""
+        torch = _torch()
+        alpha = self._dev(alpha)
+        if alpha.ndim == 1:
+            alpha = alpha[None]
+        phi, q = self.params_from_alpha(alpha, dt=dt)
+        mle, gphi, gq = self.loglik_grad(phi, q, warmup=warmup)
+        galpha = torch.empty_like(gphi)
+        check(self._L.mk_alpha_grad(self._ctx, int(alpha.shape[0]), self.R, self.N, self.K, self._p(alpha),
+                                    self._p(self.loadings), float(dt), self._p(gphi), self._p(gq), self._p(galpha)))
+        return mle, galpha
+
     def record_stride(self):
         """Doubles per packed (model, step) record for this state dimension (C ABI ``mk_record_stride``)."""
         return int(self._L.mk_record_stride(self.n))

@@ -1,0 +1,94 @@
+"""Adjoint gradient of -2 log L ("analytic/adjoint gradient").  The reference has no
+gradient; the bar is agreement with central differences of the ORACLE's objective (restating
+metran/kalmanfilter.py:236-400, 550-567) and with the numpy restatement of the backward pass."""
+import numpy as np
+import pytest
+
+import adjoint_ref
+import oracle
+from metran_amd.params import phi_q_from_alpha
+from metran_amd.synthetic import make_dfm, make_dfm_batch
+
+
+def _oracle_mle(y, phi, q, G):
+    return float(oracle.dfm_batch(y[None], phi[None], q[None], G[None], smooth=False, outputs="mle")["mle"][0])
+
+
+def test_numpy_adjoint_matches_central_differences_of_the_oracle():
+    for seed, (N, K, T, miss, first) in enumerate([(5, 2, 60, 0.25, "random"), (3, 1, 40, 0.0, "full"), (4, 1, 50, 0.5, "empty")]):
+        y, alpha, G, phi, q = make_dfm(N, K, T, 40 + seed, 0, miss, first)
+        mle, gphi, gq = adjoint_ref.gradient(y, phi, q, G)
+        assert abs(mle - _oracle_mle(y, phi, q, G)) <= 1e-10 * abs(mle)
+        for i in range(N + K):
+            for vec, g in ((phi, gphi), (q, gq)):
+                h = 1e-6
+                p = vec.copy(); p[i] += h
+                a = _oracle_mle(y, p if vec is phi else phi, p if vec is q else q, G)
+                p = vec.copy(); p[i] -= h
+                b = _oracle_mle(y, p if vec is phi else phi, p if vec is q else q, G)
+                fd = (a - b) / (2 * h)
+                assert abs(g[i] - fd) <= 2e-6 * max(1.0, abs(fd)), (seed, i, g[i], fd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["model_major", "time_major"])
+@pytest.mark.parametrize("N,K,T,B,missing,first", [(8, 2, 120, 37, 0.0, "full"), (8, 2, 90, 21, 0.3, "random"),
+                                                   (5, 1, 70, 19, 0.2, "empty"), (2, 1, 60, 5, 0.1, "random"),
+                                                   (6, 2, 50, 8, 0.4, "random")])
+def test_hip_adjoint_gradient(layout, N, K, T, B, missing, first):
+    from metran_amd.engine import BatchedKalman
+
+    d = make_dfm_batch(B, N, K, T, seed=500 + N, missing=missing, first_step=first)
+    kf = BatchedKalman(0, layout=layout)
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    mle, gphi, gq = (t.cpu().numpy() for t in kf.loglik_grad(d["phi"], d["q"]))
+    ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"], smooth=False, outputs="mle")["mle"]
+    np.testing.assert_allclose(mle, ref, rtol=1e-11)
+    for b in range(B):
+        _, rp, rq = adjoint_ref.gradient(d["obs"][b], d["phi"][b], d["q"][b], d["loadings"][b])
+        np.testing.assert_allclose(gphi[b], rp, rtol=1e-9, atol=1e-9 * np.abs(rp).max())
+        np.testing.assert_allclose(gq[b], rq, rtol=1e-9, atol=1e-9 * np.abs(rq).max())
+    # chain rule to alpha vs central differences of the oracle through the reference parametrisation
+    mle2, galpha = (t.cpu().numpy() for t in kf.loglik_grad_alpha(d["alpha"]))
+    np.testing.assert_allclose(mle2, ref, rtol=1e-11)
+    for b in (0, B - 1):
+        for i in range(N + K):
+            h = 1e-5 * d["alpha"][b, i]
+            vals = []
+            for sgn in (+1, -1):
+                al = d["alpha"][b].copy()
+                al[i] += sgn * h
+                ph, qq = phi_q_from_alpha(al, d["loadings"][b])
+                vals.append(_oracle_mle(d["obs"][b], ph, qq, d["loadings"][b]))
+            fd = (vals[0] - vals[1]) / (2 * h)
+            assert abs(galpha[b, i] - fd) <= 1e-5 * max(1e-3, abs(fd)), (b, i, galpha[b, i], fd)
+
+
+@pytest.mark.gpu
+def test_adjoint_rejects_wide_models():
+    from metran_amd._lib import MetranHipError
+    from metran_amd.engine import BatchedKalman
+
+    d = make_dfm_batch(2, 14, 3, 20, seed=1)
+    kf = BatchedKalman(0).set_observations(d["obs"]).set_loadings(d["loadings"])
+    with pytest.raises(MetranHipError, match="N\\+K <= 16"):
+        kf.loglik_grad(d["phi"], d["q"])
+
+
+@pytest.mark.gpu
+def test_adjoint_at_the_lower_bound():
+    """alpha at Metran's lower bound 1e-5 (metran/metran.py:446-462) underflows phi to 0: the gradient stays
+    finite and the components of those parameters vanish with d phi / d alpha."""
+    from metran_amd.engine import BatchedKalman
+
+    d = make_dfm_batch(6, 8, 2, 80, seed=77, missing=0.2)
+    alpha = d["alpha"].copy()
+    alpha[:, 0] = 1e-5
+    alpha[2, 9] = 1e-5
+    kf = BatchedKalman(0).set_observations(d["obs"]).set_loadings(d["loadings"])
+    mle, g = (t.cpu().numpy() for t in kf.loglik_grad_alpha(alpha))
+    assert np.isfinite(mle).all() and np.isfinite(g).all()
+    assert not g[:, 0].any() and g[2, 9] == 0.0 and np.abs(g[:, 1:9]).min() > 0
+    for b in (0, 2):
+        ph, qq = phi_q_from_alpha(alpha[b], d["loadings"][b])
+        assert abs(mle[b] - _oracle_mle(d["obs"][b], ph, qq, d["loadings"][b])) <= 1e-10 * abs(mle[b])
