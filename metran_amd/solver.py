@@ -62,6 +62,16 @@ class BatchObjective:
         self.launches += 1
         return mle.cpu().numpy()
 
+    def value_and_grad(self, x):
+        """One parameter vector (caller's order) -> (f, df/dx) by the adjoint kernel."""
+        x = np.asarray(x, dtype=np.float64)
+        mle, galpha = self.kf.loglik_grad_alpha(x[self.order][None], dt=self.dt, warmup=self.warmup)
+        g = np.zeros_like(x)
+        g[self.order] = galpha[0].cpu().numpy()
+        self.nfev += 1
+        self.launches += 2
+        return float(mle[0]), g
+
 
 def _state_order(mt):
     """Position of each state's alpha in ``mt.parameters`` (name look-up as in metran.py:283-290)."""
@@ -92,7 +102,13 @@ class HipSolve:
 
     _name = "HipSolve"
 
-    def __init__(self, mt, **kwargs):
+    def __init__(self, mt, gradient="fd", **kwargs):
+        """``gradient="fd"`` (default) follows the reference's finite-difference path; ``"adjoint"`` hands
+        scipy the exact gradient from ``mk_loglik_grad`` (state dimension <= 16): the same optimum in ~6x
+        fewer filter runs, but not the reference's iteration path."""
+        if gradient not in ("fd", "adjoint"):
+            raise ValueError("gradient must be 'fd' or 'adjoint'")
+        self.gradient = gradient
         self.mt = mt
         self.pcov = None
         self.pcor = None
@@ -126,6 +142,10 @@ class HipSolve:
         """f(x) and scipy's 2-point forward-difference gradient from ONE launch of P+1 instances."""
         x = np.asarray(x, dtype=np.float64)
         P = x.size
+        if self.gradient == "adjoint":
+            obj = self._objective()
+            f, g = obj.value_and_grad(self._array_todict(x).astype(np.float64))
+            return f, g[np.nonzero(self.vary)[0]]
         h = np.full(P, eps)
         h[np.isfinite(ub) & (x + h > ub)] = -eps  # scipy flips the step at an upper bound
         full = np.tile(self._array_todict(x).astype(np.float64), (P + 1, 1))
