@@ -205,6 +205,24 @@ def test_full_size_properties(kf):
     assert float((zx - d["obs"]).abs().max()) < 1e-9
 
 
+@pytest.mark.parametrize("B,N,K,T", [(1, 2, 1, 1), (3, 2, 1, 1), (17, 3, 1, 2), (5, 8, 2, 3), (2, 32, 4, 1)])
+def test_degenerate_sizes(kf, B, N, K, T):
+    """One- and two-step records, a batch that does not fill a workgroup, and a record with no observation
+    at all (sigmacount 0, objective 0): every output equals the oracle's."""
+    d = make_dfm_batch(B, N, K, T, seed=9)
+    d["obs"][0, :, :] = np.nan
+    ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    r = kf.filter_smooth(d["phi"], d["q"])
+    np.testing.assert_array_equal(_np(r["sigmacount"]), ref["sigmacount"])
+    np.testing.assert_allclose(_np(r["mle"]), ref["mle"], rtol=MLE_RTOL, atol=1e-12)
+    assert float(_np(r["mle"])[0]) == 0.0
+    for k, tol in (("F", FILT_ATOL), ("Pf", FILT_ATOL), ("Xp", FILT_ATOL), ("Pp", FILT_ATOL), ("S", SMOOTH_ATOL),
+                   ("Ps", SMOOTH_ATOL)):
+        np.testing.assert_allclose(_np(r[k]), ref[k], rtol=0, atol=tol)
+    np.testing.assert_allclose(_np(kf.loglik(d["phi"], d["q"])), ref["mle"], rtol=MLE_RTOL, atol=1e-12)
+
+
 def test_full_size_c4_projection(kf):
     """BASELINE configs[3] size (B=4096, 32 series / 4 factors, 30 % missing, T=2000).  Three full state
     records per step would be 264 GB; the fused projection path keeps one (88 GB) and emits what
