@@ -91,3 +91,15 @@ class ShardedObjective:
         vals = self.local_loglik(params)
         total = self.local_sum(vals).reshape(1).clone()
         return allreduce_sum(total)[0]
+
+    def value_and_grad(self, params, local_value_and_grad):
+        """Summed objective AND its gradient with respect to the SHARED parameters:
+        ``local_value_and_grad(params) -> (values [b], grads [b,P])`` for this rank's models (on the GPU:
+        ``BatchedKalman.loglik_grad_alpha``, the adjoint kernel); the local sums of both ride in ONE
+        all-reduce of P+1 float64.  Returns ``(total, grad [P])``, identical on every rank."""
+        import torch
+
+        vals, grads = local_value_and_grad(params)
+        packed = torch.cat([self.local_sum(vals).reshape(1), grads.sum(0).reshape(-1)]).clone()
+        allreduce_sum(packed)
+        return packed[0], packed[1:]

@@ -48,6 +48,23 @@ def _worker(rank, world, port, out_dir):
     total = float(obj(alpha))
     allv = gather_concat(local_loglik(alpha))
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.r_[total, allv.numpy()])
+
+    # objective + gradient w.r.t. the shared parameters in one all-reduce of P+1 doubles; the local gradient
+    # that the GPU gets from the adjoint kernel is its numpy restatement here
+    import adjoint_ref
+
+    def local_value_and_grad(alpha_shared):
+        vals, grads = [], []
+        for b in range(hi - lo):
+            ph, qq = phi_q_from_alpha(alpha_shared, d["loadings"][b])
+            m, gp, gq = adjoint_ref.gradient(d["obs"][b], ph, qq, d["loadings"][b])
+            c = np.r_[1.0 - (d["loadings"][b] ** 2).sum(1), np.ones(K)]
+            vals.append(m)
+            grads.append((gp - 2.0 * ph * c * gq) * ph / alpha_shared ** 2)
+        return torch.tensor(vals), torch.tensor(np.array(grads))
+
+    tot, grad = obj.value_and_grad(alpha, local_value_and_grad)
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), np.r_[float(tot), grad.numpy()])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,3 +88,18 @@ def test_sharded_objective_world2(tmp_path):
     assert abs(r0[0] - ref.sum()) <= 1e-12 * abs(ref.sum())  # sharding invariance of the objective
     np.testing.assert_array_equal(r0[1:], ref)              # rank-order concatenation = batch order
     np.testing.assert_array_equal(r1[1:], ref)
+    # summed objective and gradient: identical on both ranks, equal to central differences of the full sum
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    np.testing.assert_array_equal(g0, g1)
+    assert abs(g0[0] - ref.sum()) <= 1e-10 * abs(ref.sum())
+
+    def total(a):
+        ph, qq = phi_q_from_alpha(np.broadcast_to(a, (B, N + K)), d["loadings"])
+        return oracle.dfm_batch(d["obs"], ph, qq, d["loadings"], smooth=False, outputs="mle")["mle"].sum()
+
+    for i in range(N + K):
+        h = 1e-5 * alpha[i]
+        e = np.zeros(N + K)
+        e[i] = h
+        fd = (total(alpha + e) - total(alpha - e)) / (2 * h)
+        assert abs(g0[1 + i] - fd) <= 1e-5 * max(1e-3, abs(fd))
