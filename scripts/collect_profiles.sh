@@ -4,7 +4,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof; mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $CMD > $OUT/bench_kt.log 2>&1
 cp /tmp/kt/*/*kernel_stats.csv $OUT/kernel_stats_full.csv
 head -1 $OUT/kernel_stats_full.csv > $OUT/kernel_stats.csv; grep "mk::" $OUT/kernel_stats_full.csv >> $OUT/kernel_stats.csv; rm $OUT/kernel_stats_full.csv
