@@ -452,16 +452,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     // (lane l loads the N values of step t0 + l), one tile ahead of use, parked in LDS, and the
     // per-step value comes from LDS (lgkmcnt, independent of the store queue).
     constexpr int TS = 16;
-    // a tile is requested OLEAD steps before it is parked: long enough for the older stores to be
-    // acknowledged, short enough that the younger vector-memory operations still fit the 6-bit vmcnt
-    // (beyond 63 the compiler can only wait for vmcnt(0), i.e. drain every store)
-    constexpr int OLEAD = 2;
+    // The time loop is a nest: tile t0 is parked (registers -> LDS) and the loads of tile t0 + TS are issued
+    // at the top of the OUTER iteration, so they are in flight for the 16 steps of the inner loop and no
+    // load result is carried through a conditional inside it.  (An earlier version issued the tile two
+    // steps before parking it from inside a single loop: the phi copies of the staging registers on the
+    // 14 other steps each came with an `s_waitcnt vmcnt(0)` -- a full drain of the store queue EVERY step,
+    // 23 % of the filter's cycles in SQ_WAIT_INST_ANY.)
     const int lrow = lane < TS ? lane : TS - 1; // lanes >= TS (G = 64) duplicate row TS-1
     constexpr bool OV2 = (N % 2 == 0);          // 16-byte row pieces when rows are 16-byte aligned
     constexpr int ONC = OV2 ? N / 2 : N;
     using ochunk_t = typename std::conditional<OV2, v2d, double>::type;
-    __shared__ __attribute__((aligned(16))) double lds_obs[(256 / G) * 2 * TS * N];
-    double *otile = lds_obs + (threadIdx.x / G) * 2 * TS * N; // this model's two tiles
+    __shared__ __attribute__((aligned(16))) double lds_obs[(256 / G) * TS * N];
+    double *otile = lds_obs + (threadIdx.x / G) * TS * N; // this model's tile
     const double *obase = a.obs + rec * a.obs_bs * N;
     const long ostep = a.obs_ts * N;
     ochunk_t oreg[WIDE ? 1 : ONC];
@@ -479,8 +481,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             for (int i = 0; i < ONC; ++i) oreg[i] = src[i];
         }
     };
-    auto obs_park = [&](int buf) __attribute__((always_inline)) { // registers -> LDS tile `buf`
-        ochunk_t *dst = reinterpret_cast<ochunk_t *>(otile + (buf * TS + lrow) * N);
+    auto obs_park = [&]() __attribute__((always_inline)) { // registers -> the LDS tile
+        ochunk_t *dst = reinterpret_cast<ochunk_t *>(otile + lrow * N);
+        wave_lds_sync(); // the previous tile's reads are complete
         if constexpr (WIDE) {
             const ochunk_t *src = reinterpret_cast<const ochunk_t *>(obase + otr * ostep);
 #pragma unroll
@@ -492,9 +495,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
         wave_lds_sync();
     };
     obs_issue(0);
-    obs_park(0);
-    if (TS - OLEAD <= 0) obs_issue(TS);
-    double ynext = otile[jr]; // y of step 0 for series jr
+    double ynext = 0.0;
 
     double sum_sig = 0.0, sum_det = 0.0;
     double run_mant = 1.0; // !BOOK: prod of f over the counted steps, normalised
@@ -502,13 +503,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     long nobs = 0, sc = 0;
     double fmin_seen = 1.0;
 
-    for (long t = 0; t < T; ++t) {
+    for (long t0 = 0; t0 < T; t0 += TS) {
+    obs_park();           // tile t0: loads issued one outer iteration (16 steps) ago
+    obs_issue(t0 + TS);   // tile t0 + TS (rows clamped to T-1)
+    ynext = otile[jr];
+    const long tend = t0 + TS < T ? t0 + TS : T;
+    for (long t = t0; t < tend; ++t) {
         const double y = ynext;
         {
-            const long t1 = t + 1; // read next step's observation from LDS now (latency hidden by this step)
-            if ((t1 & (TS - 1)) == TS - OLEAD) obs_issue((t1 & ~(long)(TS - 1)) + TS); // request the next tile
-            if ((t1 & (TS - 1)) == 0) obs_park((int)((t1 / TS) & 1));                   // ... and park it
-            ynext = otile[(((t1 / TS) & 1) * TS + (t1 & (TS - 1))) * N + jr];
+            // next step's observation from LDS now (latency hidden by this step); the last step of a tile
+            // re-reads its own row, the outer loop supplies the next tile's first
+            const int s1 = (int)(t - t0) + 1;
+            ynext = otile[(s1 < TS ? s1 : TS - 1) * N + jr];
         }
         // which series are observed at this step (NaN / inf = missing, kalmanfilter.py:657)
         const unsigned long long ball = __ballot(lane < N && isfinite(y));
@@ -653,6 +659,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             if (oF.mat) store_cols<n>(oF.mat, P);
             oF.advance(1);
         }
+    }
     }
 
     // zero tail of the compressed arrays (np.zeros init, :307-308); record pads were written as zeros
