@@ -949,19 +949,22 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
 #pragma unroll
         for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
 
-        // mid-iteration: transpose the chunks of step t-1 into rows (LDS latency hides behind the
-        // sweep below) and issue the HBM loads of step t-2
-        double xf_next = xfn;
-        if (t >= 1) {
-            finish(xf_next, Pfc);
-            if (t >= 2) issue(xfn);
-        }
-
         // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
         sfor<0, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value;
             Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
         });
+
+        // Consume the chunks of step t-1 (requested 1.5 iterations ago) and request those of step t-2 BEFORE
+        // this iteration's stores are issued.  Loads and stores share vmcnt and complete out of order with
+        // respect to each other, so the compiler waits for vmcnt(0) whenever both are pending: consumed in
+        // mid-iteration (as before) that drained the stores issued half an iteration earlier; here every
+        // pending operation is at least one full iteration old.
+        double xf_next = xfn;
+        if (t >= 1) {
+            finish(xf_next, Pfc);
+            if (t >= 2) issue(xfn);
+        }
 
         store(xs, Psn);
         xfc = xf_next;
