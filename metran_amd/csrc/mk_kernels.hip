@@ -375,6 +375,14 @@ constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 //   BOOK : per-step sigmas/detfs are written (needs one log per step); otherwise the
 //          log-determinant is accumulated as a normalised product with ONE log at the end
 // =====================================================================================
+template <int n, int G>
+struct RecordIO;
+// packed records of the 16-lane kernels leave through wave-private LDS images as whole 16-byte chunks
+// (8 global_store_dwordx4 per step instead of 24 column-run dwordx2 stores: 1.52 -> 1.47 ms at B=4096)
+#ifndef MK_FILTER_LDS_STORES
+#define MK_FILTER_LDS_STORES 1
+#endif
+
 template <int N, int K, int G, int OUT, bool BOOK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 ? 2 : 1))) filter_kernel(FilterArgs a)
 {
@@ -443,6 +451,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     const int pslot = lane < PADN ? lane : PADN - 1;
     double *padF = RECF ? a.F + inst * a.bs * RS + NV + pslot : nullptr;
     double *padP = OUT == 1 ? a.Xp + inst * a.bs * RS + NV + pslot : nullptr;
+    // records leave through wave-private LDS images as whole 16-byte chunks (as in the smoother)
+    constexpr bool LDSOUT = MK_FILTER_LDS_STORES && RECF && G == 16;
+    using RIO = RecordIO<n, G>;
+    __shared__ __attribute__((aligned(16))) double lds_rec[LDSOUT ? 4 * 2 * RIO::LDS_PER_WAVE : 1];
+    double *imgP = lds_rec + (LDSOUT ? (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE : 0);
+    double *imgF = imgP + (LDSOUT ? RIO::LDS_PER_WAVE : 0);
+    const int lane64 = threadIdx.x & 63, gw = lane64 / G;
+    typename RIO::Map rmap;
+    double *recP = a.Xp, *recF = a.F;
+    const long rstep = a.ts * RS;
+    if constexpr (LDSOUT) {
+        rmap = RIO::make_map(lane64, (long)blockIdx.x * GPB + (threadIdx.x / 64) * RIO::GW, a.B, a.bs);
+        RIO::clear_tail(imgP, lane64);
+        RIO::clear_tail(imgF, lane64);
+        RIO::put_pad(imgP, gw, 0.0, 0.0);
+    }
+    double pad0 = 0.0, pad1 = 0.0;
 
     // ---- observation stream: tiles of 16 time steps through LDS ----
     // vmcnt retires vector-memory operations IN ORDER, so consuming a load makes the wavefront wait for
@@ -534,7 +559,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 #pragma unroll
             for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
         }
-        if constexpr (OUT == 1) {
+        if constexpr (LDSOUT && OUT == 1) {
+            RIO::put(imgP, gw, r, x, P);
+        } else if constexpr (OUT == 1) {
             *oP.vec = x;               // :332
             store_cols<n>(oP.mat, P);  // :333
             *padP = 0.0;
@@ -625,8 +652,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
                 if constexpr (RECF) {
                     // compressed entry sc lives in the pad of filtered record sc; sc == t unless an earlier
                     // step of this model was empty (then: one scattered 16-byte store, rare)
-                    if (sc == t) pad = pslot == 0 ? sigma : (pslot == 1 ? detf : 0.0);
-                    else if (lead && a.sigmas)
+                    if (sc == t) {
+                        pad = pslot == 0 ? sigma : (pslot == 1 ? detf : 0.0);
+                        pad0 = sigma;
+                        pad1 = detf;
+                    } else if (lead && a.sigmas)
                         *reinterpret_cast<v2d *>(a.F + (inst * a.bs + sc * a.ts) * RS + NV) = v2d{sigma, detf};
                 } else {
                     if (a.sigmas && lead) a.sigmas[(inst * a.bs + sc * a.ts) * a.sig_stride] = sigma;
@@ -648,7 +678,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
         }
         if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
 
-        if constexpr (RECF) {
+        if constexpr (LDSOUT) {
+            RIO::put(imgF, gw, r, x, P);
+            RIO::put_pad(imgF, gw, pad0, pad1);
+            pad0 = pad1 = 0.0;
+            if constexpr (OUT == 1) {
+                RIO::emit2(imgP, recP, imgF, recF, rmap);
+                recP += rstep;
+            } else {
+                RIO::emit(imgF, recF, rmap);
+            }
+            recF += rstep;
+        } else if constexpr (RECF) {
             *oF.vec = x;               // :389
             store_cols<n>(oF.mat, P);  // :390
             *padF = pad;               // sigma | detf | zeros
