@@ -179,6 +179,9 @@ class HipSolve:
             hi = self.result.hess_inv
             pcov = hi.todense() if hasattr(hi, "todense") else np.asarray(hi)
             _stderr = np.sqrt(np.diag(pcov))
+        if self.gradient == "adjoint":
+            pcov = self._get_covariance_adjoint(self.result.x)  # exact-gradient Hessian instead of L-BFGS's estimate
+            _stderr = np.sqrt(np.diag(pcov))
         if pcov is None or np.isnan(_stderr).any():
             pcov = self._get_covariance(self.result.x)  # finite-difference Hessian, (P+1)^2 instances, one launch
             _stderr = np.sqrt(np.diag(pcov))
@@ -201,6 +204,29 @@ class HipSolve:
         return success, optimal, stderr
 
     # ------------------------------------------------------------------ covariance helpers
+    def _get_covariance_adjoint(self, x0, rel_step=1e-5):
+        """Covariance = pinv(Hessian) with the Hessian from forward differences of the ADJOINT gradient:
+        P+1 gradient evaluations in one forward + one backward launch (the reference nests two finite
+        differences of the objective, (P+1)^2 evaluations, metran/solver.py:65-140)."""
+        x0 = np.asarray(x0, dtype=np.float64)
+        n = x0.shape[0]
+        vidx = np.nonzero(self.vary)[0]
+        obj = self._objective()
+        d = rel_step * np.maximum(np.abs(x0), 0.1)
+        pts = np.tile(self._array_todict(x0).astype(np.float64), (n + 1, 1))
+        for j in range(n):
+            pts[1 + j, vidx[j]] += d[j]
+        _, g = obj.kf.loglik_grad_alpha(pts[:, obj.order], dt=obj.dt, warmup=obj.warmup)
+        g = g.cpu().numpy()
+        gfull = np.zeros_like(pts)
+        gfull[:, obj.order] = g
+        gv = gfull[:, vidx]
+        obj.nfev += n + 1
+        obj.launches += 2
+        hessian = (gv[1:] - gv[0]) / d[:, None]      # row j: d grad / d x_j
+        hessian = 0.5 * (hessian + hessian.T)
+        return np.linalg.pinv(hessian)
+
     def _get_covariance(self, x0, epsilon=None):
         """``BaseSolver._get_covariance`` (metran/solver.py:65-140, forward scheme) with every objective
         evaluation of the nested finite differences in ONE launch."""
