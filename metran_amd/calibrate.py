@@ -28,7 +28,8 @@ class CalibrationResult(dict):
 
 
 def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
-                    ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto"):
+                    ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto",
+                    stderr=False):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
@@ -144,5 +145,22 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         if verbose:
             print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
     pg = proj_grad(x, g)
-    return CalibrationResult(alpha=x, obj=f, grad=g, converged=~active, nit=nit, nfev=nfev, launches=launches,
-                             aic=2 * n + f, pgnorm=pg.abs().amax(1))
+    res = CalibrationResult(alpha=x, obj=f, grad=g, converged=~active, nit=nit, nfev=nfev, launches=launches,
+                            aic=2 * n + f, pgnorm=pg.abs().amax(1))
+    if stderr:
+        if gradient != "adjoint":
+            raise ValueError("stderr=True needs the adjoint gradient (state dimension <= 16)")
+        d = 1e-5 * x.abs().clamp_min(0.1)                                   # [R,n] step per parameter
+        pts = x[None].repeat(n + 1, 1, 1)                                   # [n+1,R,n]
+        idx = torch.arange(n, device=dev)
+        pts[1 + idx, :, idx] += d.transpose(0, 1)
+        _, gg = kf.loglik_grad_alpha(pts.reshape((n + 1) * R, n), dt=dt, warmup=warmup)
+        gg = gg.reshape(n + 1, R, n)
+        hess = ((gg[1:] - gg[0:1]) / d.transpose(0, 1)[:, :, None]).permute(1, 0, 2)   # [R, j, :] = d grad / d x_j
+        hess = 0.5 * (hess + hess.transpose(1, 2))
+        pcov = torch.linalg.pinv(hess)
+        res["pcov"] = pcov
+        res["stderr"] = torch.sqrt(torch.diagonal(pcov, dim1=1, dim2=2))
+        res["nfev"] = nfev + (n + 1) * R
+        res["launches"] = launches + 2
+    return res
