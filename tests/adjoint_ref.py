@@ -5,10 +5,12 @@ out in mk_kernels.hip::adjoint_kernel.  Checked against central differences in t
 import numpy as np
 
 
-def forward(y, phi, q, G, warmup=1):
+def forward(y, phi, q, G, warmup=1, x0=None, P0=None, R=None):
     T, N = y.shape
     n = N + G.shape[1]
-    x, P = np.zeros(n), np.eye(n)
+    x = np.zeros(n) if x0 is None else np.array(x0, float)
+    P = np.eye(n) if P0 is None else np.array(P0, float)
+    R = np.zeros(N) if R is None else R
     F, Pf = np.zeros((T, n)), np.zeros((T, n, n))
     mle, sc, nobs = 0.0, 0, 0
     for t in range(T):
@@ -22,7 +24,7 @@ def forward(y, phi, q, G, warmup=1):
             z[N:] = G[j]
             v = y[t, j] - z @ x
             d = P @ z
-            f = z @ d
+            f = z @ d + R[j]
             x = x + d * v / f
             P = P - np.outer(d, d) / f
             sig += v * v / f
@@ -37,17 +39,18 @@ def forward(y, phi, q, G, warmup=1):
     return mle + nobs * np.log(2 * np.pi), F, Pf, sc
 
 
-def gradient(y, phi, q, G, warmup=1):
+def gradient(y, phi, q, G, warmup=1, x0=None, P0=None, R=None):
     """-> (mle, d mle/d phi, d mle/d q)"""
-    mle, F, Pf, sctot = forward(y, phi, q, G, warmup)
+    mle, F, Pf, sctot = forward(y, phi, q, G, warmup, x0, P0, R)
+    R = np.zeros(y.shape[1]) if R is None else R
     T, N = y.shape
     n = N + G.shape[1]
     xb, Pb = np.zeros(n), np.zeros((n, n))
     gphi, gq = np.zeros(n), np.zeros(n)
     rem = 0
     for t in range(T - 1, -1, -1):
-        xprev = F[t - 1] if t > 0 else np.zeros(n)
-        Pprev = Pf[t - 1] if t > 0 else np.eye(n)
+        xprev = F[t - 1] if t > 0 else (np.zeros(n) if x0 is None else np.array(x0, float))
+        Pprev = Pf[t - 1] if t > 0 else (np.eye(n) if P0 is None else np.array(P0, float))
         x = phi * xprev
         P = np.outer(phi, phi) * Pprev + np.diag(q)
         obs = [j for j in range(N) if np.isfinite(y[t, j])]
@@ -61,7 +64,7 @@ def gradient(y, phi, q, G, warmup=1):
                 z[N:] = G[j]
                 v = y[t, j] - z @ x
                 d = P @ z
-                f = z @ d
+                f = z @ d + R[j]
                 st.append((z, v, d, f))
                 x = x + d * v / f
                 P = P - np.outer(d, d) / f

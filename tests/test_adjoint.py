@@ -92,3 +92,25 @@ def test_adjoint_at_the_lower_bound():
     for b in (0, 2):
         ph, qq = phi_q_from_alpha(alpha[b], d["loadings"][b])
         assert abs(mle[b] - _oracle_mle(d["obs"][b], ph, qq, d["loadings"][b])) <= 1e-10 * abs(mle[b])
+
+
+@pytest.mark.gpu
+def test_adjoint_with_initial_state_and_observation_variance():
+    """Caller-supplied x0 / P0 (run_filter arguments, kalmanfilter.py:696-750) and a non-zero observation
+    variance R (set_matrices) flow through the backward pass as constants."""
+    from metran_amd.engine import BatchedKalman
+
+    B, N, K, T = 7, 5, 1, 60
+    d = make_dfm_batch(B, N, K, T, seed=91, missing=0.2)
+    rng = np.random.default_rng(3)
+    x0 = rng.normal(size=(B, N + K))
+    A = rng.normal(size=(B, N + K, N + K)) * 0.2
+    P0 = np.eye(N + K)[None] + A @ A.transpose(0, 2, 1)
+    R = rng.uniform(0.01, 0.2, size=(B, N))
+    kf = BatchedKalman(0).set_observations(d["obs"]).set_loadings(d["loadings"], obsvar=R)
+    mle, gphi, gq = (t.cpu().numpy() for t in kf.loglik_grad(d["phi"], d["q"], x0=x0, P0=P0))
+    for b in range(B):
+        m, rp, rq = adjoint_ref.gradient(d["obs"][b], d["phi"][b], d["q"][b], d["loadings"][b], x0=x0[b], P0=P0[b], R=R[b])
+        assert abs(mle[b] - m) <= 1e-11 * abs(m)
+        np.testing.assert_allclose(gphi[b], rp, rtol=1e-9, atol=1e-9 * np.abs(rp).max())
+        np.testing.assert_allclose(gq[b], rq, rtol=1e-9, atol=1e-9 * np.abs(rq).max())
