@@ -114,3 +114,22 @@ def test_adjoint_with_initial_state_and_observation_variance():
         assert abs(mle[b] - m) <= 1e-11 * abs(m)
         np.testing.assert_allclose(gphi[b], rp, rtol=1e-9, atol=1e-9 * np.abs(rp).max())
         np.testing.assert_allclose(gq[b], rq, rtol=1e-9, atol=1e-9 * np.abs(rq).max())
+
+
+@pytest.mark.gpu
+def test_adjoint_on_a_runtime_specialised_shape(tmp_path_factory, monkeypatch):
+    """(7,2) is not in the ahead-of-time list: the shape module built at run time carries the adjoint
+    kernel too (mkmod_launch_adjoint)."""
+    import os
+
+    from metran_amd.engine import BatchedKalman
+
+    monkeypatch.setenv("METRAN_HIP_CACHE", os.environ.get("METRAN_HIP_CACHE", str(tmp_path_factory.getbasetemp() / "mkjit")))
+    d = make_dfm_batch(5, 7, 2, 50, seed=72, missing=0.2)
+    kf = BatchedKalman(0).set_observations(d["obs"]).set_loadings(d["loadings"])
+    mle, gphi, gq = (t.cpu().numpy() for t in kf.loglik_grad(d["phi"], d["q"]))
+    for b in range(5):
+        m, rp, rq = adjoint_ref.gradient(d["obs"][b], d["phi"][b], d["q"][b], d["loadings"][b])
+        assert abs(mle[b] - m) <= 1e-11 * abs(m)
+        np.testing.assert_allclose(gphi[b], rp, rtol=1e-9, atol=1e-9 * np.abs(rp).max())
+        np.testing.assert_allclose(gq[b], rq, rtol=1e-9, atol=1e-9 * np.abs(rq).max())
