@@ -26,7 +26,7 @@ def golden_models(name):
         yield i, {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
 
 
-SYNTH_GOLDENS = ["c2_small.npz", "c2_T1000.npz", "c4_missing.npz", "edge_cases.npz", "n17_k3.npz"]
+SYNTH_GOLDENS = ["c2_small.npz", "c2_T1000.npz", "c4_missing.npz", "c4_T400.npz", "edge_cases.npz", "n17_k3.npz"]
 
 
 @pytest.fixture(scope="session")

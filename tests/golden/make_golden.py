@@ -268,6 +268,8 @@ if __name__ == "__main__":
     # C4 shape (32 series / 4 factors) with 30 % missing; model 1 has an EMPTY first step
     synthetic_case("c4_missing.npz", 32, 4, 36, seed=4000, models=[0, 1], missing=0.3,
                    first_steps=["observed", "empty"], cov_every=5)
+    # C4 shape over a longer horizon (wide kernels: one model per wavefront), covariances every 50 steps
+    synthetic_case("c4_T400.npz", 32, 4, 400, seed=4001, models=[0], missing=0.3, cov_every=50)
     # small odd shapes / degenerate missingness
     synthetic_case("edge_cases.npz", 3, 1, 14, seed=77, models=[0, 1, 2], missing=0.25,
                    first_steps=["observed", "empty", "random"], extra_nan=edge_nan)
