@@ -19,6 +19,8 @@ struct mk_context {
     bool timing;
     hipEvent_t ev[4]; // filter start/stop, smoother start/stop
     bool have_filter_time, have_smooth_time;
+    int *tlist;      // workspace of the sparse objective (observed-step list), grown on demand
+    long tlist_cap;
 };
 
 static thread_local char g_err[512] = "";
@@ -50,6 +52,7 @@ struct ShapeModule {
     int (*launch_filter)(const mk::FilterArgs *, void *);
     int (*launch_smoother)(const mk::SmootherArgs *, void *);
     int (*launch_adjoint)(const mk::AdjointArgs *, void *);
+    int (*launch_sparse)(const mk::SparseArgs *, void *);
 };
 std::vector<ShapeModule> g_modules;
 std::mutex g_modules_mutex;
@@ -85,6 +88,12 @@ hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s)
     if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_filter(&a, (void *)s);
     return hipErrorInvalidValue;
 }
+hipError_t dispatch_sparse(int N, int K, const mk::SparseArgs &a, hipStream_t s)
+{
+    if (aot_shape(N, K)) return mk::launch_sparse(N, K, a, s);
+    if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_sparse(&a, (void *)s);
+    return hipErrorInvalidValue;
+}
 hipError_t dispatch_adjoint(int N, int K, const mk::AdjointArgs &a, hipStream_t s)
 {
     if (aot_shape(N, K)) return mk::launch_adjoint(N, K, a, s);
@@ -113,11 +122,13 @@ MK_API int mk_register_shape_module(const char *path)
     auto lf = (int (*)(const mk::FilterArgs *, void *))dlsym(h, "mkmod_launch_filter");
     auto ls = (int (*)(const mk::SmootherArgs *, void *))dlsym(h, "mkmod_launch_smoother");
     auto la = (int (*)(const mk::AdjointArgs *, void *))dlsym(h, "mkmod_launch_adjoint");
-    if (!abi || !shape || !lf || !ls || !la) {
+    auto lsp = (int (*)(const mk::SparseArgs *, void *))dlsym(h, "mkmod_launch_sparse");
+    if (!abi || !shape || !lf || !ls || !la || !lsp) {
         dlclose(h);
         return fail(MK_ERR_INVALID, "%s is not a metran_hip shape module", path);
     }
-    if (abi() != (int)(sizeof(mk::FilterArgs) * 1000 + sizeof(mk::SmootherArgs) + sizeof(mk::AdjointArgs))) {
+    if (abi() != (int)(sizeof(mk::FilterArgs) * 1000 + sizeof(mk::SmootherArgs) + sizeof(mk::AdjointArgs) +
+                       sizeof(mk::SparseArgs))) {
         dlclose(h);
         return fail(MK_ERR_INVALID, "%s was built against different kernel-argument structs (stale cache)", path);
     }
@@ -132,7 +143,7 @@ MK_API int mk_register_shape_module(const char *path)
             dlclose(h);
             return MK_OK; // already registered
         }
-    g_modules.push_back(ShapeModule{N, K, h, lf, ls, la});
+    g_modules.push_back(ShapeModule{N, K, h, lf, ls, la, lsp});
     return MK_OK;
 }
 
@@ -172,6 +183,8 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->stream = nullptr;
     ctx->timing = false;
     ctx->have_filter_time = ctx->have_smooth_time = false;
+    ctx->tlist = nullptr;
+    ctx->tlist_cap = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
             delete ctx;
@@ -187,6 +200,7 @@ MK_API int mk_destroy(mk_context *ctx)
     if (!ctx) return MK_OK;
     (void)hipSetDevice(ctx->device);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->tlist) (void)hipFree(ctx->tlist);
     delete ctx;
     return MK_OK;
 }
@@ -431,6 +445,39 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
     MK_CTX(ctx);
     if (int rc = check_problem(p)) return rc;
     if (!d_mle) return fail(MK_ERR_INVALID, "d_mle is required");
+    if (p->n_records == 1 && p->N + p->K <= 16 && p->d_obs && p->d_loadings ) {
+        // every instance shares the one record (the solver's finite-difference points): walk only its
+        // observed steps, the runs of empty steps in closed form (loglik_sparse_kernel)
+        if (ctx->tlist_cap < p->T + 1) {
+            if (ctx->tlist) MK_HIP(hipFree(ctx->tlist));
+            ctx->tlist = nullptr;
+            ctx->tlist_cap = 0;
+            MK_HIP(hipMalloc((void **)&ctx->tlist, sizeof(int) * (size_t)(p->T + 1)));
+            ctx->tlist_cap = p->T + 1;
+        }
+        mk::SparseArgs a;
+        a.B = p->n_instances;
+        a.T = p->T;
+        a.warmup = p->warmup;
+        a.ostep = (p->obs_time_major ? p->n_records : 1) * p->N; // one record: both layouts coincide
+        a.obs = p->d_obs;
+        a.phi = p->d_phi;
+        a.q = p->d_q;
+        a.loadings = p->d_loadings;
+        a.obsvar = p->d_obsvar;
+        a.x0 = p->d_x0;
+        a.P0 = p->d_P0;
+        a.tlist = ctx->tlist;
+        a.mle = d_mle;
+        a.status = nullptr;
+        if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        MK_HIP(dispatch_sparse((int)p->N, (int)p->K, a, ctx->stream));
+        if (ctx->timing) {
+            MK_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+            ctx->have_filter_time = true;
+        }
+        return MK_OK;
+    }
     mk_outputs o;
     memset(&o, 0, sizeof(o));
     o.d_mle = d_mle;

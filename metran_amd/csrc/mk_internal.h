@@ -57,7 +57,18 @@ struct AdjointArgs {
     double *gphi, *gq;               // [B,n] gradient of -2 log L w.r.t. diag(Phi), diag(Q)
 };
 
+struct SparseArgs { // objective of ONE record (all instances share it), observed steps only
+    long B, T, warmup;
+    long ostep;                      // doubles between consecutive steps of the record
+    const double *obs;               // the record: step t at obs + t*ostep
+    const double *phi, *q, *loadings, *obsvar, *x0, *P0;
+    int *tlist;                      // workspace [T+1]: count, then the observed steps (built by the launch)
+    double *mle;
+    unsigned *status;
+};
+
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);
+hipError_t launch_sparse(int N, int K, const SparseArgs &a, hipStream_t s);
 hipError_t launch_adjoint(int N, int K, const AdjointArgs &a, hipStream_t s);
 hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,
                              const double *gphi, const double *gq, double *galpha, hipStream_t s);

@@ -1350,6 +1350,158 @@ smoother_wave_kernel(SmootherArgs a)
 }
 
 // =====================================================================================
+// Objective of ONE record for many parameter sets, walking only the OBSERVED steps
+//   (the solver loop of Metran.solve on real data: every finite-difference instance shares the record, and
+//   real records are sparse -- examples/data has observations on 343 of its 6255 daily steps).  Between two
+//   observed steps t- < t the prediction is applied in closed form (Phi diagonal):
+//       x <- phi^g x,   P[r][c] <- (phi_r phi_c)^g P[r][c] + [r == c] q_r (1 - phi_r^2g)/(1 - phi_r^2),   g = t - t-
+//   (g = 1 is the ordinary predict), then the scalar updates of step t run as in filter_kernel.  No state
+//   output exists in this mode, so nothing is lost by not visiting the empty steps; the compressed warm-up
+//   index of get_mle (:563-564) is simply the position in the list of observed steps.
+//   observed_steps_kernel builds that list (ascending) on the device: tlist[0] = count, tlist[1..] = t.
+// =====================================================================================
+__global__ void __launch_bounds__(256) observed_steps_kernel(long T, int N, long ostep, const double *obs, int *tlist)
+{
+    __shared__ int s_wcnt[4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (long t0 = 0; t0 < T; t0 += 256) {
+        const long t = t0 + tid;
+        bool f = false;
+        if (t < T)
+            for (int j = 0; j < N; ++j) f = f || isfinite(obs[t * ostep + j]);
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_wcnt[w] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int i = 0; i < w; ++i) off += s_wcnt[i];
+        if (f) tlist[1 + off + __popcll(b & ((1ull << lane) - 1ull))] = (int)t;
+        __syncthreads();
+        if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) tlist[0] = s_base;
+}
+
+template <int N, int K, int G>
+__global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
+{
+    constexpr int n = N + K;
+    static_assert(G == 16 && n <= 16, "sparse objective kernel: one model per 16-lane group");
+    using Gp = Group<G>;
+    constexpr int GPB = 256 / G;
+    constexpr bool HOIST = (N * K <= 32);
+    const int lane = threadIdx.x % G;
+    long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
+    if (inst > a.B - 1) inst = a.B - 1;
+    const int r = lane < n ? lane : n - 1;
+    const bool lead = lane == 0;
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+    const double lphi_r = log(phi_r); // -inf when phi underflowed to 0 at the lower bound: exp(-inf) = 0 below
+    double pp[n], qd[n], lpp[n];
+    sfor<0, n>(MK_LAMBDA(c) {
+        constexpr int cc = decltype(c)::value;
+        pp[cc] = phi_r * Gp::template bcast<cc>(phi_r);
+        lpp[cc] = lphi_r + Gp::template bcast<cc>(lphi_r);
+        qd[cc] = (cc == r) ? q_r : 0.0;
+    });
+    const double inv_em = 1.0 / expm1(2.0 * lphi_r); // 1/(phi_r^2 - 1)
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gam[k] = a.loadings[jr * K + k];
+    const double rvar = a.obsvar ? a.obsvar[jr] : 0.0;
+    double Gh[HOIST ? N : 1][K];
+    if constexpr (HOIST) {
+        sfor<0, N>(MK_LAMBDA(j) {
+            sfor<0, K>(MK_LAMBDA(k) {
+                Gh[decltype(j)::value][decltype(k)::value] = Gp::template bcast<decltype(j)::value>(gam[decltype(k)::value]);
+            });
+        });
+    }
+    double x = a.x0 ? a.x0[inst * n + r] : 0.0;
+    double P[n];
+#pragma unroll
+    for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
+
+    const int cnt = a.tlist[0];
+    const double *obase = a.obs + jr;
+    double sum_sig = 0.0, run_mant = 1.0, fmin_seen = 1.0;
+    long run_exp = 0, nobs = 0, tprev = -1;
+    double ynext = cnt > 0 ? obase[(long)a.tlist[1] * a.ostep] : 0.0;
+
+    for (int i = 0; i < cnt; ++i) {
+        const long t = a.tlist[1 + i];
+        const double y = ynext;
+        if (i + 1 < cnt) ynext = obase[(long)a.tlist[2 + i] * a.ostep];
+        const long gap = t - tprev;
+        tprev = t;
+        if (gap == 1) { // ordinary predict (:318-331)
+            x = phi_r * x;
+#pragma unroll
+            for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
+        } else { // gap - 1 empty steps and the predict of step t in one go
+            const double g = (double)gap;
+            x *= exp(g * lphi_r);
+            const double qg = q_r * expm1(2.0 * g * lphi_r) * inv_em;
+#pragma unroll
+            for (int c = 0; c < n; ++c) P[c] = fma(P[c], exp(g * lpp[c]), c == r ? qg : 0.0);
+        }
+        const unsigned long long ball = __ballot(lane < N && isfinite(y));
+        const auto vm = Gp::group_bits(ball);
+        double sigma = 0.0, fmant = 1.0;
+        int fexp = 0;
+        sfor<0, N>(MK_LAMBDA(jc) {
+            constexpr int j = decltype(jc)::value;
+            if ((vm >> j) & 1) {
+                double vl = y - x;
+                sfor<0, K>(MK_LAMBDA(k) { Gp::template fmac<N + decltype(k)::value, true>(vl, x, gam[decltype(k)::value]); });
+                const double v = Gp::template bcast<j>(vl);
+                double dr = P[j];
+                sfor<0, K>(MK_LAMBDA(k) {
+                    constexpr int kk = decltype(k)::value;
+                    double g;
+                    if constexpr (HOIST) g = Gh[j][kk];
+                    else g = Gp::template bcast<j>(gam[kk]);
+                    dr = fma(P[N + kk], g, dr);
+                });
+                double fl = rvar + dr;
+                dpp_pin(dr);
+                sfor<0, K>(MK_LAMBDA(k) { Gp::template fmac<N + decltype(k)::value, false>(fl, dr, gam[decltype(k)::value]); });
+                const double f = Gp::template bcast<j>(fl);
+                const double rf = rcp_nr(f);
+                const double kr = dr * rf;
+                Gp::template axpy_col<0, n, true, n>(P, dr, kr);
+                x = fma(kr, v, x);
+                sigma = fma(v * v, rf, sigma);
+                fmant *= f;
+                fmin_seen = min_f64(fmin_seen, f);
+            }
+            if constexpr ((j & 3) == 3 || j == N - 1) {
+                fexp += __builtin_amdgcn_frexp_exp(fmant);
+                fmant = __builtin_amdgcn_frexp_mant(fmant);
+            }
+        });
+        if (i >= a.warmup) { // compressed index of the observed step (:563-564)
+            sum_sig += sigma;
+            run_mant *= fmant;
+            run_exp += fexp + __builtin_amdgcn_frexp_exp(run_mant);
+            run_mant = __builtin_amdgcn_frexp_mant(run_mant);
+        }
+        if (t >= a.warmup) nobs += __popcll((unsigned long long)vm); // TIME index (:565)
+    }
+    if (lead) {
+        const double sum_det = fma((double)run_exp, kLn2, log(run_mant));
+        if (a.mle) a.mle[inst] = ((double)nobs * kLog2Pi + sum_det) + sum_sig;
+        if (a.status) a.status[inst] = (fmin_seen > 0.0) ? 0u : MK_FLAG_NONPOSITIVE_F;
+    }
+}
+
+// =====================================================================================
 // Reverse-mode (adjoint) gradient of the objective -2 log L with respect to diag(Phi) and diag(Q)
 //                                                     ("analytic/adjoint gradient")
 //   The reference gives scipy no gradient (metran/solver.py:248-255): every gradient is P+1 filter runs.
@@ -1718,7 +1870,16 @@ void get_shape(int i, int *N, int *K);
 // specialising per shape is what makes them fast; this is how an arbitrary Metran model gets one.
 // ---------------------------------------------------------------------------------------------
 extern "C" {
-MK_API int mkmod_abi(void) { return (int)(sizeof(FilterArgs) * 1000 + sizeof(SmootherArgs) + sizeof(AdjointArgs)); }
+MK_API int mkmod_abi(void)
+{
+    return (int)(sizeof(FilterArgs) * 1000 + sizeof(SmootherArgs) + sizeof(AdjointArgs) + sizeof(SparseArgs));
+}
+MK_API int mkmod_launch_sparse(const SparseArgs *a, void *stream)
+{
+    int N, K;
+    get_shape(0, &N, &K);
+    return (int)launch_sparse(N, K, *a, (hipStream_t)stream);
+}
 MK_API int mkmod_launch_adjoint(const AdjointArgs *a, void *stream)
 {
     int N, K;
@@ -1781,6 +1942,27 @@ hipError_t launch_decompose(long B, long RZ, long T, int N, int n, const double 
     hipLaunchKernelGGL(decompose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, B, RZ, T, N, n, Z,
                        means, sdf, cdf);
     return hipGetLastError();
+}
+
+template <int N, int K>
+static hipError_t launch_sparse_nk(const SparseArgs &a, hipStream_t s)
+{
+    constexpr int n = N + K;
+    if constexpr (n <= 16) {
+        constexpr int GPB = 256 / 16;
+        hipLaunchKernelGGL(observed_steps_kernel, dim3(1), dim3(256), 0, s, a.T, N, a.ostep, a.obs, a.tlist);
+        hipLaunchKernelGGL((loglik_sparse_kernel<N, K, 16>), dim3((unsigned)((a.B + GPB - 1) / GPB)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+#define MK_CASE_SPARSE(NN, KK) \
+    if (N == NN && K == KK) return launch_sparse_nk<NN, KK>(a, s);
+hipError_t launch_sparse(int N, int K, const SparseArgs &a, hipStream_t s)
+{
+    MK_SHAPES(MK_CASE_SPARSE)
+    return hipErrorInvalidValue;
 }
 
 template <int N, int K>

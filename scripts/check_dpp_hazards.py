@@ -115,7 +115,7 @@ def check_function(name, lines):
 
 def main(argv):
     path = argv[1]
-    want = argv[2:] or ["filter_kernel", "smoother_"]
+    want = argv[2:] or ["filter_kernel", "smoother_", "adjoint_kernel", "loglik_sparse"]
     lines = open(path).read().split("\n")
     starts = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):", l)] if m]
     total_err = []

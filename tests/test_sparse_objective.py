@@ -1,0 +1,65 @@
+"""mk_loglik on ONE shared record (the solver's finite-difference instances) walks only the observed steps
+and applies runs of empty steps in closed form (loglik_sparse_kernel).  Same objective as the reference's
+step-by-step recursion (oracle restating kalmanfilter.py:236-400, 550-567) to 1e-10 relative."""
+import numpy as np
+import pytest
+
+import oracle
+from metran_amd.params import phi_q_from_alpha
+from metran_amd.synthetic import make_dfm
+
+pytestmark = pytest.mark.gpu
+
+
+def _sparse_record(N, K, T, seed, keep_every, first):
+    y, alpha, G, phi, q = make_dfm(N, K, T, seed, 0, 0.2, "observed")
+    rng = np.random.default_rng(seed)
+    keep = np.zeros(T, bool)
+    keep[rng.choice(T, size=max(2, T // keep_every), replace=False)] = True
+    keep[0] = first
+    y[~keep] = np.nan
+    return y, alpha, G
+
+
+@pytest.mark.parametrize("N,K,T,keep_every,first", [(5, 1, 900, 18, True), (5, 1, 400, 9, False), (8, 2, 600, 25, False),
+                                                    (2, 1, 300, 3, True), (8, 2, 200, 1, True), (3, 1, 50, 50, False)])
+def test_sparse_objective_equals_the_oracle(N, K, T, keep_every, first):
+    from metran_amd.engine import BatchedKalman
+
+    y, alpha, G = _sparse_record(N, K, T, 800 + N + T, keep_every, first)
+    S = 13                                                  # parameter sets sharing the record
+    rng = np.random.default_rng(T)
+    alphas = alpha[None] * rng.uniform(0.5, 2.0, size=(S, N + K))
+    alphas[3, 0] = 1e-5                                     # phi underflows to 0 (Metran's lower bound)
+    kf = BatchedKalman(0).set_observations(y[None]).set_loadings(G[None])
+    phi, q = kf.params_from_alpha(alphas)
+    mle = kf.loglik(phi, q).cpu().numpy()
+    ph, qq = phi.cpu().numpy(), q.cpu().numpy()
+    ref = oracle.dfm_batch(np.repeat(y[None], S, 0), ph, qq, np.repeat(G[None], S, 0), smooth=False, outputs="mle")["mle"]
+    np.testing.assert_allclose(mle, ref, rtol=1e-10, atol=1e-10)
+    # warm-up variants of get_mle and caller-supplied initial state / observation variance
+    x0 = rng.normal(size=(S, N + K))
+    A = rng.normal(size=(S, N + K, N + K)) * 0.3
+    P0 = np.eye(N + K)[None] + A @ A.transpose(0, 2, 1)
+    R = rng.uniform(0.01, 0.3, size=(1, N))
+    kf.set_loadings(G[None], obsvar=R)
+    import adjoint_ref  # numpy restatement of the same recursion with x0 / P0 / R arguments
+
+    for warmup in (0, 1, 3):
+        mle = kf.loglik(phi, q, warmup=warmup, x0=x0, P0=P0).cpu().numpy()
+        for s_ in (0, 3, S - 1):
+            ref = adjoint_ref.forward(y, ph[s_], qq[s_], G, warmup=warmup, x0=x0[s_], P0=P0[s_], R=R[0])[0]
+            assert abs(mle[s_] - ref) <= 1e-10 * max(1.0, abs(ref)), (warmup, s_, mle[s_], ref)
+
+
+def test_sparse_objective_on_examples_data(g1):
+    """examples/data: 343 observed of 6255 daily steps; reference values of BASELINE.md (G1)."""
+    from metran_amd.engine import BatchedKalman
+
+    kf = BatchedKalman(0).set_observations(g1["obs"][None]).set_loadings(g1["loadings"][None])
+    kf.enable_timing(True)
+    phi, q = kf.params_from_alpha(np.stack([g1["alpha_star"], g1["alpha_10"]]))
+    mle = kf.loglik(phi, q).cpu().numpy()
+    assert abs(mle[0] - 2332.327069381027) < 1e-8 and abs(mle[1] - 2384.792799342231) < 1e-8
+    ms, _ = kf.last_kernel_ms()
+    assert ms < 3.0, ms     # the step-by-step filter needs ~9 ms for the 6255 steps of this record
