@@ -383,8 +383,10 @@ struct RecordIO;
 #define MK_FILTER_LDS_STORES 1
 #endif
 
+// (two resident wavefronts per SIMD are asked for only while the wide variant's two n-double row arrays fit
+// 256 VGPRs: compile-checked at n = 64, the constraint spilled 1.1 KB per lane)
 template <int N, int K, int G, int OUT, bool BOOK>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 ? 2 : 1))) filter_kernel(FilterArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 && N + K <= 40 ? 2 : 1))) filter_kernel(FilterArgs a)
 {
     constexpr int n = N + K;
     static_assert(n <= G, "state dimension must fit the lane group");
