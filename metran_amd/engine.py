@@ -118,7 +118,11 @@ class BatchedKalman:
             obs = obs[None]
         if obs.ndim != 3:
             raise ValueError("observations must be [R,T,N] or [T,N]")
-        self.obs = self._layout(self._dev(obs))
+        obs = self._dev(obs)
+        # the reference finds valid entries with "(x + 1e10).nonzero()" (kalmanfilter.py:666-667): a finite
+        # observation of exactly -1e10 is dropped there, so it is a missing value here too
+        obs = torch.where(obs == -1e10, torch.full_like(obs, float("nan")), obs)
+        self.obs = self._layout(obs)
         self._obs_unmasked = None
         self.R, self.T, self.N = (int(s) for s in self.obs.shape)
         return self

@@ -223,6 +223,18 @@ def test_degenerate_sizes(kf, B, N, K, T):
     np.testing.assert_allclose(_np(kf.loglik(d["phi"], d["q"])), ref["mle"], rtol=MLE_RTOL, atol=1e-12)
 
 
+def test_minus_1e10_is_dropped_like_the_reference(kf):
+    """set_observations' "+1e10 then nonzero()" (kalmanfilter.py:666-667) drops a finite -1e10; the oracle
+    restates it and the engine maps the value to missing on upload."""
+    d = make_dfm_batch(3, 5, 1, 40, seed=10)
+    d["obs"][1, 7, 2] = -1e10
+    ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    r = kf.filter_smooth(d["phi"], d["q"])
+    np.testing.assert_allclose(_np(r["mle"]), ref["mle"], rtol=MLE_RTOL)
+    np.testing.assert_allclose(_np(r["S"]), ref["S"], rtol=0, atol=SMOOTH_ATOL)
+
+
 def test_full_size_c4_projection(kf):
     """BASELINE configs[3] size (B=4096, 32 series / 4 factors, 30 % missing, T=2000).  Three full state
     records per step would be 264 GB; the fused projection path keeps one (88 GB) and emits what
