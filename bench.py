@@ -1,64 +1,99 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the hot path on MI355X (contract: see task description / DESIGN.md).
+"""bench.py -- throughput of the hot path on MI355X (contract: see task description / DESIGN.md section 6).
 
-One "step" = one pass of the hot path over one batch: batched Kalman filter + -2 log L + RTS
-smoother with every reference-equivalent state output materialised in HBM (F, Pf, Xp, Pp, S, Ps),
-followed by the summed-objective reduction (local deterministic sum + one RCCL all-reduce when
-N > 1).  Workload = BASELINE.json configs[1]: batch=4096 synthetic 8-series / 2-factor DFMs,
-T=1000, fp64, per GPU (weak scaling: every rank owns its own 4096 models; configs[2] is the same
-per-GPU load at 8 GPUs).  Inputs are resident in HBM before the timed region.
+One "step" = one pass of the hot path over one batch of synthetic models, inputs resident in HBM before
+the timed region.  ``--config`` selects the BASELINE.json configuration (default c2 = configs[1], the one
+the metric is quoted on):
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  c2  configs[1]  4096 x (8 series, 2 factors), T=1000, fp64: filter + -2 log L + RTS smoother, all six
+                  reference-equivalent state outputs (F, Pf, Xp, Pp, S, Ps) materialised in HBM
+  c3  configs[2]  the same with 8192 models per GPU (65536 over 8 GPUs; one all-reduce of the summed -2 log L)
+  c4  configs[3]  4096 x (32 series, 4 factors), 30 % missing, T=2000: filter (filtered record only) +
+                  smoother with the fused projection epilogue (what Metran.get_simulation consumes; three
+                  full-square state arrays would be 255 GB)
+  c5  configs[4]  solver loop: 50 objective evaluations x 8192 models per step (fp64: the reference has no
+                  fp32 path); sharded over the ranks, no collective per evaluation
 
-Rank 0 prints ONE JSON line.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
+
+``--gpus N`` from a plain ``python`` re-executes itself under ``torch.distributed.run`` (one rank per GPU,
+RCCL); launched under torchrun it reads RANK/LOCAL_RANK/WORLD_SIZE as usual.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy ceiling)
+
+CONFIGS = {
+    #        B      N  K   T    missing  mode
+    "c2": (4096, 8, 2, 1000, 0.0, "full"),
+    "c3": (8192, 8, 2, 1000, 0.0, "full"),
+    "c4": (4096, 32, 4, 2000, 0.3, "project"),
+    "c5": (8192, 8, 2, 1000, 0.0, "solver"),
+}
+BASELINE_NAME = {"c2": "configs[1]", "c3": "configs[2] (per-GPU share)", "c4": "configs[3]", "c5": "configs[4] (fp64)"}
+EVALS_PER_STEP = 50  # c5: "50 parameter evaluations x batch=8192"
 
 
-def algorithmic_bytes(N, K, T):
-    """bytes per model that the algorithm has to move."""
+def kernel_source_sha():
+    """Identity of the kernels a PMC profile belongs to (stamped into profiles/*/pmc_hbm.json)."""
+    h = hashlib.sha256()
+    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_internal.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_bytes(N, K, T, mode, sym=False):
+    """bytes per model the algorithm has to move, per kernel.
+    c = n + n^2 doubles per moment set (full-square), c_s = n + n(n+1)/2 (packed-symmetric records)."""
     n = N + K
-    c = n + n * n
-    filt = 8 * T * (N + 2 * c)   # read obs, write filtered (F,Pf) and predicted (Xp,Pp)
-    smooth = 8 * T * (2 * c)     # re-read filtered, write smoothed (S,Ps)
-    return filt, smooth
+    c = n + (n * (n + 1) // 2 if sym else n * n)
+    if mode == "full":      # read obs, write filtered + predicted | re-read filtered, write smoothed
+        return {"filter": 8 * T * (N + 2 * c), "smoother": 8 * T * (2 * c)}
+    if mode == "project":   # read obs, write filtered | re-read filtered, write 2N projected moments
+        return {"filter": 8 * T * (N + c), "smoother": 8 * T * (c + 2 * N)}
+    return {"filter": 8 * T * N, "smoother": 0}  # solver objective: the observation stream only (B_ll)
 
 
-def pmc_traffic(kernel_key, B, N, K, T, layout):
+def pmc_traffic(config, kernel_key, sym=False):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/<round>/pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE is doubled
-    as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; units KiB).  None when no
-    profile of the same workload is committed."""
+    (profiles/<round>/pmc_hbm*.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; units KiB).  The profile must carry
+    the hash of the kernel source it was taken with; on a mismatch (kernels edited since) or when no
+    profile of this configuration exists the answer is None -- stale counters are never reported."""
     import glob
 
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm.json"))):
+    best, note = None, "no committed PMC profile of this configuration"
+    sha = kernel_source_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        w = d.get("workload", {})
-        if (w.get("batch"), w.get("series"), w.get("factors"), w.get("T"), w.get("layout")) != (B, N, K, T, layout):
+        if d.get("config") != config or bool(d.get("packed_sym", False)) != bool(sym):
+            continue
+        if d.get("kernel_source_sha256") != sha:
+            note = "%s was taken with other kernel sources (sha %s, now %s)" % (
+                os.path.relpath(f, ROOT), d.get("kernel_source_sha256"), sha)
             continue
         for name, c in d.get("kernels", {}).items():
             if kernel_key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 best = {"GB": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / 1e9, "source": os.path.relpath(f, ROOT)}
-    return best
+    return best, (None if best else note)
 
 
-def cpu_baseline(d_host, gpu_mle, target_seconds=15.0):
-    """Reference algorithm (oracle/kalman_oracle.c = C port of the numba/numpy path) on the host
-    cores of this box, on a bounded sample of the same workload."""
+# --------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_port(host, mode, gpu_mle, target_seconds=12.0):
+    """The reference ALGORITHM (oracle/kalman_oracle.c: C restatement of kalmanfilter.py:236-476, OpenMP over
+    models) on the host cores of this box, on a bounded sample of the same workload."""
     import numpy as np
 
     import oracle
@@ -70,169 +105,308 @@ def cpu_baseline(d_host, gpu_mle, target_seconds=15.0):
     except Exception:
         pass
     cores = oracle.num_threads(native)
-    B = d_host["obs"].shape[0]
-    probe = min(B, 2 * cores)
-    sl = slice(0, probe)
+    B, T = host["obs"].shape[0], host["obs"].shape[1]
+    smooth = mode != "solver"
+
+    def run(sl):
+        return oracle.dfm_batch(host["obs"][sl], host["phi"][sl], host["q"][sl], host["loadings"][sl], native=native,
+                                smooth=smooth, outputs={"full": "all", "project": "means", "solver": "mle"}[mode])
+
+    probe = min(B, cores)
     t0 = time.perf_counter()
-    oracle.dfm_batch(d_host["obs"][sl], d_host["phi"][sl], d_host["q"][sl], d_host["loadings"][sl], native=native)
+    run(slice(0, probe))
     per_model = (time.perf_counter() - t0) / probe
     n = int(max(probe, min(B, target_seconds / max(per_model, 1e-9))))
-    n = max(cores, (n // cores) * cores)
-    sl = slice(0, n)
+    n = max(min(B, cores), (n // cores) * cores) if n >= cores else n
     t0 = time.perf_counter()
-    ref = oracle.dfm_batch(d_host["obs"][sl], d_host["phi"][sl], d_host["q"][sl], d_host["loadings"][sl],
-                           native=native)
+    ref = run(slice(0, n))
     dt = time.perf_counter() - t0
     rel = float(np.max(np.abs(gpu_mle[:n] - ref["mle"]) / np.abs(ref["mle"])))
-    T = d_host["obs"].shape[1]
-    return {
-        "value": n * T / dt,
-        "unit": "model-timesteps/s",
-        "models_per_s": n / dt,
-        "cores": cores,
-        "kind": "port",
-        "sample": "%d of the %d models of rank 0's batch, full T=%d, filter+smoother with all outputs, "
-                  "OpenMP over models, %.1f s (C restatement of kalmanfilter.py:236-476, %s)"
-                  % (n, B, T, dt, "-O3 -march=native" if native else "-O3"),
-    }, rel
+    what = "filter+smoother with all outputs" if smooth else "filter + -2 log L only (one objective evaluation per model)"
+    return {"value": n * T / dt, "unit": "model-timesteps/s", "models_per_s": n / dt, "cores": cores, "kind": "port",
+            "sample": "%d of the %d models of rank 0's batch, full T=%d, %s, OpenMP over models, %.1f s "
+                      "(C restatement of kalmanfilter.py:236-476, %s)" % (n, B, T, what, dt,
+                                                                          "-O3 -march=native" if native else "-O3")}, rel
+
+
+def cpu_baseline_reference(host, mode, gpu_mle, models=16, budget_s=25.0):
+    """SURVEY 8d legs (2) and (3): the reference AS SHIPPED -- its numpy engine ``seqkalmanfilter_np`` + the
+    Python ``kalmansmoother`` (kalmanfilter.py:122-233, 403-476), imported from the staged verbatim copy
+    ``oracle/_ref`` through the pastas stub -- on up to 16 models of the same batch, ONE core, extrapolated
+    and labelled so; plus the numba-jitted engine when ``import numba`` works on this box."""
+    import numpy as np
+
+    out = {}
+    try:
+        import numba  # noqa: F401
+
+        out["numba"] = "importable (%s)" % numba.__version__
+    except Exception as e:  # noqa: BLE001
+        out["numba"] = "not importable on this box (%s): the jitted seqkalmanfilter cannot be timed" % type(e).__name__
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    try:
+        import _refshim
+
+        if not _refshim.reference_available():
+            raise ImportError("oracle/_ref not staged (oracle/make_ref.sh)")
+        metran = _refshim.install()
+    except Exception as e:  # noqa: BLE001
+        out["reference"] = "unavailable: %s" % e
+        return out
+    import pandas as pd
+
+    kfm = metran.kalmanfilter
+    N = host["obs"].shape[2]
+    T = host["obs"].shape[1]
+    done, t_f, t_s, rel = 0, 0.0, 0.0, 0.0
+    t_start = time.perf_counter()
+    for b in range(min(models, host["obs"].shape[0])):
+        kf = kfm.SPKalmanFilter(engine="numpy")
+        if "importable (" in out["numba"]:
+            kf.filtermethod = kfm.seqkalmanfilter
+        kf.set_observations(pd.DataFrame(host["obs"][b]))
+        Z = np.hstack([np.eye(N), host["loadings"][b]])
+        kf.set_matrices(np.diag(host["phi"][b]), np.diag(host["q"][b]), Z, np.zeros(N))
+        t0 = time.perf_counter()
+        kf.run_filter()
+        t1 = time.perf_counter()
+        if mode != "solver":
+            kfm.kalmansmoother(kf.filtered_state_means, kf.filtered_state_covariances, kf.predicted_state_means,
+                               kf.predicted_state_covariances, kf.transition_matrix)
+        t2 = time.perf_counter()
+        if b > 0 or models == 1:  # first model pays imports / JIT
+            t_f += t1 - t0
+            t_s += t2 - t1
+            done += 1
+        m = kf.get_mle()
+        rel = max(rel, abs(float(gpu_mle[b]) - m) / abs(m))
+        if time.perf_counter() - t_start > budget_s and done >= 2:
+            break
+    if done:
+        per = (t_f + t_s) / done
+        out["reference"] = {"value": T / per, "unit": "model-timesteps/s", "models_per_s": 1.0 / per, "cores": 1,
+                            "kind": "reference", "filter_s_per_model": t_f / done, "smoother_s_per_model": t_s / done,
+                            "sample": "%d models of rank 0's batch through the reference as shipped (oracle/_ref: %s engine + "
+                                      "Python kalmansmoother), one core, per-model mean; EXTRAPOLATED to a rate"
+                                      % (done, "numba" if "importable (" in out["numba"] else "numpy"),
+                            "loglik_max_rel_err_vs_gpu": rel}
+    return out
+
+
+# --------------------------------------------------------------------------------------- launch plumbing
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_torchrun(n):
+    """``python bench.py --gpus N`` from a plain shell: become ``torch.distributed.run`` with N ranks on this
+    node (rendezvous on 127.0.0.1).  exec keeps the PID, so a driver timing this process times the job."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, argv)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="models per GPU")
-    ap.add_argument("--series", type=int, default=8)
-    ap.add_argument("--factors", type=int, default=2)
-    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="models per GPU (default: the configuration's)")
+    ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--packed-sym", action="store_true",
+                    help="c2/c3: packed-symmetric records (MK_PACKED_SYM; n + n(n+1)/2 doubles per moment set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--loglik-only", action="store_true", help="time the solver objective (no state outputs)")
-    ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"],
-                    help="memory layout of the per-step arrays (see BatchedKalman)")
+    ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU (gloo): launch, barrier, max-over-ranks, one JSON line with value null")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args.gpus)  # does not return
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    B, N, K, T, missing, mode = CONFIGS[args.config]
+    B = args.batch or B
+    T = args.T or T
+    steps = args.steps if args.steps is not None else (10 if mode == "full" else 3)
+    warmup = args.warmup if args.warmup is not None else (3 if mode == "full" else 1)
+
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from metran_amd.engine import BatchedKalman
-    from metran_amd.synthetic import make_dfm_batch_torch
-
-    B, N, K, T = args.batch, args.series, args.factors, args.T
-    n = N + K
-    d = make_dfm_batch_torch(B, N, K, T, seed=2000 + rank, device=dev)
-    kf = BatchedKalman(local_rank, layout=args.layout)
-    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
-    outputs = () if args.loglik_only else ("F", "Pf", "Xp", "Pp", "S", "Ps")
-    bufs = kf._alloc_outputs(B, list(outputs))
-    total = torch.zeros(1, dtype=torch.float64, device=dev)
-
-    def step():
-        if args.loglik_only:
-            kf.loglik(d["phi"], d["q"], out=bufs["mle"])
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            kf.filter_smooth(d["phi"], d["q"], buffers=bufs)
-        s = kf.sum(bufs["mle"])            # deterministic local reduction
-        total.copy_(s.reshape(1))
-        if dist is not None:
-            dist.all_reduce(total)          # RCCL all-reduce of the summed -2 log L (8 bytes)
-        return total
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
 
-    for _ in range(args.warmup):
+    def sync():
+        if not args.dry_run:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    total = torch.zeros(1, dtype=torch.float64, device=dev)
+    bufs = d = kf = None
+    if args.dry_run:
+        def step():
+            total.fill_(float(rank + 1))
+            if dist is not None:
+                dist.all_reduce(total)
+    else:
+        from metran_amd.engine import BatchedKalman
+        from metran_amd.synthetic import make_dfm_batch_torch
+
+        d = make_dfm_batch_torch(B, N, K, T, seed=2000 + rank, device=dev, missing=missing)
+        kf = BatchedKalman(local_rank, layout=args.layout, packed_sym=args.packed_sym)
+        kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+        if mode == "full":
+            bufs = kf._alloc_outputs(B, ["F", "Pf", "Xp", "Pp", "S", "Ps"])
+        elif mode == "project":
+            bufs = kf.alloc_projection(B)
+        else:
+            bufs = {"mle": torch.empty(B, dtype=torch.float64, device=dev)}
+            # the 50 parameter sets of one step: alpha_k = alpha_0 (1 + 0.02 k), SURVEY 8d
+            alphas = [d["alpha"] * (1.0 + 0.02 * k) for k in range(EVALS_PER_STEP)]
+
+        def step():
+            if mode == "full":
+                kf.filter_smooth(d["phi"], d["q"], buffers=bufs)
+            elif mode == "project":
+                kf.simulate_smoothed(d["phi"], d["q"], buffers=bufs)
+            else:
+                for a in alphas:  # a2 + a3 + a6 per evaluation, as Metran.get_mle does (metran.py:605-622)
+                    phi, q = kf.params_from_alpha(a)
+                    kf.loglik(phi, q, out=bufs["mle"])
+            s = kf.sum(bufs["mle"])            # deterministic local reduction
+            total.copy_(s.reshape(1))
+            if dist is not None and mode != "solver":
+                dist.all_reduce(total)          # RCCL all-reduce of the summed -2 log L (8 bytes)
+            return total
+
+    for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    kf.enable_timing(True)
-    torch.cuda.synchronize()
+    sync()
+    if kf is not None:
+        kf.enable_timing(True)
+        torch.cuda.synchronize()
     filt_ms, smooth_ms = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-        f_ms, s_ms = kf.last_kernel_ms()   # hipEvents on the launch stream
-        filt_ms.append(f_ms)
-        smooth_ms.append(s_ms)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+        if kf is not None:
+            f_ms, s_ms = kf.last_kernel_ms()   # hipEvents on the launch stream
+            filt_ms.append(f_ms)
+            smooth_ms.append(s_ms)
+    sync()
     elapsed = time.perf_counter() - t0
-    kf.enable_timing(False)
+    if kf is not None:
+        kf.enable_timing(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    nranks = torch.ones(1, dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nranks)  # ranks that actually took part in the collective
     elapsed = float(el.item())
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        models_per_s = world * B * args.steps / elapsed
-        fb, sb = algorithmic_bytes(N, K, T)
-        f_avg = float(np.mean(filt_ms))
-        s_avg = float(np.mean(smooth_ms)) if not args.loglik_only else 0.0
-        kernels = {"filter_kernel": {"ms": f_avg, "algorithmic_GB": fb * B / 1e9,
-                                     "GBps": fb * B / 1e9 / (f_avg / 1e3)}}
-        if not args.loglik_only:
-            kernels["smoother_record_kernel"] = {"ms": s_avg, "algorithmic_GB": sb * B / 1e9,
-                                          "GBps": sb * B / 1e9 / (s_avg / 1e3)}
-        for kname in kernels:
-            tr = pmc_traffic(kname, B, N, K, T, args.layout)
-            kernels[kname]["traffic_GB"] = tr["GB"] if tr else None
-            if tr:
-                kernels[kname]["traffic_source"] = tr["source"]
-        dom = max(kernels, key=lambda k: kernels[k]["ms"])
-        if args.loglik_only:
-            kernels["filter_kernel"]["algorithmic_GB"] = 8 * T * N * B / 1e9
-            kernels["filter_kernel"]["GBps"] = 8 * T * N * B / 1e9 / (f_avg / 1e3)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
-                    "traffic": (kernels[dom]["traffic_GB"] * 1e9 if kernels[dom].get("traffic_GB") else None),
-                    "algorithmic_bytes": kernels[dom]["algorithmic_GB"] * 1e9,
-                    "avg_launch_ms": kernels[dom]["ms"], "kernels": kernels,
-                    "path_achieved_GBps": (fb + sb) * B / 1e9 / ((f_avg + s_avg) / 1e3) if not args.loglik_only else None}
+        units = EVALS_PER_STEP if mode == "solver" else 1     # model passes per step
+        ms_per_step = 1e3 * elapsed / steps
+        models_per_s = world * B * units * steps / elapsed
+        workload = ("BASELINE.json %s: batch=%d synthetic %d-series/%d-factor DFMs per GPU, T=%d, fp64, %s"
+                    % (BASELINE_NAME[args.config], B, N, K, T,
+                       {"full": "filter+smoother, outputs F,Pf,Xp,Pp,S,Ps" + (" as packed-symmetric records" if args.packed_sym else ""),
+                        "project": "%d %% missing, filter (filtered record) + smoother with fused projection (sim_means, sim_vars)" % round(100 * missing),
+                        "solver": "solver loop: %d objective evaluations (alpha -> phi,q -> filter -> -2 log L) per step" % EVALS_PER_STEP}[mode]))
         res = {
             "metric": "Kalman filter+smoother steps/sec (batched DFMs)",
-            "value": models_per_s * T,
+            "value": None if args.dry_run else models_per_s * T,
             "unit": "model-timesteps/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch=%d synthetic %d-series/%d-factor DFMs per GPU, "
-                                   "T=%d, fp64%s" % (B, N, K, T, ", loglik only" if args.loglik_only else
-                                                     ", filter+smoother, outputs F,Pf,Xp,Pp,S,Ps"),
-                       "batch_per_gpu": B, "series": N, "factors": K, "T": T, "parallelism": "dp%d" % world,
-                       "layout": args.layout},
-            "models_per_s": models_per_s,
-            "models_per_s_per_gpu": models_per_s / world,
-            "roofline": roofline,
+            "config": {"workload": workload, "name": args.config, "batch_per_gpu": B, "series": N, "factors": K, "T": T,
+                       "parallelism": "dp%d" % world, "layout": args.layout, "packed_sym": bool(args.packed_sym)},
+            "rccl_ranks": int(nranks.item()),
         }
-        if world == 1 and not args.no_cpu_baseline and not args.loglik_only:
-            host = {k: d[k].cpu().numpy() for k in ("obs", "phi", "q", "loadings")}
-            base, rel = cpu_baseline(host, bufs["mle"].cpu().numpy())
-            res["cpu_baseline"] = base
-            res["loglik_max_rel_err"] = rel
-            res["speedup_vs_cpu_baseline"] = res["value"] / base["value"]
+        if args.dry_run:
+            res["dry_run"] = "plumbing only (gloo, no kernels): not a measurement"
+            res["allreduce_check"] = float(total.item())
+        else:
+            res["models_per_s"] = models_per_s
+            res["models_per_s_per_gpu"] = models_per_s / world
+            ab = algorithmic_bytes(N, K, T, mode, sym=args.packed_sym)
+            f_avg = float(np.mean(filt_ms))
+            s_avg = float(np.mean(smooth_ms)) if mode != "solver" else 0.0
+            fname = "filter_kernel"
+            sname = {"full": "smoother_record_kernel", "project": "smoother_wave_kernel" if N + K > 16 else "smoother_record_kernel"}.get(mode)
+            kernels = {fname: {"ms": f_avg, "algorithmic_GB": ab["filter"] * B / 1e9, "GBps": ab["filter"] * B / 1e9 / (f_avg / 1e3)}}
+            if sname:
+                kernels[sname] = {"ms": s_avg, "algorithmic_GB": ab["smoother"] * B / 1e9, "GBps": ab["smoother"] * B / 1e9 / (s_avg / 1e3)}
+            for kname in kernels:
+                tr, note = pmc_traffic(args.config, kname, args.packed_sym)
+                kernels[kname]["traffic_GB"] = tr["GB"] if tr else None
+                kernels[kname]["traffic_source" if tr else "traffic_note"] = tr["source"] if tr else note
+            dom = max(kernels, key=lambda k: kernels[k]["ms"])
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
+                        "traffic": (kernels[dom]["traffic_GB"] * 1e9 if kernels[dom].get("traffic_GB") else None),
+                        "algorithmic_bytes": kernels[dom]["algorithmic_GB"] * 1e9, "avg_launch_ms": kernels[dom]["ms"],
+                        "kernels": kernels, "kernel_source_sha256": kernel_source_sha(),
+                        "path_achieved_GBps": sum(ab.values()) * B / 1e9 / ((f_avg + s_avg) / 1e3)}
+            # SURVEY 8d's full-output accounting B_fs = 8 T (N + 4c) per model, for every configuration (what the
+            # north-star's ">= 40 % of HBM" is quoted in; the path may move fewer bytes, e.g. the projection path)
+            n = N + K
+            b_fs = 8 * T * (N + 4 * (n + n * n))
+            if mode != "solver":
+                roofline["survey_8d_full_output_accounting"] = {
+                    "bytes_per_model": b_fs, "equivalent_GBps": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3),
+                    "frac_of_peak": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3) / HBM_PEAK_GBS,
+                    "note": "kernel-time rate of this GPU x bytes a full-square six-output pass would move"}
+            else:
+                roofline["note"] = ("the solver objective is not HBM-bound (AI ~ 75 flop/B, SURVEY 8d): bound by fp64 VALU issue; "
+                                    "the HBM fraction is reported for completeness")
+            res["roofline"] = roofline
+            if world == 1 and not args.no_cpu_baseline:
+                if mode == "solver":
+                    ph, qq = kf.params_from_alpha(alphas[-1])
+                    host = {"obs": d["obs"].cpu().numpy(), "phi": ph.cpu().numpy(), "q": qq.cpu().numpy(),
+                            "loadings": d["loadings"].cpu().numpy()}
+                else:
+                    host = {k: d[k].cpu().numpy() for k in ("obs", "phi", "q", "loadings")}
+                gpu_mle = bufs["mle"].cpu().numpy()
+                base, rel = cpu_baseline_port(host, mode, gpu_mle)
+                res["cpu_baseline"] = base
+                res["loglik_max_rel_err"] = rel
+                res["speedup_vs_cpu_baseline"] = res["value"] / base["value"]
+                res["cpu_baseline_reference_as_shipped"] = cpu_baseline_reference(host, mode, gpu_mle)
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -55,8 +55,11 @@ typedef enum mk_status {
 
 /* per-instance status bits written to mk_outputs.d_status */
 #define MK_FLAG_NONPOSITIVE_F 1u /* an innovation variance f <= 0 was met in the filter    */
-#define MK_FLAG_NOT_SPD 2u       /* predicted covariance not numerically SPD in the smoother
-                                    (reference would take the pinv branch, kalmanfilter.py:455) */
+#define MK_FLAG_NOT_SPD 2u       /* ERROR: predicted covariance indefinite in the smoother (an LDL^T
+                                    pivot < -1e-8); the smoothed moments of that instance are invalid */
+#define MK_FLAG_RANK_DEFICIENT 4u /* INFO: a pivot <= 0 was met and that null direction dropped, as
+                                    numpy.linalg.pinv does in the reference (kalmanfilter.py:455): q_i = 0
+                                    for a series with communality 1 (metran.py:314-316).  Results valid. */
 
 typedef struct mk_context mk_context; /* opaque; one per (process, device) */
 

@@ -333,7 +333,7 @@ __device__ __forceinline__ void project(double x, const double (&P)[N + K], cons
     });
     mean = fma(scale, m, offset);
     const double v = scale * scale * (diag + t);
-    var = v > 0.0 ? v : 0.0; // :601-602
+    var = v < 0.0 ? 0.0 : v; // :601-602 (np.maximum keeps a NaN)
 }
 
 // log of a frexp-normalised mantissa m in [0.5, 1) as log(m) = e ln2 + l with e in {-1, 0}:
@@ -727,6 +727,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 //   whenever q > 0, where the reference's pinv (:455) is the inverse); lane i solves for ROW i of J.
 //   The factor is DISTRIBUTED: lane c keeps L(c, 0..c-1) in place of its row of A.
 // =====================================================================================
+// A = L D L^T of the predicted covariance, right-looking and distributed: lane c ends up holding L(c, j) in
+// A[j] for j < c, dinv[j] = 1/d_j.  The reference inverts Pp with numpy.linalg.pinv (kalmanfilter.py:455),
+// which drops (numerically) null directions; an LDL^T pivot d_j <= 0 is such a direction (q_j = 0 when a
+// series has communality 1, metran.py:314-316, and its state variance has decayed to rounding level).
+// GUARD = false is the hot path (no test per stage; the caller checks `pivmin` once per step);
+// GUARD = true re-factorises with 1/d_j := 0 and L(., j) := 0 for d_j <= 0 -- the generalised inverse
+// L^-T D^+ L^-1, which acts like pinv on range(Pp), where J's operands live.  Positive pivots, however
+// small, are inverted: measured against 60-digit arithmetic (tests/golden/heywood.npz) that is MORE accurate
+// than the reference's truncation (1e-14 vs 7e-8 on the smoothed means at cond(Pp) = 1e17).
+template <int n, int G, bool GUARD>
+__device__ __forceinline__ void ldlt_factor(double (&A)[n], double (&dinv)[n], double &pivmin)
+{
+    using Gp = Group<G>;
+    sfor<0, n>(MK_LAMBDA(jc) {
+        constexpr int j = decltype(jc)::value;
+        const double piv = Gp::template bcast<j>(A[j]); // d_j
+        pivmin = min_f64(pivmin, piv);
+        double ij = rcp_nr(piv);
+        if constexpr (GUARD) ij = piv > 0.0 ? ij : 0.0;
+        dinv[j] = ij;
+        const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
+        // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
+        Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+        A[j] = lr;
+    });
+}
+// status bits of a smoother instance from the smallest pivot it met (covariances of standardised series are
+// O(1): -1e-8 is far outside rounding)
+__device__ __forceinline__ unsigned pivot_flags(double pivmin)
+{
+    unsigned f = 0u;
+    if (!(pivmin > 0.0)) f |= MK_FLAG_RANK_DEFICIENT;
+    if (!(pivmin >= -1e-8)) f |= MK_FLAG_NOT_SPD;
+    return f;
+}
+
 // ---------------------------------------------------------------- packed-record I/O through LDS (smoother)
 // The smoother both reads and writes a record per step; moving whole 16-byte chunks of the
 // wavefront's GW adjacent records (lane l <-> chunks l, l+64, ...) and transposing through a
@@ -946,17 +982,13 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
         // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
         if constexpr (G == 16) dpp_guard(A); // A is compiler-produced (build-time hazard check)
         double dinv[n];
-        sfor<0, n>(MK_LAMBDA(jc) {
-            constexpr int j = decltype(jc)::value;
-            const double piv = Gp::template bcast<j>(A[j]); // d_j
-            pivmin = min_f64(pivmin, piv);
-            const double ij = rcp_nr(piv);
-            dinv[j] = ij;
-            const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
-            // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
-            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
-            A[j] = lr;
-        });
+        ldlt_factor<n, G, false>(A, dinv, pivmin);
+        if (__builtin_expect(__ballot(!(pivmin > 0.0)) != 0ull, 0)) { // a null direction (cold): pinv-like redo
+#pragma unroll
+            for (int c = 0; c < n; ++c) A[c] = fma(phi_r, z[c], qd[c]);
+            if constexpr (G == 16) dpp_guard(A);
+            ldlt_factor<n, G, true>(A, dinv, pivmin);
+        }
 
         // ---- lane i solves A z = W_i  (row i of J = Pf Phi^T A^{-1}, :458-460) ----
         sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
@@ -1012,7 +1044,7 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
         store(xs, Psn);
         xfc = xf_next;
     }
-    if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
+    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
 
@@ -1084,17 +1116,13 @@ __global__ void __launch_bounds__(256) smoother_dense_kernel(SmootherArgs a)
         // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
         if constexpr (G == 16) dpp_guard(A); // A is compiler-produced (build-time hazard check)
         double dinv[n];
-        sfor<0, n>(MK_LAMBDA(jc) {
-            constexpr int j = decltype(jc)::value;
-            const double piv = Gp::template bcast<j>(A[j]); // d_j
-            pivmin = min_f64(pivmin, piv);
-            const double ij = rcp_nr(piv);
-            dinv[j] = ij;
-            const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
-            // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
-            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
-            A[j] = lr;
-        });
+        ldlt_factor<n, G, false>(A, dinv, pivmin);
+        if (__builtin_expect(__ballot(!(pivmin > 0.0)) != 0ull, 0)) { // a null direction (cold): pinv-like redo
+#pragma unroll
+            for (int c = 0; c < n; ++c) A[c] = fma(phi_r, z[c], qd[c]);
+            if constexpr (G == 16) dpp_guard(A);
+            ldlt_factor<n, G, true>(A, dinv, pivmin);
+        }
 
         // ---- lane i solves A z = W_i  (row i of J = Pf Phi^T A^{-1}, :458-460) ----
         sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
@@ -1148,7 +1176,7 @@ __global__ void __launch_bounds__(256) smoother_dense_kernel(SmootherArgs a)
         for (int c = 0; c < n; ++c) Pfc[c] = Pfn[c];
         xfc = xfn;
     }
-    if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
+    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
 // =====================================================================================
@@ -1271,7 +1299,7 @@ smoother_wave_kernel(SmootherArgs a)
             constexpr int j = decltype(jc)::value;
             const double piv = Gp::template bcast<j>(A[j]);
             pivmin = min_f64(pivmin, piv);
-            const double ij = rcp_nr(piv);
+            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_j <= 0: null direction dropped (see ldlt_factor)
             const double lr = A[j] * ij;
             Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
             A[j] = j == lane ? ij : lr;
@@ -1348,7 +1376,7 @@ smoother_wave_kernel(SmootherArgs a)
         for (int c = 0; c < n; ++c) Psn[c] += Pfc[c];
         store(xs, Psn);
     }
-    if (a.status && live && lane == 0 && !(pivmin > 0.0)) atomicOr(a.status + inst, MK_FLAG_NOT_SPD);
+    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
 // =====================================================================================
@@ -1751,7 +1779,7 @@ __global__ void simulate_kernel(long B, long RZ, long T, int N, int n, const dou
             for (int c = 0; c < n; ++c) s += P[rr * n + c] * z[c];
             v += z[rr] * s;
         }
-        sim_vars[i] = v > 0.0 ? v : 0.0;
+        sim_vars[i] = v < 0.0 ? 0.0 : v; // np.maximum(., 0) keeps a NaN (:601-602)
     }
 }
 

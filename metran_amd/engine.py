@@ -15,10 +15,11 @@ import numpy as np
 from . import _lib
 from ._lib import MetranHipError, Outputs, Problem, check
 
-__all__ = ["BatchedKalman", "MetranHipError", "FLAG_NONPOSITIVE_F", "FLAG_NOT_SPD"]
+__all__ = ["BatchedKalman", "MetranHipError", "FLAG_NONPOSITIVE_F", "FLAG_NOT_SPD", "FLAG_RANK_DEFICIENT"]
 
 FLAG_NONPOSITIVE_F = 1
 FLAG_NOT_SPD = 2
+FLAG_RANK_DEFICIENT = 4  # informational: a null direction of Pp was dropped, as the reference's pinv does
 
 _STATE_OUTPUTS = ("F", "Pf", "Xp", "Pp", "S", "Ps")
 
@@ -46,7 +47,7 @@ class BatchedKalman:
         out = kf.filter_smooth(phi, q)      # dict of device tensors F,Pf,Xp,Pp,S,Ps,mle,...
     """
 
-    def __init__(self, device=None, layout="model_major"):
+    def __init__(self, device=None, layout="model_major", packed_sym=False):
         """layout: "model_major" -- per-step arrays are ``[B,T,...]`` contiguous (the reference's
         per-model arrays stacked); "time_major" -- the memory is ``[T,B,...]`` (one time step of all
         models contiguous: every wavefront's stores land next to its neighbours', which is what HBM
@@ -55,6 +56,7 @@ class BatchedKalman:
         if layout not in ("model_major", "time_major"):
             raise ValueError("layout must be 'model_major' or 'time_major'")
         self.time_major = layout == "time_major"
+        self.packed_sym = bool(packed_sym)
         L = _lib.lib()  # raises MetranHipError when the HIP library is not built
         if not torch.cuda.is_available():
             raise MetranHipError("no GPU visible to PyTorch-ROCm; metran_amd has no CPU fallback")
@@ -414,20 +416,26 @@ class BatchedKalman:
         self.scale, self.offset = prep(scale), prep(offset)
         return self
 
-    def simulate_smoothed(self, phi, q, warmup=1, x0=None, P0=None):
-        """``Metran.get_simulated_means/variances(method="smoother")`` for B instances in two launches
-        WITHOUT materialising the smoothed states: the filter writes only the filtered records, the
-        smoother reads them and writes the projected means/variances ``[B,T,N]`` (fused epilogue,
-        kalmanfilter.py:569-603 with the scaling set by ``set_scaling``).  Returns a dict with
-        ``sim_means, sim_vars, mle, sigmacount, status`` (and the filtered views ``F, Pf``)."""
+    def alloc_projection(self, B):
+        """Buffers of ``simulate_smoothed`` for B instances (filtered record array + projected moments), for
+        callers that run it repeatedly (pass them back as ``buffers=``)."""
         torch = _torch()
-        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         res = {"mle": torch.empty(B, dtype=torch.float64, device=self.device),
                "status": torch.zeros(B, dtype=torch.int32, device=self.device),
                "sigmacount": torch.empty(B, dtype=torch.int64, device=self.device), "_rs": self.record_stride()}
         res["_rec_filt"], res["F"], res["Pf"], res["sigmas"], res["detfs"] = self._alloc_records(B)
         res["sim_means"] = self._empty_bt(B, self.T, self.N)
         res["sim_vars"] = self._empty_bt(B, self.T, self.N)
+        return res
+
+    def simulate_smoothed(self, phi, q, warmup=1, x0=None, P0=None, buffers=None):
+        """``Metran.get_simulated_means/variances(method="smoother")`` for B instances in two launches
+        WITHOUT materialising the smoothed states: the filter writes only the filtered records, the
+        smoother reads them and writes the projected means/variances ``[B,T,N]`` (fused epilogue,
+        kalmanfilter.py:569-603 with the scaling set by ``set_scaling``).  Returns a dict with
+        ``sim_means, sim_vars, mle, sigmacount, status`` (and the filtered views ``F, Pf``)."""
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        res = buffers if buffers is not None else self.alloc_projection(B)
         o = self._outputs_struct(res)
         self._bind_stream()
         check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))

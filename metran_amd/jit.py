@@ -79,7 +79,13 @@ def build_shape_module(N, K):
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise MetranHipError("link failed for shape (%d,%d):\n%s" % (N, K, r.stderr[-2000:]))
-        os.replace(so, out) if os.path.dirname(out) == tmp else shutil.move(so, out)
+        # publish atomically: every rank of a multi-GPU job builds the same shape at the same moment, and a
+        # reader must never dlopen a half-written file (temp file INSIDE the cache directory + rename)
+        fd, stage = tempfile.mkstemp(prefix=".mk_shape_", suffix=".so", dir=cache_dir())
+        os.close(fd)
+        shutil.copyfile(so, stage)
+        os.chmod(stage, 0o755)
+        os.replace(stage, out)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out

@@ -29,6 +29,40 @@ __all__ = ["seqkalmanfilter_hip", "kalmansmoother_hip", "SPKalmanFilter", "insta
            "observations_to_nan_encoded", "MetranHipError"]
 
 _ENGINE = None
+# (F array returned to the caller, phi, q, device results) of the most recent seqkalmanfilter_hip call: the
+# reference hands that very array object to kalmansmoother (kalmanfilter.py:685-691), which has no q argument
+_LAST_FILTER = None
+
+
+def check_status(status, where):
+    """Surface the per-instance status bits of a launch (``mk_outputs.d_status``).
+
+    The reference fails loudly with ``logger.error`` + ``raise Exception`` (kalmanfilter.py:733-745) or, for
+    a non-positive innovation variance, silently returns NaN/inf; here both error bits raise
+    ``MetranHipError`` (a subclass of ``Exception``).  ``FLAG_RANK_DEFICIENT`` is not an error: the
+    reference's ``pinv`` (:455) drops null directions of the predicted covariance too; it is logged."""
+    from .engine import FLAG_NONPOSITIVE_F, FLAG_NOT_SPD, FLAG_RANK_DEFICIENT
+
+    st = status.cpu().numpy() if hasattr(status, "cpu") else np.asarray(status)
+    bits = int(np.bitwise_or.reduce(st.astype(np.int64).ravel())) if st.size else 0
+    if bits & FLAG_NONPOSITIVE_F:
+        bad = np.nonzero(st & FLAG_NONPOSITIVE_F)[0]
+        msg = ("%s: an innovation variance f <= 0 (or NaN) was met in the Kalman filter for %d model(s) "
+               "(first: %d); with zero observation variance this means linearly dependent series"
+               % (where, bad.size, int(bad[0])))
+        logger.error(msg)
+        raise MetranHipError(msg)
+    if bits & FLAG_NOT_SPD:
+        bad = np.nonzero(st & FLAG_NOT_SPD)[0]
+        msg = ("%s: the predicted state covariance is indefinite (pivot < -1e-8) for %d model(s) "
+               "(first: %d); the smoother cannot continue" % (where, bad.size, int(bad[0])))
+        logger.error(msg)
+        raise MetranHipError(msg)
+    if bits & FLAG_RANK_DEFICIENT:
+        logger.info("%s: singular predicted covariance for %d model(s): null directions dropped "
+                    "(as numpy.linalg.pinv does in the reference smoother)", where,
+                    int(np.count_nonzero(st & FLAG_RANK_DEFICIENT)))
+    return bits
 
 
 def get_engine():
@@ -91,9 +125,13 @@ def seqkalmanfilter_hip(observations, transition_matrix, transition_covariance, 
     x0 = np.asarray(filtered_state_mean, dtype=np.float64)[None]
     P0 = np.asarray(filtered_state_covariance, dtype=np.float64)[None]
     r = kf.filter(phi[None], q[None], warmup=1, x0=x0, P0=P0)
+    check_status(r["status"], "seqkalmanfilter_hip")
     sc = int(r["sigmacount"][0].item())
     cpu = lambda k: r[k][0].cpu().numpy()  # noqa: E731
-    return (cpu("sigmas"), cpu("detfs"), sc, cpu("F"), cpu("Pf"), cpu("Xp"), cpu("Pp"))
+    out = (cpu("sigmas"), cpu("detfs"), sc, cpu("F"), cpu("Pf"), cpu("Xp"), cpu("Pp"))
+    global _LAST_FILTER
+    _LAST_FILTER = (out[3], out[4], phi.copy(), q.copy(), r)
+    return out
 
 
 def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predicted_state_means,
@@ -101,19 +139,35 @@ def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predict
     """Drop-in for ``kalmansmoother`` (metran/kalmanfilter.py:403-476): 5 arguments ->
     ``(smoothed_state_means, smoothed_state_covariances)``.
 
-    The kernel recomputes the predicted moments from the filtered ones; the transition
-    variances it needs are recovered from the arguments as
-    ``q = diag(Pp[1]) - phi**2 * diag(Pf[0])`` (exact up to one rounding)."""
-    F = np.ascontiguousarray(filtered_state_means, dtype=np.float64)
-    Pf = np.ascontiguousarray(filtered_state_covariances, dtype=np.float64)
-    Pp = np.asarray(predicted_state_covariances, dtype=np.float64)
+    The kernel recomputes the predicted moments from the filtered ones and needs the transition
+    variances q, which are not among the five arguments.  The reference calls this function with the
+    very arrays the preceding engine call returned (``run_smoother``, :676-694), so q (and the
+    filtered moments still resident on the device) are remembered from that call.  Only for arrays of
+    unknown origin q is recovered as ``diag(Pp[t+1]) - phi**2 * diag(Pf[t])`` from the step where that
+    difference is largest relative to its operands (cancellation: relative error ~ eps * Pp/q)."""
     phi = _diag_only(transition_matrix, "transition_matrix")
-    T, n = F.shape
-    if T < 2:
-        return F.copy(), Pf.copy()
-    q = np.diag(Pp[1]) - phi * np.diag(Pf[0]) * phi
+    last = _LAST_FILTER
     kf = get_engine()
-    r = kf.smooth(phi[None], q[None], F[None], Pf[None])
+    if (last is not None and filtered_state_means is last[0] and filtered_state_covariances is last[1]
+            and np.array_equal(phi, last[2])):
+        T = last[0].shape[0]
+        if T < 2:
+            return last[0].copy(), last[1].copy()
+        rf = last[4]
+        r = kf.smooth(phi[None], last[3][None], rf["F"], rf["Pf"])
+    else:
+        F = np.ascontiguousarray(filtered_state_means, dtype=np.float64)
+        Pf = np.ascontiguousarray(filtered_state_covariances, dtype=np.float64)
+        Pp = np.asarray(predicted_state_covariances, dtype=np.float64)
+        T, n = F.shape
+        if T < 2:
+            return F.copy(), Pf.copy()
+        dPp = np.diagonal(Pp[1:], axis1=1, axis2=2)
+        dPf = np.diagonal(Pf[:-1], axis1=1, axis2=2) * phi * phi
+        best = np.argmin(dPp / np.maximum(dPp - dPf, 1e-300), axis=0)  # least cancellation per state
+        q = np.maximum((dPp - dPf)[best, np.arange(n)], 0.0)
+        r = kf.smooth(phi[None], q[None], F[None], Pf[None])
+    check_status(r["status"], "kalmansmoother_hip")
     return r["S"][0].cpu().numpy(), r["Ps"][0].cpu().numpy()
 
 
@@ -174,7 +228,7 @@ class SPKalmanFilter:
         packed = np.where(np.arange(dimobs)[None, :] < self.observation_count[:, None], order, 0)
         self.observation_indices = packed.astype(np.float64)
         self._obs_nan = np.where(valid, y, np.nan)
-        self._uploaded = False
+        self._obs_dev = None  # device copy, uploaded once per set_observations (not per run_filter)
 
     def _engine(self):
         if self._kf is None:
@@ -186,7 +240,11 @@ class SPKalmanFilter:
         phi = _diag_only(self.transition_matrix, "transition_matrix")
         q = _diag_only(self.transition_covariance, "transition_covariance")
         loadings = _split_observation_matrix(self.observation_matrix)
-        kf.set_observations(self._obs_nan[None])
+        if self._obs_dev is None:
+            kf.set_observations(self._obs_nan[None])
+            self._obs_dev = kf.obs
+        else:
+            kf.set_observations(self._obs_dev)  # already resident: no host-to-device copy
         kf.set_loadings(loadings[None], np.asarray(self.observation_variance, dtype=np.float64)[None])
         return kf, phi, q
 
@@ -203,6 +261,7 @@ class SPKalmanFilter:
         self._store_filter(r)
 
     def _store_filter(self, r):
+        check_status(r["status"], "SPKalmanFilter")
         sc = int(r["sigmacount"][0].item())
         self.sigmas = r["sigmas"][0, :sc].cpu().numpy()
         self.detfs = r["detfs"][0, :sc].cpu().numpy()

@@ -22,7 +22,7 @@ import numpy as np
 
 logger = logging.getLogger(__name__)
 
-__all__ = ["HipSolve", "BatchObjective"]
+__all__ = ["HipSolve", "HipSolveAdjoint", "BatchObjective"]
 
 
 class BatchObjective:
@@ -152,8 +152,9 @@ class HipSolve:
         vidx = np.nonzero(self.vary)[0]
         for i in range(P):
             full[i + 1, vidx[i]] += h[i]
+        dx = full[np.arange(1, P + 1), vidx] - full[0, vidx]  # the REALISED step (x + h) - x, as scipy divides
         f = self._objective()(full)
-        return float(f[0]), (f[1:] - f[0]) / h
+        return float(f[0]), (f[1:] - f[0]) / dx
 
     # ------------------------------------------------------------------ solve
     def solve(self, method="l-bfgs-b", **kwargs):
@@ -201,7 +202,26 @@ class HipSolve:
         self.aic = 2 * parameters.shape[0] + self.result.fun
         self.obj_func = self.result.fun
         success = self.result.success if hasattr(self.result, "success") else True
+        self._leave_filter_at(optimal)
         return success, optimal, stderr
+
+    def _leave_filter_at(self, optimal):
+        """The reference's solver evaluates ``Metran.get_mle`` (metran/metran.py:619-621), so when it returns
+        ``mt.kf`` holds the matrices of the last evaluated point and a filter run; ``Metran.solve`` then
+        stores the optimum and the default-``p`` accessors (``get_state_means()``, ``get_simulation(name)``,
+        ``decompose_simulation(name)``: ``_run_kalman(p=None)``, :978-989) run the smoother on whatever
+        ``mt.kf`` holds.  This solver never touches ``mt.kf`` while iterating, so the optimum is pushed into
+        it here (one B=1 filter run through the model's own engine)."""
+        mt = self.mt
+        if not (hasattr(mt, "_get_matrices") and getattr(mt, "kf", None) is not None):
+            return
+        from pandas import Series
+
+        p = Series(optimal, index=mt.parameters.index)
+        mt.kf.set_matrices(*mt._get_matrices(p))
+        if hasattr(mt.kf, "init_states"):
+            mt.kf.init_states()  # results of an earlier solve are stale (metran.py:984, 989 test for None)
+        mt.kf.run_filter()
 
     # ------------------------------------------------------------------ covariance helpers
     def _get_covariance_adjoint(self, x0, rel_step=1e-5):
@@ -258,10 +278,33 @@ class HipSolve:
                 hessian[j, : j + 1] = hessian[: j + 1, j]
             if not np.isnan(hessian).any():
                 cov = np.linalg.pinv(hessian)
+                if np.amin(np.diag(cov)) <= 0:  # the reference's repair step (:127-133)
+                    try:
+                        cov = np.linalg.pinv(self._nearPSD(hessian))
+                    except Exception as e:  # noqa: BLE001 -- as the reference: keep going with the raw pinv
+                        logger.debug("Could not calculate 'cov': %s", e)
                 if np.amin(np.diag(cov)) > 0:
                     return cov
             epsilon *= 10.0
+        if cov is None:
+            msg = "HipSolve: the finite-difference Hessian is NaN at every step size; no covariance of the estimates"
+            logger.error(msg)
+            raise Exception(msg)
+        logger.warning("HipSolve: covariance of the estimates has a non-positive diagonal (stderr will hold NaN)")
         return cov
+
+    @staticmethod
+    def _nearPSD(A, epsilon=0.0):
+        """Nearest positive semi-definite matrix in the sense of ``BaseSolver._nearPSD``
+        (metran/solver.py:167-192): clip the eigenvalues at ``epsilon`` and rescale the rows so that the
+        diagonal is preserved where that is possible."""
+        A = np.asarray(A, dtype=np.float64)
+        w, V = np.linalg.eigh(0.5 * (A + A.T))
+        w = np.maximum(w, epsilon)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = 1.0 / ((V * V) @ w)
+            B = (np.sqrt(t)[:, None] * V) * np.sqrt(w)[None, :]
+        return B @ B.T
 
     @staticmethod
     def _get_correlations(pcov):
@@ -270,3 +313,15 @@ class HipSolve:
         pcor = pcov.copy()
         pcor.loc[:, :] = pcov.values / np.outer(d, d)
         return pcor
+
+
+class HipSolveAdjoint(HipSolve):
+    """``HipSolve`` with the exact (adjoint) gradient, as a CLASS: ``Metran.solve`` tests
+    ``issubclass(solver, ...)`` (metran/metran.py:1033), so a lambda or ``functools.partial`` cannot be
+    passed -- ``mt.solve(solver=HipSolveAdjoint)``."""
+
+    _name = "HipSolveAdjoint"
+
+    def __init__(self, mt, **kwargs):
+        kwargs.pop("gradient", None)
+        super().__init__(mt, gradient="adjoint", **kwargs)

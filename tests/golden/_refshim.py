@@ -20,7 +20,18 @@ import types
 
 import numpy as np
 
-REFERENCE_ROOT = os.environ.get("METRAN_REFERENCE_ROOT", "/root/reference")
+_STAGED = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref")
+
+
+def _default_root():
+    """The reference itself where it is mounted (build container), else the verbatim copy that
+    ``oracle/make_ref.sh`` staged into the git-ignored ``oracle/_ref`` (travels to the GPU box)."""
+    if os.path.isdir("/root/reference/metran"):
+        return "/root/reference"
+    return _STAGED
+
+
+REFERENCE_ROOT = os.environ.get("METRAN_REFERENCE_ROOT") or _default_root()
 
 
 def reference_available():

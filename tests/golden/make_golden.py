@@ -245,6 +245,122 @@ def g2_seeded():
     print("g2_seeded mle", mle, "loadings", mt.factors.ravel())
 
 
+def exact_filter_smoother(y, phi, q, loadings, P0=None, dead=(), digits=60):
+    """The same recursions (kalmanfilter.py:236-400, 403-476) in ``digits``-digit arithmetic (mpmath, a
+    build-container-only dependency of THIS script): what the reference would return without rounding.
+    ``dead`` lists states whose variance is exactly zero throughout (their rows/columns of Pp are exactly
+    zero; the pseudo-inverse of :455 is then the inverse on the remaining states)."""
+    import mpmath as mp
+
+    mp.mp.dps = digits
+    T, N = y.shape
+    n = phi.shape[0]
+    ph = [mp.mpf(float(v)) for v in phi]
+    qq = [mp.mpf(float(v)) for v in q]
+    Z = observation_matrix(loadings)
+    Zm = [[mp.mpf(float(Z[j, c])) for c in range(n)] for j in range(N)]
+    x = [mp.mpf(0)] * n
+    P = [[mp.mpf(float((np.eye(n) if P0 is None else P0)[r, c])) for c in range(n)] for r in range(n)]
+    F, Pf = [], []
+    for t in range(T):
+        x = [ph[r] * x[r] for r in range(n)]
+        P = [[ph[r] * ph[c] * P[r][c] + (qq[r] if r == c else 0) for c in range(n)] for r in range(n)]
+        for j in range(N):
+            if not np.isfinite(y[t, j]):
+                continue
+            z = Zm[j]
+            v = mp.mpf(float(y[t, j])) - sum(z[c] * x[c] for c in range(n))
+            d = [sum(P[r][c] * z[c] for c in range(n)) for r in range(n)]
+            f = sum(z[c] * d[c] for c in range(n))
+            k = [d[r] / f for r in range(n)]
+            x = [x[r] + k[r] * v for r in range(n)]
+            P = [[P[r][c] - k[r] * d[c] for c in range(n)] for r in range(n)]
+        F.append(list(x))
+        Pf.append([row[:] for row in P])
+    live = [i for i in range(n) if i not in dead]
+    m = len(live)
+    S = [None] * T
+    Ps = [None] * T
+    S[T - 1] = mp.matrix(F[T - 1])
+    Ps[T - 1] = mp.matrix(Pf[T - 1])
+    Phi = mp.diag(ph)
+    Q = mp.diag(qq)
+    for t in range(T - 2, -1, -1):
+        Pft, Ft = mp.matrix(Pf[t]), mp.matrix(F[t])
+        A = Phi * Pft * Phi + Q
+        Al = mp.matrix(m, m)
+        for a_, i in enumerate(live):
+            for b_, j in enumerate(live):
+                Al[a_, b_] = A[i, j]
+        Ali = mp.inverse(Al)
+        Ainv = mp.zeros(n, n)
+        for a_, i in enumerate(live):
+            for b_, j in enumerate(live):
+                Ainv[i, j] = Ali[a_, b_]
+        J = Pft * Phi * Ainv
+        S[t] = Ft + J * (S[t + 1] - Phi * Ft)
+        Ps[t] = Pft + J * (Ps[t + 1] - A) * J.T
+    f64 = lambda M, r, c: np.array([[float(M[i, j]) for j in range(c)] for i in range(r)])  # noqa: E731
+    return (np.array([[float(v) for v in row] for row in F]),
+            np.array([[[float(v) for v in row] for row in Pm] for Pm in Pf]),
+            np.array([[float(S[t][i]) for i in range(n)] for t in range(T)]),
+            np.array([f64(Ps[t], n, n) for t in range(T)]))
+
+
+def heywood():
+    """(Near-)singular predicted covariances -- the ``pinv`` branch of the reference smoother (:455).
+
+    m0  one series with communality exactly 1 => q = 0 for its specific state (metran.py:314-316), T = 800,
+        every step observed: min eig(Pp) decays from 2e-2 to ~1e-17 (cond 1e17) over the record;
+    m1  a common factor at alpha = 1e8 (phi = 1 - 1e-8, q = 2e-8): small but regular;
+    m2  as m0 with P0[2,2] = 0 as well: that state is exactly zero throughout, Pp has an exactly zero
+        row/column -- an LDL^T pivot of exactly 0.
+    Stored: the reference's outputs AND the same recursion in 60-digit arithmetic (``*_exact``).  On m0 the
+    reference is 7e-8 away from the exact smoothed means: numpy's pinv truncates singular values below
+    1e-15 * s_max, and which side of that threshold a rounding-level singular value falls on is decided by
+    LAPACK's rounding (so is the position of the oracle's Jacobi eigenvalues: the oracle differs from the
+    reference by up to 1e-8 here, both from the exact answer by ~7e-8)."""
+    N, K, T = 8, 2, 800
+    data = {}
+    cases = []
+    y, alpha, load, phi, q = make_dfm(N, K, T, 5150, 0, 0.0, "observed")
+    load0 = load.copy()
+    load0[2] = [0.6, 0.8]
+    phi0, q0 = phi_q_from_alpha(alpha, load0)
+    assert q0[2] == 0.0
+    cases.append((y, phi0, q0, load0, None, ()))
+    a1 = alpha.copy()
+    a1[N] = 1e8
+    phi1, q1 = phi_q_from_alpha(a1, load)
+    cases.append((y, phi1, q1, load, None, ()))
+    P0 = np.eye(N + K)
+    P0[2, 2] = 0.0
+    cases.append((y[:200], phi0, q0, load0, P0, (2,)))
+    for i, (yy, ph, qq, ld, p0, dead) in enumerate(cases):
+        kf = kfm.SPKalmanFilter(engine="numpy")
+        kf.filtermethod = kfm.seqkalmanfilter
+        kf.set_observations(pd.DataFrame(yy))
+        Phi = np.diag(ph)
+        kf.set_matrices(Phi, np.diag(qq), observation_matrix(ld), np.zeros(N))
+        kf.run_filter(initial_state_covariance=None if p0 is None else p0.copy())
+        S, Ps = kfm.kalmansmoother(kf.filtered_state_means, kf.filtered_state_covariances,
+                                   kf.predicted_state_means, kf.predicted_state_covariances, Phi)
+        Fe, Pfe, Se, Pse = exact_filter_smoother(yy, ph, qq, ld, P0=p0, dead=dead)
+        Tn = yy.shape[0]
+        tsel = np.unique(np.r_[np.arange(0, Tn, 40), Tn - 1, Tn - 2])
+        mineig = np.array([np.linalg.eigvalsh(kf.predicted_state_covariances[t])[0] for t in range(Tn)])
+        d = dict(obs=yy, phi=ph, q=qq, loadings=ld, P0=np.eye(N + K) if p0 is None else p0, tsel=tsel,
+                 mle=np.float64(kf.get_mle()), F=kf.filtered_state_means, Pf=kf.filtered_state_covariances[tsel],
+                 S=S, Ps=Ps[tsel], F_exact=Fe, S_exact=Se, Ps_exact=Pse[tsel], Pf_exact=Pfe[tsel], mineig_Pp=mineig)
+        for k, v in d.items():
+            data[f"m{i}_{k}"] = v
+        print("heywood m%d: min eig(Pp) %.1e..%.1e | reference vs exact: F %.1e S %.1e Ps %.1e" % (
+            i, mineig[1:].min(), mineig[1:].max(), np.abs(kf.filtered_state_means - Fe).max(),
+            np.abs(S - Se).max(), np.abs(Ps - Pse).max()))
+    data["nmodels"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(HERE, "heywood.npz"), **data)
+
+
 def edge_nan(i, y):
     # model 0: series 1 never observed; model 1: a run of fully-empty steps and an inf
     if i == 0:
@@ -258,6 +374,11 @@ def edge_nan(i, y):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py heywood ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    heywood()
     g1_real()
     g1_solve()
     g2_seeded()

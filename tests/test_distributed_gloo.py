@@ -103,3 +103,25 @@ def test_sharded_objective_world2(tmp_path):
         e[i] = h
         fd = (total(alpha + e) - total(alpha - e)) / (2 * h)
         assert abs(g0[1 + i] - fd) <= 1e-5 * max(1e-3, abs(fd))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` from a plain interpreter (how the driver may call it)
+    re-executes itself under torch.distributed.run; checked here without a GPU in --dry-run mode (gloo): two
+    ranks rendezvous on 127.0.0.1, the barrier / max-over-ranks / all-reduce plumbing runs, rank 0 prints ONE
+    JSON line that says it is not a measurement."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["value"] is None and "dry_run" in res
+    assert res["allreduce_check"] == 3.0  # ranks contributed 1 + 2
+    assert res["config"]["name"] == "c2" and res["config"]["batch_per_gpu"] == 4096
