@@ -73,6 +73,7 @@ hipError_t launch_adjoint(int N, int K, const AdjointArgs &a, hipStream_t s);
 hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,
                              const double *gphi, const double *gq, double *galpha, hipStream_t s);
 hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s);
+hipError_t launch_smoother_wide(int N, int K, const SmootherArgs &a, hipStream_t s); // mk_wide.hip (n > 16)
 int record_stride(int n); // doubles per packed record for state dimension n
 int num_shapes();
 void get_shape(int i, int *N, int *K);

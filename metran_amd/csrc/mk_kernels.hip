@@ -13,360 +13,9 @@
 //   smoother_kernel : kalmansmoother   metran/kalmanfilter.py:403-476
 //   simulate/decompose kernels : SPKalmanFilter.simulate/decompose :569-644
 //   params kernel   : Metran._phi / get_transition_* metran/metran.py:246-322
-#include <hip/hip_runtime.h>
-
-#include <type_traits>
-
-#include "mk_internal.h"
+#include "mk_prims.h"
 
 namespace mk {
-
-// ---------------------------------------------------------------- compile-time loops
-template <int I, int E, class F>
-__device__ __forceinline__ void sfor(F &&f)
-{
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        sfor<I + 1, E>(static_cast<F &&>(f));
-    }
-}
-template <int I, int E, class F>
-__device__ __forceinline__ void sfor_down(F &&f) // I = E-1 .. 0 handled as (E-1-I)
-{
-    if constexpr (I < E) {
-        f(std::integral_constant<int, E - 1 - I>{});
-        sfor_down<I + 1, E>(static_cast<F &&>(f));
-    }
-}
-#define MK_LAMBDA(arg) [&](auto arg) __attribute__((always_inline))
-
-// ---------------------------------------------------------------- cross-lane primitives
-// All cross-lane traffic of the hot kernels goes through three primitives:
-//   bcast<J>(v)                          value of lane J of the group, in every lane
-//   axpy_lane<J,C0,C1>(acc, src, mul)    acc[c] (+|-)= bcast<J>(src[c]) * mul      c in [C0,C1)
-//   axpy_col<C0,C1>(acc, src, mul)       acc[c] (+|-)= bcast<c>(src)    * mul      c in [C0,C1)
-//
-// G = 16 (four models per wavefront, one per 16-lane DPP row): gfx950 has DPP64
-// `row_newbcast` on v_mov_b64 and v_fmac_f64, so a broadcast-multiply-accumulate is ONE
-// instruction (v_fmac_f64_dpp; negation is a free source modifier) with no LDS and no extra
-// move.  hipcc has no builtin for the fused form, so it is emitted as inline asm.
-// HAZARD: "VALU writes a VGPR -> DPP reads it as src0" needs 2 wait states and neither the
-// assembler nor hipcc's hazard recogniser pads it around inline asm.  A lone wavefront issues one
-// instruction per ~5 cycles and pays ~9 for an `s_nop 1`, so no blanket nops are emitted;
-// instead scripts/check_dpp_hazards.py statically verifies the generated assembly at build time
-// (see __graft_entry__.build) and `dpp_guard()` is placed where it reports a producer too close.
-// G = 64 (one model per wavefront): v_readlane -> SGPR pair, plain v_fma with a scalar operand.
-template <int G>
-struct Group;
-
-#define MK_DPPMASK " row_mask:0xf bank_mask:0xf"
-
-// Two wait states between the producers of `arr` and the DPP reads that follow: the empty asm
-// statements pin every element (its producer cannot be scheduled below them), the nop follows.
-template <int n>
-__device__ __forceinline__ void dpp_guard(double (&arr)[n])
-{
-#pragma unroll
-    for (int c = 0; c < n; ++c) asm volatile("" : "+v"(arr[c]));
-    asm volatile("s_nop 1");
-}
-__device__ __forceinline__ void dpp_pin(double &v) { asm volatile("" : "+v"(v)); }
-// two wait states before DPP reads of one or two freshly produced scalars
-__device__ __forceinline__ void dpp_guard1(double &u, double &v)
-{
-    asm volatile("s_nop 1" : "+v"(u), "+v"(v));
-}
-
-template <>
-struct Group<16> {
-    template <int J>
-    static __device__ __forceinline__ double bcast(double v)
-    {
-        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); // v_mov_b64_dpp row_newbcast:J
-    }
-    // acc += bcast<J>(src) * mul   /   acc -= bcast<J>(src) * mul
-    template <int J, bool NEG = false>
-    static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
-    {
-        if constexpr (NEG)
-            asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
-        else
-            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
-    }
-    template <int J, int C0, int C1, bool NEG, int n>
-    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
-    {
-        sfor<C0, C1>(MK_LAMBDA(c) { fmac<J, NEG>(acc[decltype(c)::value], src[decltype(c)::value], mul); });
-    }
-    template <int C0, int C1, bool NEG, int n>
-    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
-    {
-        sfor<C0, C1>(MK_LAMBDA(c) { fmac<decltype(c)::value, NEG>(acc[decltype(c)::value], src, mul); });
-    }
-    // per-group mask of lanes whose predicate holds (bit l = lane l of this group)
-    static __device__ __forceinline__ unsigned group_bits(unsigned long long m)
-    {
-        return (unsigned)(m >> ((threadIdx.x & 63) & ~15)) & 0xffffu;
-    }
-    // ballot pattern with bits [0,N) set in every group
-    static constexpr unsigned long long full_mask(int N)
-    {
-        const unsigned long long g = (1ull << N) - 1ull;
-        return g | (g << 16) | (g << 32) | (g << 48);
-    }
-};
-
-template <>
-struct Group<64> {
-    template <int J>
-    static __device__ __forceinline__ double bcast(double v)
-    {
-        int lo = __builtin_amdgcn_readlane(__double2loint(v), J);
-        int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
-        return __hiloint2double(hi, lo);
-    }
-    template <int J, bool NEG = false>
-    static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
-    {
-        acc = fma(NEG ? -bcast<J>(src) : bcast<J>(src), mul, acc);
-    }
-    // A broadcast is two v_readlane_b32 into an SGPR pair that the FMA reads as a constant, with 2 wait
-    // states between them: issued one after the other every FMA pays an `s_nop 1` (~9 cycles for a lone
-    // wavefront).  The sweeps therefore run in batches of BATCH elements, all broadcasts of a batch first
-    // (source order is what the scheduler keeps), then the FMAs; the scheduling fence after each batch
-    // bounds the live SGPRs at 2*BATCH -- left alone the compiler hoists every readlane of a sweep to
-    // its top and spills the SGPRs into VGPR lanes and those VGPRs into scratch (measured at n = 36).
-    static constexpr int BATCH = 6;
-    template <int J, int C0, int C1, bool NEG, int n>
-    static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
-    {
-        if constexpr (C0 < C1) {
-            constexpr int CE = C0 + BATCH < C1 ? C0 + BATCH : C1;
-            double b[CE - C0];
-            sfor<C0, CE>(MK_LAMBDA(c) { b[decltype(c)::value - C0] = bcast<J>(src[decltype(c)::value]); });
-            sfor<C0, CE>(MK_LAMBDA(c) {
-                constexpr int cc = decltype(c)::value;
-                acc[cc] = fma(NEG ? -b[cc - C0] : b[cc - C0], mul, acc[cc]);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            axpy_lane<J, CE, C1, NEG, n>(acc, src, mul);
-        }
-    }
-    template <int C0, int C1, bool NEG, int n>
-    static __device__ __forceinline__ void axpy_col(double (&acc)[n], double src, double mul)
-    {
-        if constexpr (C0 < C1) {
-            constexpr int CE = C0 + BATCH < C1 ? C0 + BATCH : C1;
-            double b[CE - C0];
-            sfor<C0, CE>(MK_LAMBDA(c) { b[decltype(c)::value - C0] = bcast<decltype(c)::value>(src); });
-            sfor<C0, CE>(MK_LAMBDA(c) {
-                constexpr int cc = decltype(c)::value;
-                acc[cc] = fma(NEG ? -b[cc - C0] : b[cc - C0], mul, acc[cc]);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            axpy_col<CE, C1, NEG, n>(acc, src, mul);
-        }
-    }
-    static __device__ __forceinline__ unsigned long long group_bits(unsigned long long m) { return m; }
-    static constexpr unsigned long long full_mask(int N) { return N >= 64 ? ~0ull : (1ull << N) - 1ull; }
-};
-
-typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
-
-template <int n>
-__device__ __forceinline__ void store_row(double *dst, const double (&row)[n])
-{
-    if constexpr (n % 2 == 0) {
-        v2d *d2 = reinterpret_cast<v2d *>(dst); // row offset is a multiple of 16 B
-#pragma unroll
-        for (int c = 0; c < n / 2; ++c) d2[c] = v2d{row[2 * c], row[2 * c + 1]};
-    } else {
-#pragma unroll
-        for (int c = 0; c < n; ++c) dst[c] = row[c];
-    }
-}
-
-template <int n>
-__device__ __forceinline__ void load_row(const double *src, double (&row)[n])
-{
-    if constexpr (n % 2 == 0) {
-        const v2d *s2 = reinterpret_cast<const v2d *>(src);
-#pragma unroll
-        for (int c = 0; c < n / 2; ++c) {
-            const v2d v = s2[c];
-            row[2 * c] = v.x;
-            row[2 * c + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < n; ++c) row[c] = src[c];
-    }
-}
-
-// single v_min_f64 (fmin() adds a canonicalising v_max); NaN operands are ignored, which is fine:
-// a NaN variance propagates into the outputs by itself
-__device__ __forceinline__ double min_f64(double a, double b)
-{
-    double o;
-    asm("v_min_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-
-// 1/x to ~1 ulp: v_rcp_f64 (measured relative error < 2^-25 on gfx950, tests/test_hip_parity.py::
-// test_rcp_accuracy) + one cubically convergent step (3 dependent FMAs instead of the 4 of two Newton
-// steps; no scaling/fix-up: x is an O(1) variance here, never denormal).
-__device__ __forceinline__ double rcp_nr(double x)
-{
-    const double r0 = __builtin_amdgcn_rcp(x);
-    const double e = fma(-x, r0, 1.0);   // relative error of r0
-    const double p = fma(e, e, e);        // e + e^2
-    return fma(r0, p, r0);                // r0 (1 + e + e^2): error e^3
-}
-
-// ---------------------------------------------------------------- state I/O: symmetric column runs
-// Lane r holds ROW r of a covariance; its HBM image is row-major, i.e. lane r's data is n doubles at
-// stride 1 -- stored directly, every store instruction would touch ~n scattered pieces per model
-// (measured in v1: store-issue bound at 2.5 TB/s).  The covariances are SYMMETRIC, so the kernels
-// store the transpose instead: for column index c = 0..n-1 every lane writes its element P[r][c] to
-// position (c, r), i.e. one instruction writes a contiguous n*8-byte run per model and n instructions
-// cover the block.  What lands in HBM is (P)^T = P up to the rounding-level asymmetry of the rank-1
-// updates (< 1e-14 relative).  No LDS staging, no waits, and the smoother re-reading "row r" as
-// column r gets back exactly the filter's own row r.  Lanes >= n (and the groups of a partial last
-// workgroup) are exact REPLICAS of lane n-1 (of the last model): same inputs, same instruction
-// stream, identical bytes to identical addresses -- no store in the hot loops needs an exec mask.
-//
-// PACKED RECORDS (fast path, mk_outputs.record_stride): measured on MI355X
-// (scripts/ubench/store_pattern2.hip), 6.5 GB of block stores per launch are almost free next to a
-// busy VALU, but 80-byte mean vectors and 8-byte sigma/detf scalars written as SEPARATE arrays cost
-// ~8x more per byte: they leave every cache line partially written when it is evicted, and
-// partial-line writes throttle HBM.  A record keeps one (model, step) moment set together,
-//     [ mean(n) | covariance(n*n) | sigma, detf (filtered set only) | zero pad ]     RS doubles,
-// with RS*8 a multiple of 128 bytes; the reference-shaped arrays are strided VIEWS of the record
-// arrays on the host.
-__device__ __forceinline__ void wave_lds_sync()
-{
-    // LDS-only ("local") fences: a generic fence would also pin private arrays to scratch memory
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-}
-
-constexpr int record_payload(int n) { return n + n * n; }
-constexpr int record_stride_c(int n) { return ((record_payload(n) + 2 + 15) / 16) * 16; }
-
-// pointer pair addressing one moment set of one model: element r of the mean vector and element
-// (0, r) of the covariance's column runs; `advance` moves both to the next (or previous) time step
-struct MomentPtr {
-    double *vec, *mat;
-    long vstep, mstep;
-    __device__ __forceinline__ void advance(long dir) // a null (skipped) output stays null
-    {
-        if (vec) vec += dir * vstep;
-        if (mat) mat += dir * mstep;
-    }
-    __device__ __forceinline__ void advance_nn(long dir) // both pointers known to be non-null
-    {
-        vec += dir * vstep;
-        mat += dir * mstep;
-    }
-};
-
-// inst/r already clamped; rs > 0: packed records (V is the record array), else dense arrays V [.,n], M [.,n,n]
-template <int n>
-__device__ __forceinline__ MomentPtr moment_ptr(double *V, double *M, long blk, long ts, long rs, int r)
-{
-    MomentPtr p;
-    if (rs > 0) {
-        p.vec = V ? V + blk * rs + r : nullptr; // projection-only smoothing has no smoothed record array
-        p.mat = V ? V + blk * rs + n + r : nullptr;
-        p.vstep = p.mstep = ts * rs;
-    } else {
-        p.vec = V ? V + blk * n + r : nullptr;
-        p.mat = M ? M + blk * n * n + r : nullptr;
-        p.vstep = ts * n;
-        p.mstep = ts * n * n;
-    }
-    return p;
-}
-
-template <int n>
-__device__ __forceinline__ void store_cols(double *mat, const double (&row)[n])
-{
-#pragma unroll
-    for (int c = 0; c < n; ++c) mat[c * n] = row[c]; // (c, r) <- P[r][c]: contiguous over the lanes
-}
-template <int n>
-__device__ __forceinline__ void load_cols(const double *mat, double (&row)[n])
-{
-#pragma unroll
-    for (int c = 0; c < n; ++c) row[c] = mat[c * n];
-}
-
-// ---------------------------------------------------------------- fused projection epilogue
-// SPKalmanFilter.simulate (kalmanfilter.py:569-603) for Metran's scaled observation matrix
-// Z~ = diag(s) [I | loadings] (metran/metran.py:944-961), evaluated on the moments a kernel holds
-// in registers: lane j < N returns  mean_j = s_j (x_j + sum_k g_jk x_{N+k}) + offset_j  and
-// var_j = max(s_j^2 (P_jj + 2 sum_k g_jk P_j,N+k + sum_kl g_jk g_jl P_N+k,N+l), 0).
-// Writing these 2N doubles instead of the n + n^2 state moments is what Metran.get_simulation
-// needs (metran/metran.py:831-883) and cuts the smoother's output traffic ~7x at n = 10, ~40x at n = 36.
-template <int N, int K, int G>
-__device__ __forceinline__ void project(double x, const double (&P)[N + K], const double (&gam)[K], double scale,
-                                        double offset, int lane, double &mean, double &var)
-{
-    using Gp = Group<G>;
-    double m = x, t = 0.0, diag = 0.0;
-    double pf[K][K]; // factor block of the covariance, replicated
-    sfor<0, K>(MK_LAMBDA(k) {
-        constexpr int kk = decltype(k)::value;
-        m = fma(gam[kk], Gp::template bcast<N + kk>(x), m);
-        sfor<kk, K>(MK_LAMBDA(l) {
-            constexpr int ll = decltype(l)::value;
-            pf[kk][ll] = pf[ll][kk] = Gp::template bcast<N + kk>(P[N + ll]);
-        });
-    });
-    sfor<0, N>(MK_LAMBDA(c) { diag = (decltype(c)::value == lane) ? P[decltype(c)::value] : diag; });
-    sfor<0, K>(MK_LAMBDA(k) {
-        constexpr int kk = decltype(k)::value;
-        double u = 2.0 * P[N + kk];
-        sfor<0, K>(MK_LAMBDA(l) { u = fma(gam[decltype(l)::value], pf[kk][decltype(l)::value], u); });
-        t = fma(gam[kk], u, t);
-    });
-    mean = fma(scale, m, offset);
-    const double v = scale * scale * (diag + t);
-    var = v < 0.0 ? 0.0 : v; // :601-602 (np.maximum keeps a NaN)
-}
-
-// log of a frexp-normalised mantissa m in [0.5, 1) as log(m) = e ln2 + l with e in {-1, 0}:
-// m' = m or 2m in [1/sqrt2, sqrt2), s = (m'-1)/(m'+1), l = 2 atanh(s) = 2s (1 + s^2/3 + ... + s^18/19)
-// (|s| < 0.1716: the truncated tail is < 2.3e-17 relative; measured max abs error 1.4e-16 against
-// 120-bit arithmetic, libm 0.6e-16).  ~27 instructions instead of the ~100 of the generic log(), which
-// was 1/6 of the filter's per-step instruction stream when the per-step determinants are booked.
-__device__ __forceinline__ double log_mant(double m, int &e)
-{
-    if (__builtin_expect(!(m > 0.0), 0)) { // f <= 0 or NaN somewhere in the product: let libm say so
-        e = 0;
-        return log(m);
-    }
-    const bool low = m < 0.70710678118654752440;
-    e = low ? -1 : 0;
-    const double m2 = low ? m + m : m;
-    const double s = (m2 - 1.0) * rcp_nr(m2 + 1.0);
-    const double w = s * s;
-    double p = 1.0 / 19.0;
-    p = fma(p, w, 1.0 / 17.0);
-    p = fma(p, w, 1.0 / 15.0);
-    p = fma(p, w, 1.0 / 13.0);
-    p = fma(p, w, 1.0 / 11.0);
-    p = fma(p, w, 1.0 / 9.0);
-    p = fma(p, w, 1.0 / 7.0);
-    p = fma(p, w, 1.0 / 5.0);
-    p = fma(p, w, 1.0 / 3.0);
-    p = fma(p, w, 1.0);
-    return (s + s) * p;
-}
-
-constexpr double kLn2 = 0.693147180559945309417232121458;
-constexpr double kLog2Pi = 1.837877066409345483560659472811; // log(2*pi)
 
 // =====================================================================================
 // Sequential-processing Kalman filter + -2 log L            (kalmanfilter.py:236-400, 550-567)
@@ -727,42 +376,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 //   whenever q > 0, where the reference's pinv (:455) is the inverse); lane i solves for ROW i of J.
 //   The factor is DISTRIBUTED: lane c keeps L(c, 0..c-1) in place of its row of A.
 // =====================================================================================
-// A = L D L^T of the predicted covariance, right-looking and distributed: lane c ends up holding L(c, j) in
-// A[j] for j < c, dinv[j] = 1/d_j.  The reference inverts Pp with numpy.linalg.pinv (kalmanfilter.py:455),
-// which drops (numerically) null directions; an LDL^T pivot d_j <= 0 is such a direction (q_j = 0 when a
-// series has communality 1, metran.py:314-316, and its state variance has decayed to rounding level).
-// GUARD = false is the hot path (no test per stage; the caller checks `pivmin` once per step);
-// GUARD = true re-factorises with 1/d_j := 0 and L(., j) := 0 for d_j <= 0 -- the generalised inverse
-// L^-T D^+ L^-1, which acts like pinv on range(Pp), where J's operands live.  Positive pivots, however
-// small, are inverted: measured against 60-digit arithmetic (tests/golden/heywood.npz) that is MORE accurate
-// than the reference's truncation (1e-14 vs 7e-8 on the smoothed means at cond(Pp) = 1e17).
-template <int n, int G, bool GUARD>
-__device__ __forceinline__ void ldlt_factor(double (&A)[n], double (&dinv)[n], double &pivmin)
-{
-    using Gp = Group<G>;
-    sfor<0, n>(MK_LAMBDA(jc) {
-        constexpr int j = decltype(jc)::value;
-        const double piv = Gp::template bcast<j>(A[j]); // d_j
-        pivmin = min_f64(pivmin, piv);
-        double ij = rcp_nr(piv);
-        if constexpr (GUARD) ij = piv > 0.0 ? ij : 0.0;
-        dinv[j] = ij;
-        const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
-        // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
-        Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
-        A[j] = lr;
-    });
-}
-// status bits of a smoother instance from the smallest pivot it met (covariances of standardised series are
-// O(1): -1e-8 is far outside rounding)
-__device__ __forceinline__ unsigned pivot_flags(double pivmin)
-{
-    unsigned f = 0u;
-    if (!(pivmin > 0.0)) f |= MK_FLAG_RANK_DEFICIENT;
-    if (!(pivmin >= -1e-8)) f |= MK_FLAG_NOT_SPD;
-    return f;
-}
-
 // ---------------------------------------------------------------- packed-record I/O through LDS (smoother)
 // The smoother both reads and writes a record per step; moving whole 16-byte chunks of the
 // wavefront's GW adjacent records (lane l <-> chunks l, l+64, ...) and transposing through a
@@ -1175,206 +788,6 @@ __global__ void __launch_bounds__(256) smoother_dense_kernel(SmootherArgs a)
 #pragma unroll
         for (int c = 0; c < n; ++c) Pfc[c] = Pfn[c];
         xfc = xfn;
-    }
-    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
-}
-
-// =====================================================================================
-// one model per wavefront (16 < n <= 64): the row-per-lane arrays of the kernels above would need
-// ~10 x n doubles per lane and spill (measured at n = 36: 1433 spilled VGPRs, 8x slower than the
-// filter).  Here D = Ps[t+1] - Pp[t+1], the rows of Pf[t] and the gain J live in a wave-private LDS
-// block; the two n^3 sweeps (V = J D, Ps = Pf + V J^T) are RUN-TIME loops whose operand rows are read
-// from LDS at wavefront-uniform addresses (LDS broadcast, no v_readlane), so the scheduler cannot
-// hoist n*n loads across the factorisation (it did, and spilled them, when the sweeps were unrolled)
-// and the code stays inside the instruction cache.  <= 3 row arrays are live at any time.
-template <int n>
-constexpr int wave_kernel_wpb() // wavefronts per workgroup: one, so that LDS (2 n x n matrices per wavefront)
-{                               // is handed out at wavefront granularity: 7 resident wavefronts per CU at n = 36
-    return 1;
-}
-
-template <int N, int K, bool PROJ>
-__global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) __attribute__((amdgpu_waves_per_eu(2, 2)))
-smoother_wave_kernel(SmootherArgs a)
-{
-    constexpr int n = N + K, G = 64, WPB = wave_kernel_wpb<n>();
-    static_assert(n <= G, "state dimension must fit the wavefront");
-    using Gp = Group<G>;
-    const int lane = threadIdx.x % G;
-    long inst = (long)blockIdx.x * WPB + threadIdx.x / G;
-    const bool live = inst < a.B;
-    if (!live) inst = a.B - 1;
-    const int r = lane < n ? lane : n - 1;
-    const long T = a.T;
-    __shared__ __attribute__((aligned(16))) double lds_m[WPB * 2 * n * n];
-    double *Dm = lds_m + (threadIdx.x / G) * 2 * n * n; // D row-major; after the V sweep: rows of V J^T
-    double *Jm = Dm + n * n;                            // rows of the smoother gain J
-    double *Dr = Dm + r * n;
-    const double *Jr = Jm + r * n;
-
-    const double phi_r = a.phi[inst * n + r];
-    const double q_r = a.q[inst * n + r];
-
-    const long blkT = inst * a.bs + (T - 1) * a.ts;
-    MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
-    MomentPtr oS = moment_ptr<n>(a.S, a.Ps, blkT, a.ts, a.rs, r);
-    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
-    double *padS = (a.rs > 0 && a.S) ? a.S + blkT * RS + NV + (lane < PADN ? lane : PADN - 1) : nullptr;
-
-    const long rec_id = inst % a.R;
-    const int jr = lane < N ? lane : N - 1;
-    double gam[K], pscale = 1.0, poffset = 0.0;
-    double *pM = nullptr, *pV = nullptr;
-    if constexpr (PROJ) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
-        if (a.scale) pscale = a.scale[rec_id * N + jr];
-        if (a.offset) poffset = a.offset[rec_id * N + jr];
-        const long pidx = blkT * N + jr;
-        pM = a.sim_means ? a.sim_means + pidx : nullptr;
-        pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
-    }
-    auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
-        if (oS.vec) *oS.vec = xv;
-        if (oS.mat) store_cols<n>(oS.mat, row);
-        oS.advance(-1);
-        if (padS) {
-            *padS = 0.0;
-            padS -= a.ts * RS;
-        }
-        if constexpr (PROJ) {
-            double mean, var;
-            project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
-            if (lane < N && live) {
-                if (pM) *pM = mean;
-                if (pV) *pV = var;
-            }
-            if (pM) pM -= a.ts * N;
-            if (pV) pV -= a.ts * N;
-        }
-    };
-
-    // last step: smoothed = filtered (:450-451)
-    double xs = *iF.vec, Psn[n];
-    load_cols<n>(iF.mat, Psn);
-    store(xs, Psn);
-    double pivmin = 1.0;
-
-    for (long t = T - 2; t >= 0; --t) {
-        iF.advance_nn(-1);
-        const double xfc = *iF.vec;
-        double A[n], z[n];
-        {
-            double Pfc[n];
-            load_cols<n>(iF.mat, Pfc);
-            wave_lds_sync(); // previous iteration's reads of Dm / Jm are complete
-            // element by element, D streamed to LDS in 16-byte pieces: Pf, Ps[t+1], W, Pp and D rows
-            // all live at once would be 5n doubles per lane
-            double dprev = 0.0;
-            // (opaque copies: the n loop-invariant selects "c == r ? q : 0" would otherwise be hoisted out
-            // of the time loop and spilled -- 2n VGPRs that are not there)
-            int rv = r;
-            double qv = q_r;
-            asm volatile("" : "+v"(rv), "+v"(qv));
-            sfor<0, n>(MK_LAMBDA(cc) {
-                constexpr int c = decltype(cc)::value;
-                z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
-                A[c] = fma(phi_r, z[c], c == rv ? qv : 0.0);   // Pp[t+1] row
-                const double d = Psn[c] - A[c];
-                if constexpr (n % 2 == 0) {
-                    if constexpr (c % 2 == 1) *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{dprev, d};
-                    else dprev = d;
-                } else {
-                    Dr[c] = d;
-                }
-                if constexpr (c % 8 == 7) __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        const double delta = xs - phi_r * xfc;
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- A = L D L^T (rows distributed over the lanes), as in the group kernels ----
-        // (the unused diagonal slot of lane j, L(j,j) = 1, keeps 1/d_j: no separate dinv[] array)
-        sfor<0, n>(MK_LAMBDA(jc) {
-            constexpr int j = decltype(jc)::value;
-            const double piv = Gp::template bcast<j>(A[j]);
-            pivmin = min_f64(pivmin, piv);
-            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_j <= 0: null direction dropped (see ldlt_factor)
-            const double lr = A[j] * ij;
-            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
-            A[j] = j == lane ? ij : lr;
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // the broadcast operands of the two substitutions are all known once the factorisation is done;
-        // tying each stage's operand to that stage's pivot element (empty asm, no instruction) keeps the
-        // compiler from running the n^2/2 readlanes ahead of the FMAs that consume them
-        sfor<0, n>(MK_LAMBDA(kc) {
-            constexpr int k = decltype(kc)::value;
-            asm volatile("" : "+v"(A[k]) : "v"(z[k]));
-            Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        sfor<0, n>(MK_LAMBDA(cc) {
-            constexpr int c = decltype(cc)::value;
-            z[c] *= Gp::template bcast<c>(A[c]);
-        });
-        sfor_down<0, n>(MK_LAMBDA(kc) {
-            constexpr int k = decltype(kc)::value;
-#pragma unroll
-            for (int c = 0; c < k; ++c) asm volatile("" : "+v"(A[c]) : "v"(z[k]));
-            Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        store_row<n>(Jm + r * n, z); // lane r now holds row r of J = W Pp^-1
-
-        double acc0 = xfc, acc1 = 0.0;
-        sfor<0, n>(MK_LAMBDA(cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
-            else Gp::template fmac<c>(acc1, delta, z[c]);
-        });
-        xs = acc0 + acc1;
-        wave_lds_sync(); // Dm, Jm visible to the whole wavefront
-        __builtin_amdgcn_sched_barrier(0);
-        // Pf[t] again (L2-resident; its registers were needed by the factorisation): lands during the sweeps
-        double Pfc[n];
-        load_cols<n>(iF.mat, Pfc);
-
-        // V = J D: V[r][:] += J[r][k] * D[k][:], D row k broadcast from LDS
-        double V[n];
-#pragma unroll
-        for (int c = 0; c < n; ++c) V[c] = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < n; ++k) {
-            const double zk = Jr[k];
-            double Dk[n];
-            load_row<n>(Dm + k * n, Dk);
-#pragma unroll
-            for (int c = 0; c < n; ++c) V[c] = fma(zk, Dk[c], V[c]);
-        }
-        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J row c broadcast from LDS.  c is a run-time index, so
-        // the sums go back into this lane's row of Dm (every lane is past the V sweep: the wavefront runs
-        // in lock-step and LDS operations of one wavefront complete in order)
-        wave_lds_sync();
-#pragma unroll 1
-        for (int c = 0; c < n; ++c) {
-            double Jc[n];
-            load_row<n>(Jm + c * n, Jc);
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int k = 0; k < n; ++k) {
-                if (k % 4 == 0) s0 = fma(V[k], Jc[k], s0);
-                else if (k % 4 == 1) s1 = fma(V[k], Jc[k], s1);
-                else if (k % 4 == 2) s2 = fma(V[k], Jc[k], s2);
-                else s3 = fma(V[k], Jc[k], s3);
-            }
-            Dr[c] = (s0 + s1) + (s2 + s3);
-        }
-        wave_lds_sync(); // orders the scalar stores above before the vector loads of the same row
-        load_row<n>(Dr, Psn);
-#pragma unroll
-        for (int c = 0; c < n; ++c) Psn[c] += Pfc[c];
-        store(xs, Psn);
     }
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
@@ -1847,13 +1260,8 @@ static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
 {
     constexpr int n = N + K;
     constexpr int G = n <= 16 ? 16 : 64;
-    if constexpr (G == 64) { // one model per wavefront: LDS-resident matrices, any addressing
-        constexpr int WPB = wave_kernel_wpb<n>();
-        const unsigned wgrid = (unsigned)((a.B + WPB - 1) / WPB);
-        if (a.sim_means || a.sim_vars)
-            hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(wgrid), dim3(64 * WPB), 0, s, a);
-        else
-            hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(wgrid), dim3(64 * WPB), 0, s, a);
+    if constexpr (G == 64) { // one model per wavefront: mk_wide.hip
+        return launch_smoother_wide(N, K, a, s);
     } else {
         constexpr int GPB = 256 / G;
         const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
@@ -1893,6 +1301,9 @@ int num_shapes();
 void get_shape(int i, int *N, int *K);
 
 #ifdef MK_SHAPE_MODULE
+} // namespace mk
+#include "mk_wide.hip" // one translation unit per run-time shape module
+namespace mk {
 // ---------------------------------------------------------------------------------------------
 // Shape module: this same translation unit compiled at run time for ONE (N, K) that is not in the
 // ahead-of-time list (metran_amd/jit.py drives hipcc, runs the DPP hazard check on the assembly and

@@ -1,0 +1,566 @@
+// mk_wide.hip -- RTS smoother for wide models (16 < n <= 64 states, one model per wavefront): the round-1
+// broadcast kernel (smoother_wave_kernel, kept as the A/B reference) and the MFMA kernel that replaces it.
+// Reference semantics: kalmansmoother, /root/reference/metran/kalmanfilter.py:403-476.
+// A separate translation unit in the library build (compiles in parallel with mk_kernels.hip); textually
+// included by mk_kernels.hip when a run-time shape module is built (MK_SHAPE_MODULE, metran_amd/jit.py).
+#include <cstdlib>
+
+#include "mk_prims.h"
+
+namespace mk {
+
+// =====================================================================================
+// one model per wavefront (16 < n <= 64): the row-per-lane arrays of the kernels above would need
+// ~10 x n doubles per lane and spill (measured at n = 36: 1433 spilled VGPRs, 8x slower than the
+// filter).  Here D = Ps[t+1] - Pp[t+1], the rows of Pf[t] and the gain J live in a wave-private LDS
+// block; the two n^3 sweeps (V = J D, Ps = Pf + V J^T) are RUN-TIME loops whose operand rows are read
+// from LDS at wavefront-uniform addresses (LDS broadcast, no v_readlane), so the scheduler cannot
+// hoist n*n loads across the factorisation (it did, and spilled them, when the sweeps were unrolled)
+// and the code stays inside the instruction cache.  <= 3 row arrays are live at any time.
+template <int n>
+constexpr int wave_kernel_wpb() // wavefronts per workgroup: one, so that LDS (2 n x n matrices per wavefront)
+{                               // is handed out at wavefront granularity: 7 resident wavefronts per CU at n = 36
+    return 1;
+}
+
+template <int N, int K, bool PROJ>
+__global__ void __launch_bounds__(64 * wave_kernel_wpb<N + K>()) __attribute__((amdgpu_waves_per_eu(2, 2)))
+smoother_wave_kernel(SmootherArgs a)
+{
+    constexpr int n = N + K, G = 64, WPB = wave_kernel_wpb<n>();
+    static_assert(n <= G, "state dimension must fit the wavefront");
+    using Gp = Group<G>;
+    const int lane = threadIdx.x % G;
+    long inst = (long)blockIdx.x * WPB + threadIdx.x / G;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1;
+    const int r = lane < n ? lane : n - 1;
+    const long T = a.T;
+    __shared__ __attribute__((aligned(16))) double lds_m[WPB * 2 * n * n];
+    double *Dm = lds_m + (threadIdx.x / G) * 2 * n * n; // D row-major; after the V sweep: rows of V J^T
+    double *Jm = Dm + n * n;                            // rows of the smoother gain J
+    double *Dr = Dm + r * n;
+    const double *Jr = Jm + r * n;
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+
+    const long blkT = inst * a.bs + (T - 1) * a.ts;
+    MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
+    MomentPtr oS = moment_ptr<n>(a.S, a.Ps, blkT, a.ts, a.rs, r);
+    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
+    double *padS = (a.rs > 0 && a.S) ? a.S + blkT * RS + NV + (lane < PADN ? lane : PADN - 1) : nullptr;
+
+    const long rec_id = inst % a.R;
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K], pscale = 1.0, poffset = 0.0;
+    double *pM = nullptr, *pV = nullptr;
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
+        if (a.scale) pscale = a.scale[rec_id * N + jr];
+        if (a.offset) poffset = a.offset[rec_id * N + jr];
+        const long pidx = blkT * N + jr;
+        pM = a.sim_means ? a.sim_means + pidx : nullptr;
+        pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
+    }
+    auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
+        if (oS.vec) *oS.vec = xv;
+        if (oS.mat) store_cols<n>(oS.mat, row);
+        oS.advance(-1);
+        if (padS) {
+            *padS = 0.0;
+            padS -= a.ts * RS;
+        }
+        if constexpr (PROJ) {
+            double mean, var;
+            project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
+            if (lane < N && live) {
+                if (pM) *pM = mean;
+                if (pV) *pV = var;
+            }
+            if (pM) pM -= a.ts * N;
+            if (pV) pV -= a.ts * N;
+        }
+    };
+
+    // last step: smoothed = filtered (:450-451)
+    double xs = *iF.vec, Psn[n];
+    load_cols<n>(iF.mat, Psn);
+    store(xs, Psn);
+    double pivmin = 1.0;
+
+    for (long t = T - 2; t >= 0; --t) {
+        iF.advance_nn(-1);
+        const double xfc = *iF.vec;
+        double A[n], z[n];
+        {
+            double Pfc[n];
+            load_cols<n>(iF.mat, Pfc);
+            wave_lds_sync(); // previous iteration's reads of Dm / Jm are complete
+            // element by element, D streamed to LDS in 16-byte pieces: Pf, Ps[t+1], W, Pp and D rows
+            // all live at once would be 5n doubles per lane
+            double dprev = 0.0;
+            // (opaque copies: the n loop-invariant selects "c == r ? q : 0" would otherwise be hoisted out
+            // of the time loop and spilled -- 2n VGPRs that are not there)
+            int rv = r;
+            double qv = q_r;
+            asm volatile("" : "+v"(rv), "+v"(qv));
+            sfor<0, n>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;
+                z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
+                A[c] = fma(phi_r, z[c], c == rv ? qv : 0.0);   // Pp[t+1] row
+                const double d = Psn[c] - A[c];
+                if constexpr (n % 2 == 0) {
+                    if constexpr (c % 2 == 1) *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{dprev, d};
+                    else dprev = d;
+                } else {
+                    Dr[c] = d;
+                }
+                if constexpr (c % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        const double delta = xs - phi_r * xfc;
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- A = L D L^T (rows distributed over the lanes), as in the group kernels ----
+        // (the unused diagonal slot of lane j, L(j,j) = 1, keeps 1/d_j: no separate dinv[] array)
+        sfor<0, n>(MK_LAMBDA(jc) {
+            constexpr int j = decltype(jc)::value;
+            const double piv = Gp::template bcast<j>(A[j]);
+            pivmin = min_f64(pivmin, piv);
+            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_j <= 0: null direction dropped (see ldlt_factor)
+            const double lr = A[j] * ij;
+            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+            A[j] = j == lane ? ij : lr;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // the broadcast operands of the two substitutions are all known once the factorisation is done;
+        // tying each stage's operand to that stage's pivot element (empty asm, no instruction) keeps the
+        // compiler from running the n^2/2 readlanes ahead of the FMAs that consume them
+        sfor<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+            asm volatile("" : "+v"(A[k]) : "v"(z[k]));
+            Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            z[c] *= Gp::template bcast<c>(A[c]);
+        });
+        sfor_down<0, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value;
+#pragma unroll
+            for (int c = 0; c < k; ++c) asm volatile("" : "+v"(A[c]) : "v"(z[k]));
+            Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        store_row<n>(Jm + r * n, z); // lane r now holds row r of J = W Pp^-1
+
+        double acc0 = xfc, acc1 = 0.0;
+        sfor<0, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
+            else Gp::template fmac<c>(acc1, delta, z[c]);
+        });
+        xs = acc0 + acc1;
+        wave_lds_sync(); // Dm, Jm visible to the whole wavefront
+        __builtin_amdgcn_sched_barrier(0);
+        // Pf[t] again (L2-resident; its registers were needed by the factorisation): lands during the sweeps
+        double Pfc[n];
+        load_cols<n>(iF.mat, Pfc);
+
+        // V = J D: V[r][:] += J[r][k] * D[k][:], D row k broadcast from LDS
+        double V[n];
+#pragma unroll
+        for (int c = 0; c < n; ++c) V[c] = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < n; ++k) {
+            const double zk = Jr[k];
+            double Dk[n];
+            load_row<n>(Dm + k * n, Dk);
+#pragma unroll
+            for (int c = 0; c < n; ++c) V[c] = fma(zk, Dk[c], V[c]);
+        }
+        // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J row c broadcast from LDS.  c is a run-time index, so
+        // the sums go back into this lane's row of Dm (every lane is past the V sweep: the wavefront runs
+        // in lock-step and LDS operations of one wavefront complete in order)
+        wave_lds_sync();
+#pragma unroll 1
+        for (int c = 0; c < n; ++c) {
+            double Jc[n];
+            load_row<n>(Jm + c * n, Jc);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                if (k % 4 == 0) s0 = fma(V[k], Jc[k], s0);
+                else if (k % 4 == 1) s1 = fma(V[k], Jc[k], s1);
+                else if (k % 4 == 2) s2 = fma(V[k], Jc[k], s2);
+                else s3 = fma(V[k], Jc[k], s3);
+            }
+            Dr[c] = (s0 + s1) + (s2 + s3);
+        }
+        wave_lds_sync(); // orders the scalar stores above before the vector loads of the same row
+        load_row<n>(Dr, Psn);
+#pragma unroll
+        for (int c = 0; c < n; ++c) Psn[c] += Pfc[c];
+        store(xs, Psn);
+    }
+    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
+}
+
+
+// =====================================================================================
+// smoother_mfma_kernel (round 2): the same recursion with the n^3 work moved off the broadcast path.
+//   Measured on MI355X (scripts/ubench/mfma_f64.hip), SIMD cycles per 64-lane fused multiply-add:
+//     v_readlane pair + v_fma_f64 ........ 14-19      (what every broadcast of smoother_wave_kernel costs)
+//     uniform ds_read_b128 + 2 v_fma ..... 9-12 each  (LDS broadcast; the LDS pipe is shared by 4 SIMDs)
+//     v_mfma_f64_16x16x4_f64 ............. 70 per instruction = 4.4 per 64 multiply-adds, and the MFMA
+//                                          pipe runs CONCURRENTLY with another wavefront's VALU work
+//   (f64 MFMA has the same 32 flop/clk/SIMD peak as the f64 VALU on gfx950 -- the gain is that operands
+//   need no broadcast and all 64 lanes carry data, not a higher peak.)
+//   What changed against smoother_wave_kernel:
+//   * factorisation: unchanged (rows distributed over the lanes, readlane broadcasts; n^2/2 of them);
+//   * the two triangular substitutions (n^2 broadcasts) read L from an LDS copy at wavefront-uniform
+//     addresses instead of 2 readlanes per element: forward in dot form over row c of L, backward in
+//     axpy form over row k of L, so every read is a contiguous 16-byte pair of ONE row-major copy;
+//   * V^T = D J^T and Ps = Pf + J V^T are 16x16x4 f64 MFMA tiles.  No operand ever needs a transposing
+//     round trip: a C/D tile (row = (lane>>4) + 4 reg, col = lane&15) IS the B operand of k-step `reg`,
+//     and the C-layout tile of X^T IS the A operand of X.  So J^T tiles (read once from the LDS rows of
+//     J) serve as B operand of product 1 and, unchanged, as A operand (J) of product 2; the V^T tiles
+//     product 1 leaves in registers are the B operand of product 2; D is symmetric, its C-layout tiles
+//     are its A operand.  K runs over exactly ceil(n/4) k-steps (36 = 9 x 4: no padding in K); M and N
+//     are padded to 16 and the padding only ever pollutes padded outputs.  Ps tiles with Ib <= Jb are
+//     computed and mirrored into the LDS matrix the lanes then read their rows from.
+// =====================================================================================
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int N, int K, bool PROJ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_mfma_kernel(SmootherArgs a)
+{
+    constexpr int n = N + K, G = 64;
+    static_assert(n > 16 && n <= G, "one model per wavefront, 16 < n <= 64");
+    constexpr int NB = (n + 15) / 16; // 16-wide tile rows / columns
+    constexpr int KS = (n + 3) / 4;   // k-steps
+    constexpr int LD = (n + 3) & ~1;  // LDS row stride: even (16-byte rows), n + 2 or n + 3
+    using Gp = Group<G>;
+    const int lane = threadIdx.x;
+    long inst = (long)blockIdx.x;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1;
+    const int r = lane < n ? lane : n - 1;
+    const long T = a.T;
+    __shared__ __attribute__((aligned(16))) double lds_m[2 * n * LD + 64];
+    double *Dm = lds_m;           // D = Ps[t+1] - Pp[t+1] row-major; after product 1: J V^T
+    double *Lm = Dm + n * LD;     // L (unit lower, 1/d_j in the diagonal slot); after the substitutions: J
+    double *dl = Lm + n * LD;     // delta = xs[t+1] - Xp[t+1]
+    double *Dr = Dm + r * LD;
+    double *Lr = Lm + r * LD;
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+
+    const long blkT = inst * a.bs + (T - 1) * a.ts;
+    MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
+    MomentPtr oS = moment_ptr<n>(a.S, a.Ps, blkT, a.ts, a.rs, r);
+    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
+    double *padS = (a.rs > 0 && a.S) ? a.S + blkT * RS + NV + (lane < PADN ? lane : PADN - 1) : nullptr;
+
+    const long rec_id = inst % a.R;
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K], pscale = 1.0, poffset = 0.0;
+    double *pM = nullptr, *pV = nullptr;
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
+        if (a.scale) pscale = a.scale[rec_id * N + jr];
+        if (a.offset) poffset = a.offset[rec_id * N + jr];
+        const long pidx = blkT * N + jr;
+        pM = a.sim_means ? a.sim_means + pidx : nullptr;
+        pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
+    }
+    auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
+        if (oS.vec) *oS.vec = xv;
+        if (oS.mat) store_cols<n>(oS.mat, row);
+        oS.advance(-1);
+        if (padS) {
+            *padS = 0.0;
+            padS -= a.ts * RS;
+        }
+        if constexpr (PROJ) {
+            double mean, var;
+            project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
+            if (lane < N && live) {
+                if (pM) *pM = mean;
+                if (pV) *pV = var;
+            }
+            if (pM) pM -= a.ts * N;
+            if (pV) pV -= a.ts * N;
+        }
+    };
+
+    // tile addressing (loop invariant): lane l of a C-layout tile sits at row (l>>4) + 4 reg, column l&15
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int jt_row[NB]; // LDS row (of J) this lane reads the J^T tile column-block Ib from: i = 16 Ib + l15, clamped
+#pragma unroll
+    for (int b = 0; b < NB; ++b) jt_row[b] = (16 * b + l15 < n ? 16 * b + l15 : n - 1) * LD;
+
+    // last step: smoothed = filtered (:450-451)
+    double xs = *iF.vec, Psn[n];
+    load_cols<n>(iF.mat, Psn);
+    store(xs, Psn);
+    double pivmin = 1.0;
+
+    for (long t = T - 2; t >= 0; --t) {
+        iF.advance_nn(-1);
+        const double xfc = *iF.vec;
+        double A[n], z[n];
+        {
+            double Pfc[n];
+            load_cols<n>(iF.mat, Pfc);
+            wave_lds_sync(); // previous iteration's reads of Dm / Lm are complete
+            double dprev = 0.0;
+            int rv = r; // opaque copies: keeps the n selects inside the loop (hoisted, they are 2n VGPRs)
+            double qv = q_r;
+            asm volatile("" : "+v"(rv), "+v"(qv));
+            sfor<0, n>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;
+                z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
+                A[c] = fma(phi_r, z[c], c == rv ? qv : 0.0);   // Pp[t+1] row
+                const double d = Psn[c] - A[c];
+                if constexpr (c % 2 == 1) *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{dprev, d};
+                else if constexpr (c == n - 1) Dr[c] = d;
+                else dprev = d;
+                if constexpr (c % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        dl[lane] = xs - phi_r * xfc; // delta (lanes >= n: replicas of lane n-1, never read)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- A = L D L^T, rows distributed over the lanes (as smoother_wave_kernel) ----
+        sfor<0, n>(MK_LAMBDA(jc) {
+            constexpr int j = decltype(jc)::value;
+            const double piv = Gp::template bcast<j>(A[j]);
+            pivmin = min_f64(pivmin, piv);
+            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_j <= 0: null direction dropped (see ldlt_factor)
+            const double lr = A[j] * ij;
+            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+            A[j] = j == r ? ij : lr; // (r, not lane: the replica lanes >= n write row n-1 too)
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        store_row<n>(Lr, A); // row r of L (entries above the diagonal are dead values, never read)
+        wave_lds_sync();
+
+        // ---- lane i solves A z = W_i: operands L(c,k) from the LDS copy, wavefront-uniform addresses ----
+        // forward (dot form): y_c = w_c - sum_{k<c} L(c,k) y_k, then y_c *= 1/d_c (diagonal slot of row c).
+        // The 16-byte reads of a row are issued as a BATCH ahead of the multiply-adds that consume them (left
+        // to itself hipcc emits read / s_waitcnt lgkmcnt(0) / 2 FMAs per pair: one LDS round trip per pair).
+        sfor<1, n>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int NP = (c + 1) / 2; // pairs covering elements 0 .. c-1 (the last may reach the diagonal slot)
+            const double *Lc = Lm + c * LD;
+            v2d buf[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) buf[p] = *reinterpret_cast<const v2d *>(Lc + 2 * p);
+            __builtin_amdgcn_sched_barrier(0);
+            double s0 = z[c], s1 = 0.0, s2 = 0.0, s3 = 0.0; // four chains: a lone wavefront's dependent f64 FMAs are slow
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (p % 2 == 0) {
+                    s0 = fma(-buf[p].x, z[2 * p], s0);
+                    if (2 * p + 1 < c) s1 = fma(-buf[p].y, z[2 * p + 1], s1);
+                } else {
+                    s2 = fma(-buf[p].x, z[2 * p], s2);
+                    if (2 * p + 1 < c) s3 = fma(-buf[p].y, z[2 * p + 1], s3);
+                }
+            }
+            z[c] = (s0 + s1) + (s2 + s3);
+        });
+        {
+            double dv[n];
+#pragma unroll
+            for (int c = 0; c < n; ++c) dv[c] = Lm[c * LD + c];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < n; ++c) z[c] *= dv[c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // backward (axpy form): for k = n-1 .. 1: z_c -= L(k,c) z_k, c < k
+        sfor_down<1, n>(MK_LAMBDA(kc) {
+            constexpr int k = decltype(kc)::value + 1; // sfor_down<1,n> yields n-2 .. 0; rows n-1 .. 1
+            constexpr int NP = (k + 1) / 2;
+            const double *Lk = Lm + k * LD;
+            v2d buf[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) buf[p] = *reinterpret_cast<const v2d *>(Lk + 2 * p);
+            __builtin_amdgcn_sched_barrier(0);
+            const double zk = z[k];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                z[2 * p] = fma(-buf[p].x, zk, z[2 * p]);
+                if (2 * p + 1 < k) z[2 * p + 1] = fma(-buf[p].y, zk, z[2 * p + 1]);
+            }
+        });
+        // z = J[r, :]
+        wave_lds_sync();        // every lane is done with L
+        store_row<n>(Lr, z);    // Lm now holds J row-major
+        // smoothed mean (:461-464): xs[t] = F[t] + J delta, delta from LDS (uniform reads)
+        {
+            double a0 = xfc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int c = 0; c + 1 < n; c += 2) {
+                const v2d v = *reinterpret_cast<const v2d *>(dl + c);
+                if (c % 4 == 0) {
+                    a0 = fma(v.x, z[c], a0);
+                    a1 = fma(v.y, z[c + 1], a1);
+                } else {
+                    a2 = fma(v.x, z[c], a2);
+                    a3 = fma(v.y, z[c + 1], a3);
+                }
+            }
+            if constexpr (n % 2 == 1) a0 = fma(dl[n - 1], z[n - 1], a0);
+            xs = (a0 + a1) + (a2 + a3);
+        }
+        wave_lds_sync(); // Dm (D) and Lm (J) visible to the whole wavefront
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- MFMA tiles ----
+        // Pf[t] once more (L2-resident), this time as C-layout tiles Ib <= Jb: they seed the accumulators of
+        // product 2, so that what comes out of it is Ps[t] itself.  Issued here, they land during product 1.
+        // (Pf is stored as column runs = row-major of its transpose = itself; padded rows/columns are clamped
+        // duplicates that the masked tile write-back below never stores.)
+        constexpr int NT = NB * (NB + 1) / 2;
+        v4d Pt[NT];
+        {
+            const double *pf = iF.mat - r; // element (0, 0) of this step's covariance block
+            sfor<0, NB>(MK_LAMBDA(ib) {
+                constexpr int Ib = decltype(ib)::value;
+                sfor<Ib, NB>(MK_LAMBDA(jb) {
+                    constexpr int Jb = decltype(jb)::value;
+                    constexpr int ti = Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib);
+                    const int col = 16 * Jb + l15 < n ? 16 * Jb + l15 : n - 1;
+                    sfor<0, 4>(MK_LAMBDA(vv) {
+                        constexpr int v = decltype(vv)::value;
+                        const int row = 16 * Ib + l4 + 4 * v < n ? 16 * Ib + l4 + 4 * v : n - 1;
+                        Pt[ti][v] = pf[row * n + col];
+                    });
+                });
+            });
+        }
+        // J^T in C-layout: JT[Ib][ks] = J[16 Ib + l15][4 ks + l4] (k >= n only when n % 4 != 0: zero)
+        double JT[NB][KS];
+        sfor<0, NB>(MK_LAMBDA(ib) {
+            sfor<0, KS>(MK_LAMBDA(ks) {
+                constexpr int kb = 4 * decltype(ks)::value;
+                if constexpr (kb + 3 < n) {
+                    JT[decltype(ib)::value][decltype(ks)::value] = Lm[jt_row[decltype(ib)::value] + kb + l4];
+                } else {
+                    const int k = kb + l4;
+                    const double v = Lm[jt_row[decltype(ib)::value] + (k < n ? k : n - 1)];
+                    JT[decltype(ib)::value][decltype(ks)::value] = k < n ? v : 0.0;
+                }
+            });
+        });
+        // product 1: V^T = D J^T.  A operand: D[m][k'] (= D[k'][m]), m = 4 ms + l4 (K), k' = 16 Kb' + l15 (M).
+        // Only the rows of V^T that product 2 consumes as k-steps are kept: VK[s][Jb] = rows 4 s + l4.
+        double VK[KS][NB];
+        sfor<0, NB>(MK_LAMBDA(kb) {
+            constexpr int Kb = decltype(kb)::value;
+            const int kcol = 16 * Kb + l15 < n ? 16 * Kb + l15 : n - 1; // M padding: duplicates, harmless
+            double Da[KS];
+            sfor<0, KS>(MK_LAMBDA(ms) {
+                constexpr int mb = 4 * decltype(ms)::value;
+                if constexpr (mb + 3 < n) {
+                    Da[decltype(ms)::value] = Dm[(mb + l4) * LD + kcol];
+                } else {
+                    const int m = mb + l4;
+                    const double v = Dm[(m < n ? m : n - 1) * LD + kcol];
+                    Da[decltype(ms)::value] = m < n ? v : 0.0;
+                }
+            });
+            sfor<0, NB>(MK_LAMBDA(jb) {
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                sfor<0, KS>(MK_LAMBDA(ms) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Da[decltype(ms)::value],
+                                                               JT[decltype(jb)::value][decltype(ms)::value], acc, 0, 0, 0);
+                });
+                sfor<0, 4>(MK_LAMBDA(vv) {
+                    constexpr int s = 4 * Kb + decltype(vv)::value;
+                    if constexpr (s < KS) VK[s][decltype(jb)::value] = acc[decltype(vv)::value];
+                });
+            });
+        });
+        wave_lds_sync(); // all reads of D are done: Dm is free for Ps[t]
+        // product 2: Ps = Pf + J V^T, tiles Ib <= Jb, mirrored.  A operand J[i][k] = JT[Ib][ks]; B operand VK[ks][Jb]
+        {
+            sfor<0, NB>(MK_LAMBDA(ib) {
+                constexpr int Ib = decltype(ib)::value;
+                sfor<Ib, NB>(MK_LAMBDA(jb) {
+                    constexpr int Jb = decltype(jb)::value;
+                    v4d acc = Pt[Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib)];
+                    sfor<0, KS>(MK_LAMBDA(ks) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(JT[Ib][decltype(ks)::value], VK[decltype(ks)::value][Jb],
+                                                                   acc, 0, 0, 0);
+                    });
+                    const int col = 16 * Jb + l15;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * Ib + l4 + 4 * v;
+                        if (16 * Ib + 4 * v + 3 < n && 16 * Jb + 15 < n) { // interior: no mask (compile-time)
+                            Dm[row * LD + col] = acc[v];
+                            if constexpr (Ib != Jb) Dm[col * LD + row] = acc[v];
+                        } else if (row < n && col < n) {
+                            Dm[row * LD + col] = acc[v];
+                            if constexpr (Ib != Jb) Dm[col * LD + row] = acc[v];
+                        }
+                    }
+                });
+            });
+        }
+        wave_lds_sync();
+        load_row<n>(Dr, Psn);
+        store(xs, Psn);
+    }
+    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
+}
+
+// which smoother serves the shapes with n > 16: the MFMA kernel, or (MK_WIDE_SMOOTHER=v1 in the environment,
+// for A/B measurements) the round-1 kernel
+static bool use_v1()
+{
+    static const int v = [] {
+        const char *e = getenv("MK_WIDE_SMOOTHER");
+        return (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
+    }();
+    return v != 0;
+}
+
+template <int N, int K>
+static hipError_t launch_wide_nk(const SmootherArgs &a, hipStream_t s)
+{
+    if constexpr (N + K > 16) {
+        const unsigned grid = (unsigned)a.B;
+        const bool proj = a.sim_means || a.sim_vars;
+        if (use_v1()) {
+            if (proj) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
+        } else {
+            if (proj) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((smoother_mfma_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
+        }
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+#define MK_CASE_WIDE(NN, KK) \
+    if (N == NN && K == KK) return launch_wide_nk<NN, KK>(a, s);
+#define MK_CASE_WIDE_N(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_wide_nk<NN, KK>(a, s);
+hipError_t launch_smoother_wide(int N, int K, const SmootherArgs &a, hipStream_t s)
+{
+    MK_SHAPES(MK_CASE_WIDE)
+    MK_SHAPES(MK_CASE_WIDE_N)
+    return hipErrorInvalidValue;
+}
+
+} // namespace mk

@@ -20,6 +20,7 @@ logger = logging.getLogger(__name__)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SOURCES = [os.path.join(_HERE, "csrc", "mk_kernels.hip"), os.path.join(_HERE, "csrc", "mk_internal.h"),
+            os.path.join(_HERE, "csrc", "mk_prims.h"), os.path.join(_HERE, "csrc", "mk_wide.hip"),
             os.path.join(_ROOT, "include", "metran_hip.h")]
 
 
