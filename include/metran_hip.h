@@ -234,6 +234,32 @@ MK_API int mk_mask_observations(mk_context *ctx, int64_t count, const double *d_
 MK_API int mk_pack_observations(mk_context *ctx, int64_t R, int64_t T, int64_t N, const double *d_obs,
                                 double *d_observations, double *d_indices, int64_t *d_count);
 
+/* ---- batched factor analysis (what produces the loadings; metran/factoranalysis.py) ----------- */
+/* FactorAnalysis._get_correlations (factoranalysis.py:404-418; pandas DataFrame.corr, pearson, pairwise
+ * complete): d_corr [R,N,N] from NaN-encoded d_obs [R,T,N] ([T,R,N] when time_major != 0).  N <= 64. */
+MK_API int mk_fa_correlation(mk_context *ctx, int64_t R, int64_t T, int64_t N, int time_major,
+                             const double *d_obs, double *d_corr);
+/* _get_eigval (:420-460), _maptest (:220-312), the factor-count rules of solve (:66-82; maxfactors <= 0 =
+ * None) and the start vector of _minres (:188-203) for B correlation matrices.  d_eigval [B,N] descending,
+ * clipped at 0; d_nfactors / d_nfactors_map / d_nfactors_map4 [B]; d_psi0 [B,N]; d_status [B]: 1 = no factors
+ * can be derived (NaN correlation or singular matrix; the reference returns None).  Outputs may be NULL. */
+MK_API int mk_fa_analyse(mk_context *ctx, int64_t B, int64_t N, int64_t maxfactors, const double *d_corr,
+                         double *d_eigval, int64_t *d_nfactors, int64_t *d_nfactors_map, int64_t *d_nfactors_map4,
+                         double *d_psi0, uint32_t *d_status);
+/* _minresfun (:315-347), _minresgrad (:349-373) and _get_loadings (:375-401) for B vectors d_psi [B,N];
+ * instance b uses correlation matrix and factor count b % R.  d_fval [B], d_grad [B,N], d_loadings [B,N,KMAX]
+ * (columns >= nfactors zero); any output may be NULL. */
+MK_API int mk_fa_minres(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t KMAX, const double *d_corr,
+                        const int64_t *d_nfactors, const double *d_psi, double *d_fval, double *d_grad,
+                        double *d_loadings);
+/* Communality normalisation + varimax rotation (_rotate, :121-171; gamma = 1, maxiter = 20, tol = 1e-6 in the
+ * reference) + sign convention of FactorAnalysis.solve (:84-108), in place on d_loadings [B,N,KMAX]. */
+MK_API int mk_fa_rotate(mk_context *ctx, int64_t B, int64_t N, int64_t KMAX, const int64_t *d_nfactors,
+                        double *d_loadings, double gamma, int maxiter, double tol);
+/* Symmetric eigen-decomposition of B matrices d_sym [B,N,N] (cyclic Jacobi): d_val [B,N] descending, d_vec
+ * [B,N,N] eigenvectors in columns (may be NULL).  The one dense-linear-algebra routine of the kernels above. */
+MK_API int mk_fa_eigh(mk_context *ctx, int64_t B, int64_t N, const double *d_sym, double *d_val, double *d_vec);
+
 /* ---- instrumentation --------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
 MK_API int mk_enable_timing(mk_context *ctx, int enable);

@@ -104,6 +104,13 @@ API = {
     "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_mask_observations": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mk_pack_observations": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mk_fa_correlation": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mk_fa_analyse": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
+    "mk_fa_minres": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p]),
+    "mk_fa_rotate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double, c_int, c_double]),
+    "mk_fa_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mk_enable_timing": (c_int, [c_void_p, c_int]),
     "mk_last_kernel_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
 }

@@ -12,12 +12,14 @@ back-tracking line search evaluates one trial point per still-searching model pe
 The iteration is not scipy's L-BFGS-B code path (that is ``metran_amd.solver.HipSolve``, which keeps
 scipy on the host and reproduces the reference's trajectory for ONE model); it minimises the same
 objective -2 log L(alpha) under the same bounds alpha >= pmin (metran/metran.py:439-462) and reaches the
-same optimum.  With torch.distributed initialised, the models are simply sharded over the ranks
-(``distributed.shard_range``): per-model parameters need no collective.
+same optimum.  Multi-GPU (one process per GPU): ``calibrate_sharded`` gives every rank a contiguous slice of the
+models (``distributed.shard_range``) and gathers the per-model results in rank order -- per-model parameters need no
+collective; ``calibrate_shared`` fits ONE parameter vector to all models of all ranks (summed objective and summed
+adjoint gradient in one all-reduce of P+1 doubles per evaluation, ``ShardedObjective.value_and_grad``).
 """
 import numpy as np
 
-__all__ = ["calibrate_batch", "CalibrationResult"]
+__all__ = ["calibrate_batch", "calibrate_sharded", "calibrate_shared", "CalibrationResult"]
 
 
 class CalibrationResult(dict):
@@ -164,3 +166,49 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         res["nfev"] = nfev + (n + 1) * R
         res["launches"] = launches + 2
     return res
+
+
+
+def calibrate_sharded(n_models, build_engine, **kwargs):
+    """``calibrate_batch`` over the ranks of torch.distributed: ``build_engine(lo, hi)`` returns a ``BatchedKalman``
+    holding records ``lo .. hi-1`` (observations + loadings set); every rank calibrates its slice and the per-model
+    results (``alpha [R,P]``, ``obj``, ``converged``, ``pgnorm`` and, with ``stderr=True``, ``stderr``) come back
+    concatenated in rank order on every rank.  ``nfev``/``launches``/``nit`` are this rank's own."""
+    from .distributed import run_sharded
+
+    info = {}
+
+    def local(lo, hi):
+        res = calibrate_batch(build_engine(lo, hi), **kwargs)
+        info.update(nit=res.nit, nfev=res.nfev, launches=res.launches, shard=(lo, hi))
+        out = {k: res[k] for k in ("alpha", "obj", "pgnorm") if k in res}
+        out["converged"] = res.converged.to(res.obj.dtype)
+        if "stderr" in res:
+            out["stderr"] = res["stderr"]
+        return out
+
+    g = run_sharded(n_models, local)
+    g["converged"] = g["converged"] > 0.5
+    return CalibrationResult(aic=2 * g["alpha"].shape[1] + g["obj"], **g, **info)
+
+
+def calibrate_shared(local_value_and_grad, x0, pmin=1e-5, **kwargs):
+    """ONE parameter vector for all models of all ranks: scipy L-BFGS-B on the host (the reference's optimiser,
+    metran/solver.py:248-255) minimising the SUMMED objective.  ``local_value_and_grad(alpha [P]) -> (values [b],
+    grads [b,P])`` evaluates this rank's models (``BatchedKalman.loglik_grad_alpha`` on the alpha vector repeated for
+    every local record: forward filter + adjoint kernel); the ranks are combined by ``ShardedObjective.value_and_grad``
+    -- one all-reduce of P+1 float64 per evaluation, after which every rank holds bit-identical values and follows the
+    same iteration.  Returns scipy's result object."""
+    import torch
+    from scipy.optimize import minimize
+
+    from .distributed import ShardedObjective
+
+    obj = ShardedObjective(None)
+
+    def fun(x):
+        total, grad = obj.value_and_grad(torch.as_tensor(x, dtype=torch.float64), local_value_and_grad)
+        return float(total), grad.detach().cpu().numpy().astype(np.float64)
+
+    x0 = np.asarray(x0, dtype=np.float64)
+    return minimize(fun, x0, jac=True, method="l-bfgs-b", bounds=[(pmin, None)] * x0.size, **kwargs)

@@ -621,6 +621,55 @@ MK_API int mk_pack_observations(mk_context *ctx, int64_t R, int64_t T, int64_t N
     return MK_OK;
 }
 
+MK_API int mk_fa_correlation(mk_context *ctx, int64_t R, int64_t T, int64_t N, int time_major, const double *obs,
+                             double *corr)
+{
+    MK_CTX(ctx);
+    if (R <= 0 || T <= 0 || N <= 0 || N > 64 || !obs || !corr)
+        return fail(MK_ERR_INVALID, "mk_fa_correlation: bad argument (1 <= N <= 64)");
+    MK_HIP(mk::launch_fa_corr(R, T, (int)N, time_major, obs, corr, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_fa_analyse(mk_context *ctx, int64_t B, int64_t N, int64_t maxfactors, const double *corr, double *eigval,
+                         int64_t *nfactors, int64_t *nfactors_map, int64_t *nfactors_map4, double *psi0, uint32_t *status)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || N < 2 || N > 64 || !corr) return fail(MK_ERR_INVALID, "mk_fa_analyse: bad argument (2 <= N <= 64)");
+    MK_HIP(mk::launch_fa_analyse(B, (int)N, maxfactors, corr, eigval, (long long *)nfactors, (long long *)nfactors_map,
+                                 (long long *)nfactors_map4, psi0, status, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_fa_minres(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t KMAX, const double *corr,
+                        const int64_t *nfactors, const double *psi, double *fval, double *grad, double *loadings)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || R <= 0 || R > B || N < 2 || N > 64 || KMAX < 1 || KMAX > N || !corr || !nfactors || !psi)
+        return fail(MK_ERR_INVALID, "mk_fa_minres: bad argument (2 <= N <= 64, 1 <= KMAX <= N)");
+    MK_HIP(mk::launch_fa_minres(B, R, (int)N, (int)KMAX, corr, (const long long *)nfactors, psi, fval, grad, loadings,
+                                ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_fa_rotate(mk_context *ctx, int64_t B, int64_t N, int64_t KMAX, const int64_t *nfactors, double *loadings,
+                        double gamma, int maxiter, double tol)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || N < 1 || N > 64 || KMAX < 1 || KMAX > N || !nfactors || !loadings)
+        return fail(MK_ERR_INVALID, "mk_fa_rotate: bad argument");
+    MK_HIP(mk::launch_fa_rotate(B, (int)N, (int)KMAX, (const long long *)nfactors, loadings, gamma, maxiter, tol, ctx->stream));
+    return MK_OK;
+}
+
+MK_API int mk_fa_eigh(mk_context *ctx, int64_t B, int64_t N, const double *sym, double *val, double *vec)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || N < 1 || N > 64 || !sym || !val) return fail(MK_ERR_INVALID, "mk_fa_eigh: bad argument (1 <= N <= 64)");
+    MK_HIP(mk::launch_fa_eigh(B, (int)N, sym, val, vec, ctx->stream));
+    return MK_OK;
+}
+
 MK_API int mk_enable_timing(mk_context *ctx, int enable)
 {
     MK_CTX(ctx);

@@ -10,7 +10,7 @@ combines the ranks.  The reference has no counterpart (single process, metran/so
 """
 import os
 
-__all__ = ["shard_range", "init_from_env", "allreduce_sum", "gather_concat", "ShardedObjective"]
+__all__ = ["shard_range", "init_from_env", "world", "allreduce_sum", "gather_concat", "run_sharded", "ShardedObjective"]
 
 
 def shard_range(n_items, rank, world_size):
@@ -44,6 +44,30 @@ def init_from_env(backend=None):
             kwargs["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
+
+
+def world():
+    """``(rank, world_size)`` of the default process group; ``(0, 1)`` when torch.distributed is not initialised."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def run_sharded(n_items, local_fn):
+    """The data-parallel pattern of the whole path: rank r works on its contiguous slice ``[lo, hi)`` of the
+    ``n_items`` models -- ``local_fn(lo, hi) -> dict of tensors [hi-lo, ...]`` (e.g. ``calibrate_batch`` on an engine
+    holding those records) -- and the per-model results are concatenated in rank order on every rank.  No collective
+    inside ``local_fn``: models are independent."""
+    rank, size = world()
+    lo, hi = shard_range(n_items, rank, size)
+    local = local_fn(lo, hi)
+    out = {}
+    for k, t in local.items():
+        tail = tuple(t.shape[1:])
+        out[k] = gather_concat(t.reshape(-1)).reshape((-1,) + tail)
+    return out
 
 
 def allreduce_sum(t):

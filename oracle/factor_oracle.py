@@ -1,0 +1,161 @@
+"""CPU oracle for the factor analysis (row f4) -- TEST INFRASTRUCTURE ONLY, never imported by ``metran_amd``.
+
+A numpy restatement of /root/reference/metran/factoranalysis.py, each function citing the lines it follows.
+Parity status: PINNED against ``tests/golden/factor_analysis.npz`` (generated from the reference itself by
+``tests/golden/make_golden.py factor_analysis``; ``tests/test_factor_oracle.py``).
+
+Third-party arithmetic, as in the reference: ``numpy.linalg`` (LAPACK eig / eigh / svd / inv) and
+``scipy.optimize.minimize(method="L-BFGS-B")`` -- the optimiser is CALLED here exactly as the reference calls it
+(:209-216), not restated: its iteration path is what decides the result for the models where it leaves its start
+vector (fixtures ``g2`` and ``s6k1``; it returns the start vector unchanged, "ABNORMAL", for the others).
+"""
+import numpy as np
+
+EPS = np.finfo(float).eps
+
+
+def correlations(y):
+    """_get_correlations (:404-418): DataFrame.corr() = pairwise-complete Pearson, y [T,N] with NaN = missing."""
+    T, N = y.shape
+    c = np.full((N, N), np.nan)
+    for i in range(N):
+        for j in range(i, N):
+            m = ~np.isnan(y[:, i]) & ~np.isnan(y[:, j])
+            if m.sum() > 0:
+                dx = y[m, i] - y[m, i].mean()
+                dy = y[m, j] - y[m, j].mean()
+                den = np.sqrt((dx * dx).sum() * (dy * dy).sum())
+                if den != 0:
+                    c[i, j] = c[j, i] = (dx * dy).sum() / den
+    return c
+
+
+def get_eigval(correlation):
+    """_get_eigval (:420-460): descending eigenvalues (negatives -> 0), eigenvectors scaled by sqrt(eigval).
+    Same LAPACK routine as the reference (``eig``) so that the borderline MAP test of 2- and 3-series models,
+    which rounding decides (see ``maptest``), comes out as in the reference."""
+    w, v = np.linalg.eig(correlation)
+    order = np.argsort(-w)
+    w = w[order]
+    w[w < 0] = 0.0
+    return w, np.dot(v[:, order], np.sqrt(np.diag(w)))
+
+
+def maptest(cov, eigvec, eigval):
+    """_maptest (:220-312) -> (nfacts, nfacts4), restated WITH its indexing behaviour.  The reference stores the
+    criterion v_k (average squared partial correlation after removing k components) with ``np.put(fm, [k, 1], v)``
+    (:282-294), and ``np.put`` takes FLAT indices: v_k lands in ``fm.flat[k]`` and (every time) in ``fm.flat[1]``.
+    Read back as ``fm[s, 1]`` (:300-311) that is: fm[0,1] = v_{n-1} (the last one written), fm[s,1] = v_{2s+1} when
+    2s+1 <= n-1, and the initial ``arange`` value s otherwise.  So the test compares only the criteria of an ODD
+    number of removed components, against v_{n-1} (which is 1 up to rounding: a rank-one residual)."""
+    n = len(eigval)
+    v2 = np.empty(n)
+    v4 = np.empty(n)
+    v2[0] = (np.sum(cov ** 2) - n) / (n * (n - 1))
+    v4[0] = (np.sum(cov ** 4) - n) / (n * (n - 1))
+    with np.errstate(all="ignore"):
+        for m in range(n - 1):
+            a = eigvec[:, : m + 1]
+            pc = cov - np.dot(a, a.T)
+            if np.amin(np.diag(pc)) < 0:
+                return 1, 1
+            d = np.diag(1 / np.sqrt(np.diag(pc)))
+            pr = np.dot(d, np.dot(pc, d))
+            v2[m + 1] = (np.sum(pr ** 2) - n) / (n * (n - 1))
+            v4[m + 1] = (np.sum(pr ** 4) - n) / (n * (n - 1))
+
+    def pick(v):
+        col = np.array([float(s) for s in range(n)])
+        col[0] = v[n - 1]
+        for s in range(1, n):
+            if 2 * s + 1 <= n - 1:
+                col[s] = v[2 * s + 1]
+        best, nf = col[0], 0
+        for s in range(n):
+            if col[s] < best:
+                best, nf = col[s], s
+        return nf
+
+    return pick(v2), pick(v4)
+
+
+def minresfun(psi, s, nf):
+    """_minresfun (:315-347): note ``eigh`` is ascending and ``[:nf]`` takes the SMALLEST pairs."""
+    s2 = np.array(s, dtype=float)
+    np.fill_diagonal(s2, 1 - psi)
+    w, v = np.linalg.eigh(s2)
+    w = np.where(w < EPS, 100 * EPS, w)
+    if nf > 1:
+        load = v[:, :nf] * np.sqrt(w[:nf])[None, :]
+        model = load @ load.T
+    else:  # :341-343: a 1-D loading vector, and np.dot(l, l.T) of a 1-D array is the SCALAR l.l = w[0]
+        model = w[0]
+    res = (s2 - model) ** 2
+    np.fill_diagonal(res, 0)
+    return res.sum()
+
+
+def get_loadings(psi, s, nf):
+    """_get_loadings (:375-401) with the nf LARGEST eigenpairs of psi^-1/2 S psi^-1/2 (what LAPACK's ``eig``
+    returns first for these matrices in every fixture; column signs are LAPACK's and are not reproduced)."""
+    sc = 1 / np.sqrt(psi)
+    w, v = np.linalg.eigh(s * sc[:, None] * sc[None, :])
+    order = np.argsort(-w)[:nf]
+    load = v[:, order] * np.sqrt(np.maximum(w[order] - 1, 0))[None, :]
+    return np.sqrt(psi)[:, None] * load
+
+
+def minresgrad(psi, s, nf):
+    """_minresgrad (:349-373)."""
+    load = get_loadings(psi, s, nf)
+    g = load @ load.T + np.diag(psi) - s
+    return np.diag(g) / psi ** 2
+
+
+def start_vector(s):
+    """_minres start (:188-197): diag(s) - (1 - 1/diag(inv(s)))."""
+    return np.diag(s) - (1 - 1 / np.diag(np.linalg.inv(s)))
+
+
+def rotate(phi, gamma=1.0, maxiter=20, tol=1e-6):
+    """_rotate (:121-171), varimax for gamma = 1."""
+    p, k = phi.shape
+    R = np.eye(k)
+    d = 0.0
+    for _ in range(maxiter):
+        d_old = d
+        lam = phi @ R
+        u, sv, vh = np.linalg.svd(phi.T @ (lam ** 3 - (gamma / p) * lam @ np.diag(np.diag(lam.T @ lam))))
+        R = u @ vh
+        d = sv.sum()
+        if d_old != 0 and d / d_old < 1 + tol:
+            break
+    return phi @ R
+
+
+def solve(y, maxfactors=None):
+    """FactorAnalysis.solve (:42-119) -> dict(corr, eigval, nfactors_map, nfactors_map4, nfactors, psi, factors, fep)."""
+    import scipy.optimize as scopt
+
+    corr = correlations(y)
+    eigval, eigvec = get_eigval(corr)
+    nfm, nfm4 = maptest(corr, eigvec, eigval)
+    nf = nfm if nfm > 0 else int(np.sum(eigval > 1))
+    if maxfactors is not None:
+        nf = min(nf, maxfactors)
+    out = dict(corr=corr, eigval=eigval, nfactors_map=nfm, nfactors_map4=nfm4, nfactors=0, factors=None, fep=np.nan)
+    if nf == 0:
+        return out
+    start = start_vector(corr)
+    res = scopt.minimize(minresfun, start, method="L-BFGS-B", jac=minresgrad, bounds=[(0.005, 1)] * len(start),
+                         args=(corr, nf))
+    f = get_loadings(res.x, corr, nf)
+    out.update(psi0=np.clip(start, 0.005, 1), psi=res.x, nit=res.nit)
+    if np.count_nonzero(f) == 0:
+        return out
+    if nf > 1:
+        comm = (f ** 2).sum(1)
+        f = rotate(f / np.sqrt(comm)[:, None]) * np.sqrt(comm)[:, None]
+    f = np.where((f.sum(0) < 0)[None, :], -f, f)
+    out.update(nfactors=nf, factors=f, fep=100 * np.sum((eigval / eigval.sum())[:nf]))
+    return out

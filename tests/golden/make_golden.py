@@ -361,6 +361,95 @@ def heywood():
     np.savez_compressed(os.path.join(HERE, "heywood.npz"), **data)
 
 
+def factor_analysis():
+    """Row f4: ``FactorAnalysis.solve`` of the reference (metran/factoranalysis.py:42-119) and its pieces on
+    examples/data (BASELINE G1e: loadings 0.857982 ...), the seeded notebook model (G2: 0.93540765), the 2 x 2
+    matrix of the reference's own unit tests (tests/test_factoranalysis.py:10-17) and seeded synthetic models with
+    one, two and three common factors, missing observations included (pairwise-complete correlations).  What
+    scipy's L-BFGS-B did inside ``_minres`` is recorded as well (message, nit, nfev, x): it returns its start vector
+    in every case (see metran_amd/factoranalysis.py)."""
+    import scipy.optimize as scopt
+
+    from metran.factoranalysis import FactorAnalysis
+
+    cases = []
+    d = os.path.join(_refshim.REFERENCE_ROOT, "examples", "data")
+    series = []
+    for i in range(1, 6):
+        s = pd.read_csv(f"{d}/B21B021400{i}_res.csv", index_col=0, parse_dates=True).squeeze()
+        s.name = f"B21B021400{i}"
+        series.append(s)
+    cases.append(("g1", metran.Metran(series, name="B21B0214").oseries.values.astype(float)))
+    np.random.seed(20210505)
+    noise = np.random.multivariate_normal(np.zeros(3), np.diag(np.square([1, 0.6, 2])), 2001)
+    a = np.zeros_like(noise)
+    for i in range(1, noise.shape[0]):
+        a[i] = noise[i] + np.multiply(a[i - 1], np.array([0.80, 0.95, 0.90]))
+    cases.append(("g2", np.array([a[1:, 0] + a[1:, 2], a[1:, 1] + a[1:, 2]]).T))
+    rng = np.random.default_rng(424242)
+
+    def synth(N, K, T, strength, miss):
+        load = np.zeros((N, K))
+        for j in range(N):  # simple structure + small cross-loadings
+            load[j, j % K] = strength * rng.uniform(0.8, 1.0)
+            load[j] += rng.uniform(-0.08, 0.08, size=K)
+        f = np.zeros((T, K))
+        e = np.zeros((T, N))
+        for t in range(1, T):
+            f[t] = 0.9 * f[t - 1] + rng.standard_normal(K) * np.sqrt(1 - 0.81)
+            e[t] = 0.7 * e[t - 1] + rng.standard_normal(N) * np.sqrt(1 - 0.49)
+        y = f @ load.T + e * np.sqrt(np.maximum(1 - (load ** 2).sum(1), 0.05))
+        y[rng.random((T, N)) < miss] = np.nan
+        return y
+
+    cases.append(("s8k2", synth(8, 2, 1500, 0.85, 0.2)))
+    cases.append(("s12k3", synth(12, 3, 2500, 0.8, 0.1)))
+    cases.append(("s6k1", synth(6, 1, 800, 0.7, 0.3)))
+    cases.append(("s20k4", synth(20, 4, 3000, 0.85, 0.0)))
+    cases.append(("weak", rng.standard_normal((400, 5))))  # no structure: Kaiser fallback / whatever the reference does
+    data = {"names": np.array([c[0] for c in cases])}
+    orig = scopt.minimize
+    for name, y in cases:
+        rec = {}
+
+        def spy(fun, x0, *a_, **k_):
+            r = orig(fun, x0, *a_, **k_)
+            rec.update(x0=np.array(x0, float), x=np.array(r.x, float), nit=int(r.nit), nfev=int(r.nfev),
+                       message=str(r.message), fun0=float(fun(np.array(x0, float), *k_["args"])),
+                       grad0=np.array(k_["jac"](np.array(x0, float), *k_["args"]), float))
+            return r
+
+        scopt.minimize = spy
+        try:
+            fa = FactorAnalysis()
+            df = pd.DataFrame(y)
+            factors = fa.solve(df)
+            corr = fa._get_correlations(df)
+            ev, evec = fa._get_eigval(corr)
+            nfm, nfm4 = fa._maptest(corr, evec, ev)
+        finally:
+            scopt.minimize = orig
+        nf = 0 if factors is None else factors.shape[1]
+        out = dict(obs=y, corr=corr, eigval=fa.eigval, nfactors_map=np.int64(nfm), nfactors_map4=np.int64(nfm4),
+                   nfactors=np.int64(nf), factors=np.zeros((y.shape[1], 0)) if factors is None else factors,
+                   fep=np.float64(getattr(fa, "fep", np.nan) if factors is not None else np.nan))
+        if rec:
+            out.update(psi0=rec["x0"], psi=rec["x"], nit=np.int64(rec["nit"]), nfev=np.int64(rec["nfev"]),
+                       fun0=np.float64(rec["fun0"]), grad0=rec["grad0"], message=np.array(rec["message"]),
+                       loadings_unrotated=fa._get_loadings(rec["x"], corr, max(nf, 1)))
+        for k, v in out.items():
+            data[f"{name}_{k}"] = v
+        print("factor_analysis %-6s N=%d nf(map,map4,used)=(%d,%d,%d) lbfgsb: %s nit=%s |x-x0|=%.1e" % (
+            name, y.shape[1], nfm, nfm4, nf, rec.get("message"), rec.get("nit"),
+            np.abs(rec["x"] - rec["x0"]).max() if rec else float("nan")))
+    c2 = np.array([[1.0, 0.8], [0.8, 1.0]])
+    ev, evec = FactorAnalysis()._get_eigval(c2)
+    data["unit_corr"] = c2
+    data["unit_eigval"] = ev
+    data["unit_maptest"] = np.array(FactorAnalysis()._maptest(c2, evec, ev), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "factor_analysis.npz"), **data)
+
+
 def edge_nan(i, y):
     # model 0: series 1 never observed; model 1: a run of fully-empty steps and an inf
     if i == 0:
@@ -379,6 +468,7 @@ if __name__ == "__main__":
             globals()[name]()
         sys.exit(0)
     heywood()
+    factor_analysis()
     g1_real()
     g1_solve()
     g2_seeded()

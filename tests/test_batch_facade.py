@@ -46,6 +46,40 @@ def test_facade_on_examples_data(g1):
     assert list(st.columns) == ["B21B021400%d_sdf" % i for i in range(1, 6)] + ["cdf1"]
     np.testing.assert_allclose(st.values[:5], g1["state_means_head"], rtol=0, atol=1e-8)
     np.testing.assert_allclose(st.values[-5:], g1["state_means_tail"], rtol=0, atol=1e-8)
+    # decompose_simulation / get_state_variances / get_state (metran.py:682-756, 885-942) vs the reference's
+    dec = mb.decompose_simulation(0, "B21B0214001", alpha=astar)
+    assert list(dec.columns) == ["sdf", "cdf1"]
+    np.testing.assert_allclose(dec.values[:50], g1["decompose_001"], rtol=0, atol=1e-8)
+    sv = mb.get_state_variances(0, astar)
+    assert list(sv.columns) == list(st.columns)
+    np.testing.assert_allclose(sv.values[g1["tsel"]], np.diagonal(g1["Ps"], axis1=1, axis2=2), rtol=0, atol=1e-8)
+    s0 = mb.get_state(0, 0, astar)
+    from scipy.stats import norm
+
+    assert list(s0.columns) == ["mean", "lower", "upper"]
+    np.testing.assert_allclose(s0["mean"].values, g1["S"][:, 0], rtol=0, atol=1e-8)
+    np.testing.assert_allclose((s0["upper"] - s0["mean"]).values[g1["tsel"]], norm.ppf(0.975) * np.sqrt(g1["Ps"][:, 0, 0]),
+                               rtol=0, atol=1e-7)
+    ff = mb.get_state_means(0, astar, method="filter")
+    np.testing.assert_allclose(ff.values, g1["F"], rtol=0, atol=1e-8)
+    # the result cache (metran.py:978-989): the accessors above launched one run per kind for this parameter set
+    assert set(mb._cache) == {"project", "smoother", "filter"}
+    before = {k: id(v[1]) for k, v in mb._cache.items()}
+    mb.get_simulation(0, "B21B0214002", alpha=astar), mb.get_state(0, 3, astar), mb.decompose_simulation(1, "B21B0214003", astar)
+    assert {k: id(v[1]) for k, v in mb._cache.items()} == before
+    mb.get_state_means(0, astar * 1.01)   # another parameter set: recomputed
+    assert id(mb._cache["smoother"][1]) != before["smoother"]
+    # masking (metran.py:464-506): the projection at the masked date changes and the cache is dropped
+    import torch
+
+    mask = torch.zeros((2, 6255, 5), dtype=torch.uint8)
+    mask[0, int(g1["mask_t"]), 4] = 1
+    mb.mask_observations(mask)
+    msim = mb.get_simulation(0, "B21B0214005", alpha=astar, ci=None)
+    np.testing.assert_allclose(msim.values, g1["masked_sim_005"].ravel(), rtol=0, atol=1e-7)
+    mb.unmask_observations()
+    np.testing.assert_allclose(mb.get_simulation(0, "B21B0214005", alpha=astar, ci=None).values[:50],
+                               g1["get_simulation_005"][:, 0], rtol=0, atol=1e-8)
     # the padded model returns frames of its own length
     assert mb.get_simulation(1, "B21B0214001", alpha=astar).shape[0] == int(mb.batch.lengths[1]) < 6255
     with pytest.raises(KeyError, match="Unknown name"):

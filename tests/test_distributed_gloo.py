@@ -125,3 +125,74 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["value"] is None and "dry_run" in res
     assert res["allreduce_check"] == 3.0  # ranks contributed 1 + 2
     assert res["config"]["name"] == "c2" and res["config"]["batch_per_gpu"] == 4096
+
+
+def _worker_calibrate(rank, world, port, out_dir):
+    """Multi-GPU calibration paths on 2 CPU ranks: ``run_sharded`` (per-model parameters:
+    slice, local work, rank-order gather -- what ``calibrate_sharded`` wraps around ``calibrate_batch``) and
+    ``calibrate_shared`` (one parameter vector for all models of all ranks, scipy L-BFGS-B on the summed objective
+    and summed gradient, one all-reduce of P+1 doubles per evaluation).  The per-rank filter evaluation that the GPU
+    performs (mk_loglik_grad) is stood in for by the oracle's objective + adjoint restatement."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import adjoint_ref
+    from metran_amd.calibrate import calibrate_shared
+    from metran_amd.distributed import init_from_env, run_sharded, world as world_fn
+    from metran_amd.params import phi_q_from_alpha
+    from metran_amd.synthetic import make_dfm_batch
+
+    init_from_env(backend="gloo")
+    assert world_fn() == (rank, world)
+    Bc, Tc = 5, 40  # 5 models over 2 ranks: shards of 3 and 2
+
+    def local(lo, hi):  # per-model "results" that identify model and owner
+        idx = torch.arange(lo, hi, dtype=torch.float64)
+        return {"alpha": torch.stack([idx, idx * 10.0 + rank], 1), "obj": idx * idx}
+
+    g = run_sharded(Bc, local)
+    assert g["alpha"].shape == (Bc, 2) and g["obj"].tolist() == [float(i * i) for i in range(Bc)]
+    assert g["alpha"][:, 1].tolist() == [0.0, 10.0, 20.0, 31.0, 41.0]  # models 3, 4 came from rank 1
+
+    from metran_amd.distributed import shard_range
+
+    lo, hi = shard_range(Bc, rank, world)
+    d = make_dfm_batch(hi - lo, N, K, Tc, seed=SEED + 7, start=lo)
+
+    def local_value_and_grad(alpha_shared):
+        a = alpha_shared.numpy()
+        vals, grads = [], []
+        for b in range(hi - lo):
+            ph, qq = phi_q_from_alpha(a, d["loadings"][b])
+            m, gp, gq = adjoint_ref.gradient(d["obs"][b], ph, qq, d["loadings"][b])
+            c = np.r_[1.0 - (d["loadings"][b] ** 2).sum(1), np.ones(K)]
+            vals.append(m)
+            grads.append((gp - 2.0 * ph * c * gq) * ph / a ** 2)
+        return torch.tensor(vals), torch.tensor(np.array(grads))
+
+    res = calibrate_shared(local_value_and_grad, np.full(N + K, 10.0), options={"maxiter": 6})
+    np.save(os.path.join(out_dir, "c%d.npy" % rank), np.r_[res.fun, res.x, res.nfev])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_and_shared_calibration_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker_calibrate, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    c0, c1 = np.load(tmp_path / "c0.npy"), np.load(tmp_path / "c1.npy")
+    np.testing.assert_array_equal(c0, c1)  # every rank followed the same iteration to the same point
+    sys.path.insert(0, ROOT)
+    import oracle
+    from metran_amd.params import phi_q_from_alpha
+    from metran_amd.synthetic import make_dfm_batch
+
+    d = make_dfm_batch(5, N, K, 40, seed=SEED + 7)
+
+    def total(a):
+        ph, qq = phi_q_from_alpha(np.broadcast_to(a, (5, N + K)), d["loadings"])
+        return oracle.dfm_batch(d["obs"], ph, qq, d["loadings"], smooth=False, outputs="mle")["mle"].sum()
+
+    x = c0[1:-1]
+    assert abs(c0[0] - total(x)) <= 1e-9 * abs(c0[0])       # the reported optimum is the summed objective there
+    assert c0[0] < total(np.full(N + K, 10.0)) - 1e-3        # and it improved on the start

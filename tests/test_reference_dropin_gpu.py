@@ -179,3 +179,21 @@ def test_metran_masked_oseries(mt, g1):
         mt.unmask_observations()
     assert (proj1 != proj2).any().any()
     assert abs(mt.get_mle(p) - 2332.327069381027) < 1e-9 * 2332
+
+
+def test_metran_get_factors_on_the_device(metran, mt_init):
+    """Row f4 through the reference class: Metran.get_factors (metran.py:199-226) constructs FactorAnalysis by its
+    module-global name; with metran_amd.factoranalysis.install it is the MI355X one.  BASELINE.md G1e."""
+    import metran_amd.factoranalysis as hfa
+
+    hfa.install(metran)
+    try:
+        f = mt_init.get_factors()
+        assert isinstance(metran.metran.FactorAnalysis(), hfa.FactorAnalysis)
+    finally:
+        hfa.uninstall(metran)
+    assert f.shape == (5, 1) and mt_init.nfactors == 1
+    np.testing.assert_allclose(f.ravel(), [0.85798172, 0.93587365, 0.96619738, 0.95779419, 0.90085667], atol=1e-8)
+    np.testing.assert_allclose(mt_init.eigval, [4.41619129, 0.30437694, 0.13506397, 0.08427842, 0.06008939], atol=1e-8)
+    assert abs(mt_init.fep - 88.32382575015878) < 1e-8
+    assert not isinstance(metran.metran.FactorAnalysis(), hfa.FactorAnalysis)
