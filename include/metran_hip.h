@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define MK_API __attribute__((visibility("default")))
-#define MK_ABI_VERSION 1
+#define MK_ABI_VERSION 2
 
 typedef enum mk_status {
     MK_OK = 0,
@@ -121,7 +121,23 @@ typedef struct mk_outputs {
                               vectors were measured to throttle HBM writes).  mk_filter uses records when
                               the predicted AND filtered sets are both requested this way; mk_smooth when
                               d_F (and d_S) are record arrays.                                         */
+    int64_t flags;         /* MK_OUT_* bits (0 = none):
+                              MK_OUT_PACKED_SYM  the records are PACKED-SYMMETRIC: RS = mk_record_stride_sym(n),
+                                [ mean(n) | upper triangle by rows, n(n+1)/2 | sigma, detf | zero pad ],
+                                640 B instead of 896 B per (model, step) at n = 10, 5632 B instead of 10752 B at
+                                n = 36 (c_s = n + n(n+1)/2).  Pointer conventions as for
+                                records with n*n replaced by n(n+1)/2: d_Pf = d_F + n, d_sigmas = d_F + n +
+                                n(n+1)/2, ...  Element (r,c), r <= c, of a covariance sits at
+                                r*n - r(r-1)/2 + (c - r) of its triangle.  Requires record_stride != 0.
+                              MK_OUT_VAR_ONLY    mk_smooth / mk_filter_smooth write the smoothed state MEANS to
+                                d_S [B,T,n] and the smoothed state VARIANCES (diagonals of the covariances) to
+                                d_Ps [B,T,n], both dense (time_major applies), instead of smoothed records --
+                                what Metran.get_state_means / get_state_variances / get_state consume
+                                (metran.py:655-756).  d_F/d_Pf stay a (full or packed-symmetric) record array;
+                                d_Xp/d_Pp must be NULL in mk_filter_smooth (filtered record only).          */
 } mk_outputs;
+#define MK_OUT_PACKED_SYM 1
+#define MK_OUT_VAR_ONLY 2
 
 /* ---- library / context ------------------------------------------------------------------ */
 MK_API int mk_abi_version(void);
@@ -141,6 +157,8 @@ MK_API int mk_shape_supported(int64_t N, int64_t K);
 MK_API int mk_register_shape_module(const char *path);
 /* Doubles per packed record (see mk_outputs.record_stride) for state dimension n = N + K. */
 MK_API int64_t mk_record_stride(int64_t n);
+/* ... per PACKED-SYMMETRIC record (mk_outputs.flags & MK_OUT_PACKED_SYM). */
+MK_API int64_t mk_record_stride_sym(int64_t n);
 /* Writes up to `cap` supported (N,K) pairs into shapes[2*i], shapes[2*i+1]; returns the count. */
 MK_API int mk_supported_shapes(int64_t *shapes, int cap);
 

@@ -66,6 +66,7 @@ class Outputs(Structure):
         ("d_sim_means", c_void_p),
         ("d_sim_vars", c_void_p),
         ("record_stride", c_int64),
+        ("flags", c_int64),
     ]
 
 
@@ -81,6 +82,7 @@ API = {
     "mk_shape_supported": (c_int, [c_int64, c_int64]),
     "mk_register_shape_module": (c_int, [c_char_p]),
     "mk_record_stride": (c_int64, [c_int64]),
+    "mk_record_stride_sym": (c_int64, [c_int64]),
     "mk_supported_shapes": (c_int, [c_i64p, c_int]),
     "mk_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "mk_free": (c_int, [c_void_p, c_void_p]),
@@ -144,8 +146,8 @@ def lib():
             raise MetranHipError("%s does not export %s (stale build?)" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if L.mk_abi_version() != 1:
-        raise MetranHipError("ABI version mismatch: library %d, binding 1" % L.mk_abi_version())
+    if L.mk_abi_version() != 2:
+        raise MetranHipError("ABI version mismatch: library %d, binding 2" % L.mk_abi_version())
     _lib = L
     return L
 

@@ -225,6 +225,7 @@ MK_API int mk_shape_supported(int64_t N, int64_t K)
 }
 
 MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
+MK_API int64_t mk_record_stride_sym(int64_t n) { return mk::record_stride_sym((int)n); }
 
 MK_API int mk_supported_shapes(int64_t *shapes, int cap)
 {
@@ -327,10 +328,16 @@ static int check_problem(const mk_problem *p)
 // 1 if it does (and is consistent), < 0 on an inconsistent description.
 static int records_filter(const mk_problem *p, const mk_outputs *o)
 {
-    if (o->record_stride == 0) return 0;
-    const int64_t n = p->N + p->K, nv = n + n * n;
-    if (o->record_stride != mk::record_stride((int)n))
-        return fail(MK_ERR_INVALID, "record_stride must be mk_record_stride(n) = %d doubles", mk::record_stride((int)n));
+    const bool sym = (o->flags & MK_OUT_PACKED_SYM) != 0;
+    if (o->record_stride == 0) {
+        if (sym) return fail(MK_ERR_INVALID, "MK_OUT_PACKED_SYM needs the record layout (record_stride = mk_record_stride_sym(n))");
+        return 0;
+    }
+    const int64_t n = p->N + p->K, nc = sym ? n * (n + 1) / 2 : n * n, nv = n + nc;
+    const int64_t want = sym ? mk::record_stride_sym((int)n) : mk::record_stride((int)n);
+    if (o->record_stride != want)
+        return fail(MK_ERR_INVALID, "record_stride must be %s(n) = %lld doubles", sym ? "mk_record_stride_sym" : "mk_record_stride",
+                    (long long)want);
     const bool any = o->d_F || o->d_Pf || o->d_Xp || o->d_Pp;
     if (!any) return 0; // bookkeeping-only / loglik launches do not touch state arrays
     if (!(o->d_F && o->d_Pf == o->d_F + n))
@@ -339,7 +346,8 @@ static int records_filter(const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_INVALID, "record layout needs d_Pp = d_Xp + n (or both NULL: filtered record only)");
     if (o->d_sigmas || o->d_detfs)
         if (o->d_sigmas != o->d_F + nv || (o->d_detfs && o->d_detfs != o->d_sigmas + 1))
-            return fail(MK_ERR_INVALID, "record layout needs d_sigmas = d_F + n + n*n and d_detfs = d_sigmas + 1");
+            return fail(MK_ERR_INVALID, "record layout needs d_sigmas = d_F + n + %s and d_detfs = d_sigmas + 1",
+                        sym ? "n*(n+1)/2" : "n*n");
     return 1;
 }
 
@@ -350,6 +358,7 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (rec < 0) return rec;
     mk::FilterArgs a;
     a.rs = rec ? o->record_stride : 0;
+    a.sym = (rec && (o->flags & MK_OUT_PACKED_SYM)) ? 1 : 0;
     // dense sigmas/detfs are [B,T] (stride 1); inside filtered records they are RS doubles apart
     a.sig_stride = o->record_stride ? o->record_stride : 1;
     a.B = p->n_instances;
@@ -391,20 +400,32 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
     mk::SmootherArgs a;
     a.rs = 0;
+    a.sym = 0;
+    a.state_means = a.state_vars = nullptr;
+    const bool sym = (o->flags & MK_OUT_PACKED_SYM) != 0, var = (o->flags & MK_OUT_VAR_ONLY) != 0;
     if (o->record_stride) {
         const int64_t n = p->N + p->K;
-        if (o->record_stride != mk::record_stride((int)n))
-            return fail(MK_ERR_INVALID, "record_stride must be mk_record_stride(n) = %d doubles", mk::record_stride((int)n));
+        const int64_t want = sym ? mk::record_stride_sym((int)n) : mk::record_stride((int)n);
+        if (o->record_stride != want)
+            return fail(MK_ERR_INVALID, "record_stride must be %s(n) = %lld doubles", sym ? "mk_record_stride_sym" : "mk_record_stride",
+                        (long long)want);
         const bool proj = o->d_sim_means || o->d_sim_vars;
         if (o->d_Pf != o->d_F + n) return fail(MK_ERR_INVALID, "record layout needs d_Pf = d_F + n");
-        if ((o->d_S || o->d_Ps) && !(o->d_S && o->d_Ps == o->d_S + n))
-            return fail(MK_ERR_INVALID, "record layout needs a smoothed record array d_S with d_Ps = d_S + n");
-        if (!o->d_S && !proj)
-            return fail(MK_ERR_INVALID, "nothing to write: give d_S/d_Ps records or d_sim_means/d_sim_vars");
+        if (var) {
+            if (!o->d_S || !o->d_Ps || proj)
+                return fail(MK_ERR_INVALID, "MK_OUT_VAR_ONLY needs d_S [B,T,n] (means) and d_Ps [B,T,n] (variances), no projection outputs");
+        } else {
+            if ((o->d_S || o->d_Ps) && !(o->d_S && o->d_Ps == o->d_S + n))
+                return fail(MK_ERR_INVALID, "record layout needs a smoothed record array d_S with d_Ps = d_S + n");
+            if (!o->d_S && !proj)
+                return fail(MK_ERR_INVALID, "nothing to write: give d_S/d_Ps records or d_sim_means/d_sim_vars");
+        }
         if (proj && !p->d_loadings) return fail(MK_ERR_INVALID, "the projection outputs need d_loadings");
         a.rs = o->record_stride;
-    } else if (o->d_sim_means || o->d_sim_vars) {
-        return fail(MK_ERR_INVALID, "d_sim_means / d_sim_vars need the record layout (record_stride = mk_record_stride(n))");
+        a.sym = sym ? 1 : 0;
+    } else if (o->d_sim_means || o->d_sim_vars || sym || var) {
+        return fail(MK_ERR_INVALID, "d_sim_means / d_sim_vars, MK_OUT_PACKED_SYM and MK_OUT_VAR_ONLY need the record layout "
+                                    "(record_stride = mk_record_stride[_sym](n))");
     }
     a.R = p->n_records;
     a.loadings = p->d_loadings;
@@ -420,8 +441,12 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.q = p->d_q;
     a.F = o->d_F;
     a.Pf = o->d_Pf;
-    a.S = o->d_S;
-    a.Ps = o->d_Ps;
+    a.S = var ? nullptr : o->d_S;
+    a.Ps = var ? nullptr : o->d_Ps;
+    if (var) {
+        a.state_means = o->d_S;
+        a.state_vars = o->d_Ps;
+    }
     a.status = o->d_status;
     if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     MK_HIP(dispatch_smoother((int)p->N, (int)p->K, a, ctx->stream));
@@ -497,6 +522,8 @@ MK_API int mk_filter_smooth(mk_context *ctx, const mk_problem *p, const mk_outpu
     MK_CTX(ctx);
     if (int rc = check_problem(p)) return rc;
     if (!o) return fail(MK_ERR_INVALID, "null mk_outputs");
+    if ((o->flags & MK_OUT_VAR_ONLY) && (o->d_Xp || o->d_Pp))
+        return fail(MK_ERR_INVALID, "MK_OUT_VAR_ONLY: d_Xp / d_Pp must be NULL (the filter writes the filtered record only)");
     if (int rc = do_filter(ctx, p, o)) return rc;
     return do_smooth(ctx, p, o);
 }

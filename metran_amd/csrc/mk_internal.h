@@ -25,6 +25,7 @@ struct FilterArgs {
     long B, R, T, warmup;
     long bs, ts;         // state/bookkeeping outputs: block (b, t) at index b*bs + t*ts
     long rs;             // > 0: packed records of rs doubles (Xp/F are the record arrays), 0: dense arrays
+    long sym;            // records are packed-symmetric (MK_OUT_PACKED_SYM): rs = record_stride_sym(n)
     long sig_stride;     // element stride of sigmas/detfs entries (1 for dense [B,T] arrays)
     long obs_bs, obs_ts; // observations: record (r, t) at row r*obs_bs + t*obs_ts
     const double *obs, *phi, *q, *loadings, *obsvar, *x0, *P0;
@@ -38,6 +39,8 @@ struct SmootherArgs {
     long B, T;
     long bs, ts;
     long rs;             // > 0: F and S are packed-record arrays (Pf = F + n, Ps = S + n)
+    long sym;            // records are packed-symmetric
+    double *state_means, *state_vars; // MK_OUT_VAR_ONLY: [., n] smoothed state means / variances (dense)
     long R;              // observation records (loadings / scale / offset are per record)
     const double *loadings, *scale, *offset; // fused projection epilogue (record kernel, optional)
     double *sim_means, *sim_vars;            // [.,N] per (b,t), same (bs, ts) addressing
@@ -75,6 +78,7 @@ hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, 
 hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s);
 hipError_t launch_smoother_wide(int N, int K, const SmootherArgs &a, hipStream_t s); // mk_wide.hip (n > 16)
 int record_stride(int n); // doubles per packed record for state dimension n
+int record_stride_sym(int n); // ... per packed-symmetric record
 int num_shapes();
 void get_shape(int i, int *N, int *K);
 hipError_t launch_params(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,

@@ -24,7 +24,7 @@ namespace mk {
 //   BOOK : per-step sigmas/detfs are written (needs one log per step); otherwise the
 //          log-determinant is accumulated as a normalised product with ONE log at the end
 // =====================================================================================
-template <int n, int G>
+template <int n, int G, bool SYM>
 struct RecordIO;
 // packed records of the 16-lane kernels leave through wave-private LDS images as whole 16-byte chunks
 // (8 global_store_dwordx4 per step instead of 24 column-run dwordx2 stores: 1.52 -> 1.47 ms at B=4096)
@@ -34,9 +34,10 @@ struct RecordIO;
 
 // (two resident wavefronts per SIMD are asked for only while the wide variant's two n-double row arrays fit
 // 256 VGPRs: compile-checked at n = 64, the constraint spilled 1.1 KB per lane)
-template <int N, int K, int G, int OUT, bool BOOK>
+template <int N, int K, int G, int OUT, bool BOOK, bool SYM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 && N + K <= 40 ? 2 : 1))) filter_kernel(FilterArgs a)
 {
+    static_assert(!SYM || OUT == 1 || OUT == 3, "packed-symmetric layout applies to record outputs");
     constexpr int n = N + K;
     static_assert(n <= G, "state dimension must fit the lane group");
     using Gp = Group<G>;
@@ -98,13 +99,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     MomentPtr oF = moment_ptr<n>(a.F, a.Pf, inst * a.bs, a.ts, RECF ? a.rs : 0, r);      // filtered moments
     // OUT == 1 (packed records): the RS - NV pad doubles of both records are written too (whole cache
     // lines): lane l owns pad slot min(l, PADN-1); filtered record: slot 0 = sigma, slot 1 = detf, rest 0
-    constexpr int RS = record_stride_c(n), PADN = RS - NV;
+    // (RS / NVO: stride and payload of the record in HBM -- full-square or packed-symmetric)
+    constexpr int RS = SYM ? record_stride_sym_c(n) : record_stride_c(n), NVO = SYM ? record_payload_sym(n) : NV;
+    constexpr int PADN = RS - NVO;
     const int pslot = lane < PADN ? lane : PADN - 1;
-    double *padF = RECF ? a.F + inst * a.bs * RS + NV + pslot : nullptr;
-    double *padP = OUT == 1 ? a.Xp + inst * a.bs * RS + NV + pslot : nullptr;
+    double *padF = RECF ? a.F + inst * a.bs * RS + NVO + pslot : nullptr;
+    double *padP = OUT == 1 ? a.Xp + inst * a.bs * RS + NVO + pslot : nullptr;
     // records leave through wave-private LDS images as whole 16-byte chunks (as in the smoother)
     constexpr bool LDSOUT = MK_FILTER_LDS_STORES && RECF && G == 16;
-    using RIO = RecordIO<n, G>;
+    using RIO = RecordIO<n, G, SYM>;
     __shared__ __attribute__((aligned(16))) double lds_rec[LDSOUT ? 4 * 2 * RIO::LDS_PER_WAVE : 1];
     double *imgP = lds_rec + (LDSOUT ? (threadIdx.x / 64) * 2 * RIO::LDS_PER_WAVE : 0);
     double *imgF = imgP + (LDSOUT ? RIO::LDS_PER_WAVE : 0);
@@ -214,7 +217,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             RIO::put(imgP, gw, r, x, P);
         } else if constexpr (OUT == 1) {
             *oP.vec = x;               // :332
-            store_cols<n>(oP.mat, P);  // :333
+            if constexpr (SYM) store_cols_sym<n>(oP.mat - r, P, r);
+            else store_cols<n>(oP.mat, P);  // :333
             *padP = 0.0;
             oP.advance_nn(1);
             padP += a.ts * RS;
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
                         pad0 = sigma;
                         pad1 = detf;
                     } else if (lead && a.sigmas)
-                        *reinterpret_cast<v2d *>(a.F + (inst * a.bs + sc * a.ts) * RS + NV) = v2d{sigma, detf};
+                        *reinterpret_cast<v2d *>(a.F + (inst * a.bs + sc * a.ts) * RS + NVO) = v2d{sigma, detf};
                 } else {
                     if (a.sigmas && lead) a.sigmas[(inst * a.bs + sc * a.ts) * a.sig_stride] = sigma;
                     if (a.detfs && lead) a.detfs[(inst * a.bs + sc * a.ts) * a.sig_stride] = detf;
@@ -342,7 +346,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             recF += rstep;
         } else if constexpr (RECF) {
             *oF.vec = x;               // :389
-            store_cols<n>(oF.mat, P);  // :390
+            if constexpr (SYM) store_cols_sym<n>(oF.mat - r, P, r);
+            else store_cols<n>(oF.mat, P);  // :390
             *padF = pad;               // sigma | detf | zeros
             oF.advance_nn(1);
             padF += a.ts * RS;
@@ -380,21 +385,56 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 // The smoother both reads and writes a record per step; moving whole 16-byte chunks of the
 // wavefront's GW adjacent records (lane l <-> chunks l, l+64, ...) and transposing through a
 // wave-private LDS image measured faster there (1.65 ms) than symmetric column runs (2.1 ms).
-template <int n, int G>
+// SYM (mk_outputs.flags & MK_OUT_PACKED_SYM): the record in HBM is PACKED-SYMMETRIC,
+//     [ mean(n) | upper triangle by rows: (0,0..n-1) (1,1..n-1) ... | sigma, detf | zero pad ]   RSO doubles,
+// n + n(n+1)/2 (+2) doubles padded to 128 bytes (n = 10: 640 B instead of 896 B).  The LDS image keeps the full
+// square layout (the lanes still put / read whole rows); only the chunk maps change: a 16-byte chunk of the packed
+// record is two doubles gathered from (scattered to) two image positions, and a loaded off-diagonal element is
+// written to its mirror position as well.
+template <int n, int G, bool SYM>
 struct RecordIO {
-    static constexpr int NV = n + n * n;                    // payload doubles
-    static constexpr int RS = record_stride_c(n);           // record stride in doubles (128-byte multiple)
-    static constexpr int RC = RS / 2;                       // 16-byte chunks per record
+    static constexpr int NV = n + n * n;                    // payload doubles of the IMAGE (full square)
+    static constexpr int RS = record_stride_c(n);           // image stride per model, doubles
+    static constexpr int NVO = SYM ? record_payload_sym(n) : NV;   // payload doubles of the HBM record
+    static constexpr int RSO = SYM ? record_stride_sym_c(n) : RS;  // HBM record stride in doubles (128-byte multiple)
+    static constexpr int RC = RSO / 2;                      // 16-byte chunks per record
     static constexpr int GW = 64 / G;                       // models per wavefront
     static constexpr int CW = GW * RC;                      // chunks per wavefront-step
     static constexpr int PER = (CW + 63) / 64;              // chunks per lane
-    static constexpr int LDS_PER_WAVE = GW * RS;            // doubles of one wavefront image
+    static constexpr int SPARE = GW * RS;                   // SYM: two spare doubles behind the image (zeros / dump)
+    static constexpr int LDS_PER_WAVE = GW * RS + (SYM ? 2 : 0); // doubles of one wavefront image
     using chunk_t = v2d;
 
     struct Map {          // loop-invariant per-lane addressing of its PER chunks
         long off[PER];    // element offset of the chunk inside the record ARRAY at t = 0
-        int lq[PER];      // chunk index inside the wavefront's LDS image
+        int lq[PER];      // !SYM: chunk index inside the wavefront's LDS image
+        int a0[SYM ? PER : 1], a1[SYM ? PER : 1]; // SYM: image position of the chunk's two doubles (store side)
+        int b0[SYM ? PER : 1], b1[SYM ? PER : 1]; // SYM: the same for the load side (pads go to the dump slot)
+        int m0[SYM ? PER : 1], m1[SYM ? PER : 1]; // SYM: mirror positions (c,r) of loaded off-diagonal elements
     };
+    // packed index p of a record -> position inside ONE model's image block; kind: 0 payload, 1 sigma/detf, 2 zero pad
+    static __device__ __forceinline__ void locate(int p, int &pos, int &mirror, int &kind)
+    {
+        kind = 0;
+        if (p < n) {
+            pos = mirror = p;
+        } else if (p < NVO) {
+            int u = p - n, r = 0;
+            while (u >= n - r) {
+                u -= n - r;
+                ++r;
+            }
+            const int c = r + u;
+            pos = n + r * n + c;
+            mirror = n + c * n + r;
+        } else if (p < NVO + 2) {
+            pos = mirror = NV + (p - NVO);
+            kind = 1;
+        } else {
+            pos = mirror = 0;
+            kind = 2;
+        }
+    }
     static __device__ __forceinline__ Map make_map(int lane64, long inst0, long B, long bs)
     {
         Map mp;
@@ -405,8 +445,19 @@ struct RecordIO {
             const int g = q / RC, w = q - g * RC;
             long ig = inst0 + g;
             if (ig > B - 1) ig = B - 1; // surplus groups replicate the last model
-            mp.off[m] = ig * bs * RS + 2 * w;
+            mp.off[m] = ig * bs * RSO + 2 * w;
             mp.lq[m] = q;
+            if constexpr (SYM) {
+                int pos, mir, kind;
+                locate(2 * w, pos, mir, kind);
+                mp.a0[m] = kind == 2 ? SPARE : g * RS + pos;
+                mp.b0[m] = kind == 0 ? g * RS + pos : SPARE;
+                mp.m0[m] = kind == 0 ? g * RS + mir : SPARE;
+                locate(2 * w + 1, pos, mir, kind);
+                mp.a1[m] = kind == 2 ? SPARE + 1 : g * RS + pos;
+                mp.b1[m] = kind == 0 ? g * RS + pos : SPARE + 1;
+                mp.m1[m] = kind == 0 ? g * RS + mir : SPARE + 1;
+            }
         }
         return mp;
     }
@@ -420,22 +471,28 @@ struct RecordIO {
     {
         *reinterpret_cast<v2d *>(img + g * RS + NV) = v2d{s0, s1};
     }
-    // zero the pad tail [NV+2, RS) of every record once (it is never rewritten)
+    // zero the pad tail [NV+2, RS) of every record once (it is never rewritten); SYM: and the two spare doubles
     static __device__ __forceinline__ void clear_tail(double *img, int lane64)
     {
         for (int i = lane64; i < GW * (RS - NV - 2); i += 64) {
             const int g = i / (RS - NV - 2 > 0 ? RS - NV - 2 : 1), w = i % (RS - NV - 2 > 0 ? RS - NV - 2 : 1);
             img[g * RS + NV + 2 + w] = 0.0;
         }
+        if constexpr (SYM)
+            if (lane64 < 2) img[SPARE + lane64] = 0.0;
     }
-    // LDS image -> HBM records of this step (base = record array + t*ts*RS)
+    static __device__ __forceinline__ chunk_t gather(const double *img, const Map &mp, int m)
+    {
+        if constexpr (SYM) return chunk_t{img[mp.a0[m]], img[mp.a1[m]]};
+        else return reinterpret_cast<const chunk_t *>(img)[mp.lq[m]];
+    }
+    // LDS image -> HBM records of this step (base = record array + t*ts*RSO)
     static __device__ __forceinline__ void emit(const double *img, double *base, const Map &mp)
     {
         wave_lds_sync();
-        const chunk_t *l = reinterpret_cast<const chunk_t *>(img);
         chunk_t tmp[PER];
 #pragma unroll
-        for (int m = 0; m < PER; ++m) tmp[m] = l[mp.lq[m]];
+        for (int m = 0; m < PER; ++m) tmp[m] = gather(img, mp, m);
 #pragma unroll
         for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base + mp.off[m]) = tmp[m];
     }
@@ -443,13 +500,11 @@ struct RecordIO {
                                                  const Map &mp)
     {
         wave_lds_sync();
-        const chunk_t *l0 = reinterpret_cast<const chunk_t *>(img0);
-        const chunk_t *l1 = reinterpret_cast<const chunk_t *>(img1);
         chunk_t t0[PER], t1[PER];
 #pragma unroll
         for (int m = 0; m < PER; ++m) {
-            t0[m] = l0[mp.lq[m]];
-            t1[m] = l1[mp.lq[m]];
+            t0[m] = gather(img0, mp, m);
+            t1[m] = gather(img1, mp, m);
         }
 #pragma unroll
         for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base0 + mp.off[m]) = t0[m];
@@ -467,18 +522,31 @@ struct RecordIO {
                                                        int r, double &x, double (&row)[n])
     {
         wave_lds_sync();
-        chunk_t *l = reinterpret_cast<chunk_t *>(img);
+        if constexpr (SYM) {
 #pragma unroll
-        for (int m = 0; m < PER; ++m) l[mp.lq[m]] = buf[m];
+            for (int m = 0; m < PER; ++m) {
+                img[mp.b0[m]] = buf[m].x;
+                img[mp.b1[m]] = buf[m].y;
+                img[mp.m0[m]] = buf[m].x; // mirror of an off-diagonal element; means and diagonals rewrite themselves
+                img[mp.m1[m]] = buf[m].y;
+            }
+        } else {
+            chunk_t *l = reinterpret_cast<chunk_t *>(img);
+#pragma unroll
+            for (int m = 0; m < PER; ++m) l[mp.lq[m]] = buf[m];
+        }
         wave_lds_sync();
         x = img[g * RS + r];
         load_row<n>(img + g * RS + n + r * n, row);
     }
 };
 
-template <int N, int K, int G, bool PROJ>
+// EPI: 0 = smoothed records only; 1 = + fused projection (sim_means / sim_vars, section f2); 2 = + state means and
+// VARIANCES (mk_outputs.flags & MK_OUT_VAR_ONLY: what get_state_means / get_state_variances / get_state consume)
+template <int N, int K, int G, int EPI, bool SYM>
 __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
 {
+    constexpr bool PROJ = (EPI == 1), VAR = (EPI == 2);
     constexpr int n = N + K;
     static_assert(n <= G, "state dimension must fit the lane group");
     using Gp = Group<G>;
@@ -501,7 +569,7 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
     // REC: packed records (RecordIO): one load image and one store image per wavefront;
     // !REC: dense arrays with arbitrary strides (BlockIO), one staging buffer per model
     constexpr bool REC = true;
-    using RIO = RecordIO<n, G>;
+    using RIO = RecordIO<n, G, SYM>;
     constexpr int LDS_DOUBLES = 4 * 2 * RIO::LDS_PER_WAVE;
     __shared__ __attribute__((aligned(16))) double lds_io[LDS_DOUBLES];
     const int lane64 = threadIdx.x & 63;
@@ -517,7 +585,7 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
     typename RIO::chunk_t prer[RIO::PER]; // chunks of the next filtered record
 
     // addressing: (b, t) at block index b*bs + t*ts
-    const long rstep = a.ts * RIO::RS;
+    const long rstep = a.ts * RIO::RSO;
     const double *recF = a.F + (T - 1) * rstep; // record array positioned at step t
     double *recS = a.S ? a.S + (T - 1) * rstep : nullptr; // smoothed records are optional when projecting
 
@@ -534,6 +602,12 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
         const long pidx = (inst * a.bs + (T - 1) * a.ts) * N + jr;
         pM = a.sim_means ? a.sim_means + pidx : nullptr;
         pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
+    }
+    double *sM = nullptr, *sV = nullptr; // VAR: state means / variances [., n]
+    if constexpr (VAR) {
+        const long sidx = (inst * a.bs + (T - 1) * a.ts) * n + r;
+        sM = a.state_means + sidx;
+        sV = a.state_vars + sidx;
     }
 
     // fetch helpers: issue the HBM loads of one step / turn them into (x_r, row r)
@@ -559,6 +633,16 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             }
             if (pM) pM -= a.ts * N;
             if (pV) pV -= a.ts * N;
+        }
+        if constexpr (VAR) {
+            double diag = 0.0;
+            sfor<0, n>(MK_LAMBDA(c) { diag = (decltype(c)::value == lane) ? row[decltype(c)::value] : diag; });
+            if (lane < n && live) {
+                *sM = xv;
+                *sV = diag;
+            }
+            sM -= a.ts * n;
+            sV -= a.ts * n;
         }
     };
 
@@ -1243,15 +1327,19 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     const bool book = a.sigmas || a.detfs;
     const bool any = a.F || a.Pf || a.Xp || a.Pp;
     if (!any && !book)
-        hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false, false>), dim3(grid), dim3(256), 0, s, a);
     else if (!any)
-        hipLaunchKernelGGL((filter_kernel<N, K, G, 0, true>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 0, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rs > 0 && a.Xp && a.sym) // packed-symmetric records
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 1, true, true>), dim3(grid), dim3(256), 0, s, a);
     else if (a.rs > 0 && a.Xp) // packed records (validated by the C ABI): whole-cache-line stores
-        hipLaunchKernelGGL((filter_kernel<N, K, G, 1, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.rs > 0) // filtered record only
-        hipLaunchKernelGGL((filter_kernel<N, K, G, 3, true>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 1, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rs > 0 && a.sym) // filtered record only
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 3, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.rs > 0)
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 3, true, false>), dim3(grid), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((filter_kernel<N, K, G, 2, true>), dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_kernel<N, K, G, 2, true, false>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1265,11 +1353,20 @@ static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
     } else {
         constexpr int GPB = 256 / G;
         const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
-        if (a.rs > 0 && (a.sim_means || a.sim_vars))
-            hipLaunchKernelGGL((smoother_record_kernel<N, K, G, true>), dim3(grid), dim3(256), 0, s, a);
-        else if (a.rs > 0)
-            hipLaunchKernelGGL((smoother_record_kernel<N, K, G, false>), dim3(grid), dim3(256), 0, s, a);
-        else
+        const int epi = (a.sim_means || a.sim_vars) ? 1 : (a.state_means ? 2 : 0);
+        if (a.rs > 0) {
+#define MK_LAUNCH_REC(E, S) hipLaunchKernelGGL((smoother_record_kernel<N, K, G, E, S>), dim3(grid), dim3(256), 0, s, a)
+            if (a.sym) {
+                if (epi == 1) MK_LAUNCH_REC(1, true);
+                else if (epi == 2) MK_LAUNCH_REC(2, true);
+                else MK_LAUNCH_REC(0, true);
+            } else {
+                if (epi == 1) MK_LAUNCH_REC(1, false);
+                else if (epi == 2) MK_LAUNCH_REC(2, false);
+                else MK_LAUNCH_REC(0, false);
+            }
+#undef MK_LAUNCH_REC
+        } else
             hipLaunchKernelGGL((smoother_dense_kernel<n, G>), dim3(grid), dim3(256), 0, s, a);
     }
     return hipGetLastError();
@@ -1350,6 +1447,7 @@ MK_API int mkmod_launch_smoother(const SmootherArgs *a, void *stream)
 static const int kShapes[][2] = {MK_SHAPES(MK_CASE_LIST)};
 
 int record_stride(int n) { return record_stride_c(n); }
+int record_stride_sym(int n) { return record_stride_sym_c(n); }
 
 int num_shapes() { return (int)(sizeof(kShapes) / sizeof(kShapes[0])); }
 void get_shape(int i, int *N, int *K)

@@ -242,6 +242,11 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr int record_payload(int n) { return n + n * n; }
 constexpr int record_stride_c(int n) { return ((record_payload(n) + 2 + 15) / 16) * 16; }
+// packed-symmetric records (mk_outputs.flags & MK_OUT_PACKED_SYM): mean + upper triangle by rows
+constexpr int record_payload_sym(int n) { return n + n * (n + 1) / 2; }
+constexpr int record_stride_sym_c(int n) { return ((record_payload_sym(n) + 2 + 15) / 16) * 16; }
+// offset of row c of the packed upper triangle (elements (c, c) .. (c, n-1))
+constexpr int sym_row_offset(int n, int c) { return c * n - c * (c - 1) / 2; }
 
 // pointer pair addressing one moment set of one model: element r of the mean vector and element
 // (0, r) of the covariance's column runs; `advance` moves both to the next (or previous) time step
@@ -289,6 +294,24 @@ __device__ __forceinline__ void load_cols(const double *mat, double (&row)[n])
 {
 #pragma unroll
     for (int c = 0; c < n; ++c) row[c] = mat[c * n];
+}
+
+// packed-symmetric variants (base = first double of the record's packed upper triangle): lane r writes its
+// P[r][c] to position (c, r) of the triangle for c <= r -- for a fixed c the lanes r >= c write one contiguous
+// run -- and reads row r back as (c, r) for c <= r, (r, c) for c > r.
+template <int n>
+__device__ __forceinline__ void store_cols_sym(double *base, const double (&row)[n], int r)
+{
+#pragma unroll
+    for (int c = 0; c < n; ++c)
+        if (r >= c) base[sym_row_offset(n, c) + (r - c)] = row[c];
+}
+template <int n>
+__device__ __forceinline__ void load_cols_sym(const double *base, double (&row)[n], int r)
+{
+    const int offr = r * n - r * (r - 1) / 2 - r; // sym_row_offset(n, r) - r: element (r, c) sits at offr + c
+#pragma unroll
+    for (int c = 0; c < n; ++c) row[c] = base[r >= c ? sym_row_offset(n, c) + (r - c) : offr + c];
 }
 
 // ---------------------------------------------------------------- fused projection epilogue

@@ -235,10 +235,13 @@ smoother_wave_kernel(SmootherArgs a)
 // =====================================================================================
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int N, int K, bool PROJ>
+// EPI / SYM as in smoother_record_kernel: 0 records, 1 + projection, 2 + state means and variances; SYM: the
+// filtered (and smoothed) records are packed-symmetric
+template <int N, int K, int EPI, bool SYM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_mfma_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, G = 64;
+    constexpr bool PROJ = (EPI == 1), VAR = (EPI == 2);
     static_assert(n > 16 && n <= G, "one model per wavefront, 16 < n <= 64");
     constexpr int NB = (n + 15) / 16; // 16-wide tile rows / columns
     constexpr int KS = (n + 3) / 4;   // k-steps
@@ -263,7 +266,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const long blkT = inst * a.bs + (T - 1) * a.ts;
     MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
     MomentPtr oS = moment_ptr<n>(a.S, a.Ps, blkT, a.ts, a.rs, r);
-    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
+    constexpr int NV = SYM ? record_payload_sym(n) : record_payload(n), RS = SYM ? record_stride_sym_c(n) : record_stride_c(n);
+    constexpr int PADN = RS - NV;
     double *padS = (a.rs > 0 && a.S) ? a.S + blkT * RS + NV + (lane < PADN ? lane : PADN - 1) : nullptr;
 
     const long rec_id = inst % a.R;
@@ -279,9 +283,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         pM = a.sim_means ? a.sim_means + pidx : nullptr;
         pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
     }
+    double *sM = nullptr, *sV = nullptr;
+    if constexpr (VAR) {
+        sM = a.state_means + blkT * n + r;
+        sV = a.state_vars + blkT * n + r;
+    }
+    auto load_pf_rows = [&](double(&row)[n]) __attribute__((always_inline)) {
+        if constexpr (SYM) load_cols_sym<n>(iF.mat - r, row, r);
+        else load_cols<n>(iF.mat, row);
+    };
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
         if (oS.vec) *oS.vec = xv;
-        if (oS.mat) store_cols<n>(oS.mat, row);
+        if (oS.mat) {
+            if constexpr (SYM) store_cols_sym<n>(oS.mat - r, row, r);
+            else store_cols<n>(oS.mat, row);
+        }
         oS.advance(-1);
         if (padS) {
             *padS = 0.0;
@@ -297,6 +313,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (pM) pM -= a.ts * N;
             if (pV) pV -= a.ts * N;
         }
+        if constexpr (VAR) {
+            double diag = 0.0;
+            sfor<0, n>(MK_LAMBDA(c) { diag = (decltype(c)::value == lane) ? row[decltype(c)::value] : diag; });
+            if (lane < n && live) {
+                *sM = xv;
+                *sV = diag;
+            }
+            sM -= a.ts * n;
+            sV -= a.ts * n;
+        }
     };
 
     // tile addressing (loop invariant): lane l of a C-layout tile sits at row (l>>4) + 4 reg, column l&15
@@ -307,7 +333,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // last step: smoothed = filtered (:450-451)
     double xs = *iF.vec, Psn[n];
-    load_cols<n>(iF.mat, Psn);
+    load_pf_rows(Psn);
     store(xs, Psn);
     double pivmin = 1.0;
 
@@ -317,7 +343,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double A[n], z[n];
         {
             double Pfc[n];
-            load_cols<n>(iF.mat, Pfc);
+            load_pf_rows(Pfc);
             wave_lds_sync(); // previous iteration's reads of Dm / Lm are complete
             double dprev = 0.0;
             int rv = r; // opaque copies: keeps the n selects inside the loop (hoisted, they are 2n VGPRs)
@@ -441,7 +467,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     sfor<0, 4>(MK_LAMBDA(vv) {
                         constexpr int v = decltype(vv)::value;
                         const int row = 16 * Ib + l4 + 4 * v < n ? 16 * Ib + l4 + 4 * v : n - 1;
-                        Pt[ti][v] = pf[row * n + col];
+                        if constexpr (SYM) { // element (min, max) of the packed upper triangle
+                            const int lo = row < col ? row : col, hi = row < col ? col : row;
+                            Pt[ti][v] = pf[lo * n - lo * (lo - 1) / 2 + (hi - lo)];
+                        } else {
+                            Pt[ti][v] = pf[row * n + col];
+                        }
                     });
                 });
             });
@@ -540,12 +571,22 @@ static hipError_t launch_wide_nk(const SmootherArgs &a, hipStream_t s)
     if constexpr (N + K > 16) {
         const unsigned grid = (unsigned)a.B;
         const bool proj = a.sim_means || a.sim_vars;
-        if (use_v1()) {
+        const int epi = proj ? 1 : (a.state_means ? 2 : 0);
+        if (use_v1() && !a.sym && epi != 2) { // the round-1 kernel knows neither packed-symmetric records nor VAR_ONLY
             if (proj) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
         } else {
-            if (proj) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((smoother_mfma_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
+#define MK_LAUNCH_WIDE(E, S) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S>), dim3(grid), dim3(64), 0, s, a)
+            if (a.sym) {
+                if (epi == 1) MK_LAUNCH_WIDE(1, true);
+                else if (epi == 2) MK_LAUNCH_WIDE(2, true);
+                else MK_LAUNCH_WIDE(0, true);
+            } else {
+                if (epi == 1) MK_LAUNCH_WIDE(1, false);
+                else if (epi == 2) MK_LAUNCH_WIDE(2, false);
+                else MK_LAUNCH_WIDE(0, false);
+            }
+#undef MK_LAUNCH_WIDE
         }
         return hipGetLastError();
     } else {

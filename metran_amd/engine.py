@@ -328,8 +328,23 @@ class BatchedKalman:
         return mle, galpha
 
     def record_stride(self):
-        """Doubles per packed (model, step) record for this state dimension (C ABI ``mk_record_stride``)."""
+        """Doubles per packed (model, step) record for this state dimension (C ABI ``mk_record_stride``, or
+        ``mk_record_stride_sym`` for an engine created with ``packed_sym=True``)."""
+        if self.packed_sym:
+            return int(self._L.mk_record_stride_sym(self.n))
         return int(self._L.mk_record_stride(self.n))
+
+    def unpack_sym(self, packed):
+        """Packed upper triangle ``[..., n(n+1)/2]`` (what the covariance entries of a ``packed_sym`` engine's results
+        are) -> full symmetric ``[..., n, n]``.  Lazy by design: the packed records are what moves through HBM."""
+        torch = _torch()
+        n = self.n
+        idx = getattr(self, "_sym_index", None)
+        if idx is None or idx.shape[0] != n:
+            r = torch.arange(n, device=self.device)
+            lo, hi = torch.minimum(r[:, None], r[None, :]), torch.maximum(r[:, None], r[None, :])
+            idx = self._sym_index = lo * n - (lo * (lo - 1)) // 2 + (hi - lo)
+        return packed[..., idx]
 
     def _alloc_records(self, B):
         """One record array ``[B,T,RS]`` (logical; memory follows the engine layout) and its views
@@ -337,6 +352,9 @@ class BatchedKalman:
         T, n = self.T, self.n
         RS = self.record_stride()
         rec = self._empty_bt(B, T, RS)
+        if self.packed_sym:  # covariance entry = the packed upper triangle [B,T,n(n+1)/2]; see unpack_sym
+            nv = n + n * (n + 1) // 2
+            return rec, rec[..., :n], rec[..., n:nv], rec[..., nv], rec[..., nv + 1]
         nv = n + n * n
         return rec, rec[..., :n], rec[..., n:nv].unflatten(-1, (n, n)), rec[..., nv], rec[..., nv + 1]
 
@@ -357,6 +375,9 @@ class BatchedKalman:
             res["sigmacount"] = torch.empty(B, dtype=torch.int64, device=self.device)
         smooth_pair = ("S" in want) + ("Ps" in want)
         records = all(k in want for k in ("F", "Pf", "Xp", "Pp")) and smooth_pair in (0, 2)
+        if self.packed_sym and not records:
+            raise MetranHipError("a packed_sym engine writes record outputs only: ask for F, Pf, Xp, Pp (and S, Ps), "
+                                 "or use simulate_smoothed / smooth_state_variances")
         if records:
             res["_rs"] = self.record_stride()
             res["_rec_pred"], res["Xp"], res["Pp"], _, _ = self._alloc_records(B)
@@ -378,7 +399,8 @@ class BatchedKalman:
         return Outputs(self._p(g("mle")), self._p(g("sigmas")), self._p(g("detfs")), self._p(g("sigmacount")),
                        self._p(g("F")), self._p(g("Pf")), self._p(g("Xp")), self._p(g("Pp")), self._p(g("S")),
                        self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0,
-                       self._p(g("sim_means")), self._p(g("sim_vars")), int(g("_rs", 0)))
+                       self._p(g("sim_means")), self._p(g("sim_vars")), int(g("_rs", 0)),
+                       (1 if (self.packed_sym and g("_rs", 0)) else 0) | (2 if g("_var_only") else 0))
 
     def filter(self, phi, q, warmup=1, x0=None, P0=None, outputs=("F", "Pf", "Xp", "Pp"), buffers=None):
         """``run_filter`` for B instances (kalmanfilter.py:696-778).  Returns a dict of device tensors."""
@@ -437,6 +459,26 @@ class BatchedKalman:
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         res = buffers if buffers is not None else self.alloc_projection(B)
         o = self._outputs_struct(res)
+        self._bind_stream()
+        check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
+        return res
+
+    def smooth_state_variances(self, phi, q, warmup=1, x0=None, P0=None, buffers=None):
+        """``Metran.get_state_means`` / ``get_state_variances`` (metran.py:655-711, method="smoother") for B instances
+        without materialising the smoothed covariances (``MK_OUT_VAR_ONLY``): the filter writes the filtered records,
+        the smoother reads them and writes the smoothed state means ``S [B,T,n]`` and variances ``var [B,T,n]``."""
+        torch = _torch()
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        res = buffers
+        if res is None:
+            res = {"mle": torch.empty(B, dtype=torch.float64, device=self.device),
+                   "status": torch.zeros(B, dtype=torch.int32, device=self.device),
+                   "sigmacount": torch.empty(B, dtype=torch.int64, device=self.device), "_rs": self.record_stride(),
+                   "_var_only": True}
+            res["_rec_filt"], res["F"], res["Pf"], res["sigmas"], res["detfs"] = self._alloc_records(B)
+            res["S"] = self._empty_bt(B, self.T, self.n)
+            res["var"] = self._empty_bt(B, self.T, self.n)
+        o = self._outputs_struct(dict(res, Ps=res["var"]))
         self._bind_stream()
         check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
         return res
