@@ -28,6 +28,10 @@ template <int n, int G, bool SYM>
 struct RecordIO;
 // packed records of the 16-lane kernels leave through wave-private LDS images as whole 16-byte chunks
 // (8 global_store_dwordx4 per step instead of 24 column-run dwordx2 stores: 1.52 -> 1.47 ms at B=4096)
+// resident wavefronts per SIMD asked of the compiler for the wide (one model per wavefront) filter
+#ifndef MK_WIDE_FILTER_WAVES
+#define MK_WIDE_FILTER_WAVES 2
+#endif
 #ifndef MK_FILTER_LDS_STORES
 #define MK_FILTER_LDS_STORES 1
 #endif
@@ -35,7 +39,7 @@ struct RecordIO;
 // (two resident wavefronts per SIMD are asked for only while the wide variant's two n-double row arrays fit
 // 256 VGPRs: compile-checked at n = 64, the constraint spilled 1.1 KB per lane)
 template <int N, int K, int G, int OUT, bool BOOK, bool SYM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 && N + K <= 40 ? 2 : 1))) filter_kernel(FilterArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 64 && N + K <= 40 ? MK_WIDE_FILTER_WAVES : 1))) filter_kernel(FilterArgs a)
 {
     static_assert(!SYM || OUT == 1 || OUT == 3, "packed-symmetric layout applies to record outputs");
     constexpr int n = N + K;
