@@ -327,18 +327,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // tile addressing (loop invariant): lane l of a C-layout tile sits at row (l>>4) + 4 reg, column l&15
     const int l15 = lane & 15, l4 = lane >> 4;
+    // Pf tiles are fetched as  (wavefront-uniform record pointer) + (per-lane element offset) + (compile-time
+    // offset): one per-lane offset per tile column serves every tile row and register, instead of a 64-bit
+    // pointer per element (24 of them were kept across the loop and spilled).  Columns beyond n are clamped to
+    // n-1 and rows beyond n wrap to row n-1 through the clamp of the final index (never stored: masked write-back).
+    int pt_col[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pt_col[b] = 16 * b + l15 < n ? 16 * b + l15 : n - 1;
+    const double *recU = a.F + (inst * a.bs + (T - 1) * a.ts) * a.rs; // uniform (one model per wavefront); rs > 0 only
+    const long recUstep = a.ts * a.rs;
     int jt_row[NB]; // LDS row (of J) this lane reads the J^T tile column-block Ib from: i = 16 Ib + l15, clamped
 #pragma unroll
     for (int b = 0; b < NB; ++b) jt_row[b] = (16 * b + l15 < n ? 16 * b + l15 : n - 1) * LD;
 
     // last step: smoothed = filtered (:450-451)
-    double xs = *iF.vec, Psn[n];
-    load_pf_rows(Psn);
-    store(xs, Psn);
+    // Ps[t+1] lives in the LDS matrix Dm between iterations (row r in lane r's row), NOT in registers: with the
+    // rows of Pf[t], W, A and Ps[t+1] all live at the top of an iteration the wavefront needs 4n doubles per lane
+    // and spills (measured: 74 scratch operations per step, whose traffic reaches the Infinity Cache)
+    double xs = *iF.vec;
+    {
+        double Psn[n];
+        load_pf_rows(Psn);
+        store(xs, Psn);
+        store_row<n>(Dr, Psn);
+    }
     double pivmin = 1.0;
 
     for (long t = T - 2; t >= 0; --t) {
         iF.advance_nn(-1);
+        recU -= recUstep;
         const double xfc = *iF.vec;
         double A[n], z[n];
         {
@@ -349,14 +366,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             int rv = r; // opaque copies: keeps the n selects inside the loop (hoisted, they are 2n VGPRs)
             double qv = q_r;
             asm volatile("" : "+v"(rv), "+v"(qv));
-            sfor<0, n>(MK_LAMBDA(cc) {
+            sfor<0, n>(MK_LAMBDA(cc) { // D = Ps[t+1] - Pp[t+1], in place in this lane's row of Dm, pair by pair
                 constexpr int c = decltype(cc)::value;
                 z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
                 A[c] = fma(phi_r, z[c], c == rv ? qv : 0.0);   // Pp[t+1] row
-                const double d = Psn[c] - A[c];
-                if constexpr (c % 2 == 1) *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{dprev, d};
-                else if constexpr (c == n - 1) Dr[c] = d;
-                else dprev = d;
+                if constexpr (c % 2 == 1) {
+                    const v2d ps = *reinterpret_cast<const v2d *>(Dr + c - 1);
+                    *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{ps.x - dprev, ps.y - A[c]};
+                } else if constexpr (c == n - 1) {
+                    Dr[c] = Dr[c] - A[c];
+                } else {
+                    dprev = A[c];
+                }
                 if constexpr (c % 8 == 7) __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -432,19 +453,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // smoothed mean (:461-464): xs[t] = F[t] + J delta, delta from LDS (uniform reads)
         {
             double a0 = xfc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            constexpr int PB = 6; // pairs per batch (left alone, hipcc reads all n/2 pairs first and spills half of them)
+            sfor<0, (n / 2 + PB - 1) / PB>(MK_LAMBDA(bb) {
+                constexpr int p0 = PB * decltype(bb)::value, p1 = p0 + PB < n / 2 ? p0 + PB : n / 2;
+                v2d v[PB];
 #pragma unroll
-            for (int c = 0; c + 1 < n; c += 2) {
-                const v2d v = *reinterpret_cast<const v2d *>(dl + c);
-                if (c % 4 == 0) {
-                    a0 = fma(v.x, z[c], a0);
-                    a1 = fma(v.y, z[c + 1], a1);
-                } else {
-                    a2 = fma(v.x, z[c], a2);
-                    a3 = fma(v.y, z[c + 1], a3);
+                for (int p = p0; p < p1; ++p) v[p - p0] = *reinterpret_cast<const v2d *>(dl + 2 * p);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = p0; p < p1; ++p) {
+                    if (p % 2 == 0) {
+                        a0 = fma(v[p - p0].x, z[2 * p], a0);
+                        a1 = fma(v[p - p0].y, z[2 * p + 1], a1);
+                    } else {
+                        a2 = fma(v[p - p0].x, z[2 * p], a2);
+                        a3 = fma(v[p - p0].y, z[2 * p + 1], a3);
+                    }
                 }
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            });
             if constexpr (n % 2 == 1) a0 = fma(dl[n - 1], z[n - 1], a0);
             xs = (a0 + a1) + (a2 + a3);
+            asm volatile("" : "+v"(xs)); // finished HERE: deferred behind the products, its delta operands were spilled
         }
         wave_lds_sync(); // Dm (D) and Lm (J) visible to the whole wavefront
         __builtin_amdgcn_sched_barrier(0);
@@ -457,21 +487,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr int NT = NB * (NB + 1) / 2;
         v4d Pt[NT];
         {
-            const double *pf = iF.mat - r; // element (0, 0) of this step's covariance block
+            const double *pf = (a.rs > 0 ? recU : iF.mat - r - n) + n; // element (0, 0) of this step's covariance block
             sfor<0, NB>(MK_LAMBDA(ib) {
                 constexpr int Ib = decltype(ib)::value;
                 sfor<Ib, NB>(MK_LAMBDA(jb) {
                     constexpr int Jb = decltype(jb)::value;
                     constexpr int ti = Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib);
-                    const int col = 16 * Jb + l15 < n ? 16 * Jb + l15 : n - 1;
                     sfor<0, 4>(MK_LAMBDA(vv) {
                         constexpr int v = decltype(vv)::value;
-                        const int row = 16 * Ib + l4 + 4 * v < n ? 16 * Ib + l4 + 4 * v : n - 1;
-                        if constexpr (SYM) { // element (min, max) of the packed upper triangle
+                        if constexpr (16 * Ib + 4 * v >= n) {
+                            Pt[ti][v] = 0.0; // a register whose rows are all padding: never stored
+                        } else if constexpr (SYM) { // element (min, max) of the packed upper triangle
+                            const int row = 16 * Ib + l4 + 4 * v < n ? 16 * Ib + l4 + 4 * v : n - 1, col = pt_col[Jb];
                             const int lo = row < col ? row : col, hi = row < col ? col : row;
                             Pt[ti][v] = pf[lo * n - lo * (lo - 1) / 2 + (hi - lo)];
+                        } else if constexpr (16 * Ib + 4 * v + 3 < n) { // all four row groups inside: affine address
+                            Pt[ti][v] = pf[(l4 * n + pt_col[Jb]) + (16 * Ib + 4 * v) * n];
                         } else {
-                            Pt[ti][v] = pf[row * n + col];
+                            const int row = 16 * Ib + l4 + 4 * v < n ? 16 * Ib + l4 + 4 * v : n - 1;
+                            Pt[ti][v] = pf[row * n + pt_col[Jb]];
                         }
                     });
                 });
@@ -491,11 +525,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
             });
         });
-        // product 1: V^T = D J^T.  A operand: D[m][k'] (= D[k'][m]), m = 4 ms + l4 (K), k' = 16 Kb' + l15 (M).
-        // Only the rows of V^T that product 2 consumes as k-steps are kept: VK[s][Jb] = rows 4 s + l4.
-        double VK[KS][NB];
+        // products, block row by block row of V^T (so that only ONE block row of V^T is ever live):
+        //   product 1   V^T[Kb', :] = D[Kb', :] J^T        A operand: D[m][k'] (= D[k'][m]), m = 4 ms + l4 (K), k' = 16 Kb' + l15 (M)
+        //   product 2   Ps[Ib][Jb] += J[Ib][k in Kb'] V^T[k][Jb], tiles Ib <= Jb, accumulating in the Pf tiles
+        // Product 2 may not overwrite Dm before every block row of D has been read: the accumulators stay in
+        // registers until the end.  A operand of product 2: J[i][k] = JT[Ib][ks]; B operand: the V^T rows just made.
+        __builtin_amdgcn_sched_barrier(0);
         sfor<0, NB>(MK_LAMBDA(kb) {
             constexpr int Kb = decltype(kb)::value;
+            __builtin_amdgcn_sched_barrier(0); // keeps the next block row's operand loads from being hoisted (registers)
             const int kcol = 16 * Kb + l15 < n ? 16 * Kb + l15 : n - 1; // M padding: duplicates, harmless
             double Da[KS];
             sfor<0, KS>(MK_LAMBDA(ms) {
@@ -508,48 +546,54 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     Da[decltype(ms)::value] = m < n ? v : 0.0;
                 }
             });
+            v4d VT[NB];
             sfor<0, NB>(MK_LAMBDA(jb) {
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
                 sfor<0, KS>(MK_LAMBDA(ms) {
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Da[decltype(ms)::value],
                                                                JT[decltype(jb)::value][decltype(ms)::value], acc, 0, 0, 0);
                 });
-                sfor<0, 4>(MK_LAMBDA(vv) {
-                    constexpr int s = 4 * Kb + decltype(vv)::value;
-                    if constexpr (s < KS) VK[s][decltype(jb)::value] = acc[decltype(vv)::value];
-                });
+                VT[decltype(jb)::value] = acc;
             });
-        });
-        wave_lds_sync(); // all reads of D are done: Dm is free for Ps[t]
-        // product 2: Ps = Pf + J V^T, tiles Ib <= Jb, mirrored.  A operand J[i][k] = JT[Ib][ks]; B operand VK[ks][Jb]
-        {
             sfor<0, NB>(MK_LAMBDA(ib) {
                 constexpr int Ib = decltype(ib)::value;
                 sfor<Ib, NB>(MK_LAMBDA(jb) {
                     constexpr int Jb = decltype(jb)::value;
-                    v4d acc = Pt[Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib)];
-                    sfor<0, KS>(MK_LAMBDA(ks) {
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(JT[Ib][decltype(ks)::value], VK[decltype(ks)::value][Jb],
-                                                                   acc, 0, 0, 0);
+                    constexpr int ti = Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib);
+                    sfor<0, 4>(MK_LAMBDA(vv) {
+                        constexpr int s = 4 * Kb + decltype(vv)::value; // k-step = row group of V^T
+                        if constexpr (s < KS)
+                            Pt[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(JT[Ib][s], VT[Jb][decltype(vv)::value], Pt[ti], 0, 0, 0);
                     });
-                    const int col = 16 * Jb + l15;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int row = 16 * Ib + l4 + 4 * v;
-                        if (16 * Ib + 4 * v + 3 < n && 16 * Jb + 15 < n) { // interior: no mask (compile-time)
-                            Dm[row * LD + col] = acc[v];
-                            if constexpr (Ib != Jb) Dm[col * LD + row] = acc[v];
-                        } else if (row < n && col < n) {
-                            Dm[row * LD + col] = acc[v];
-                            if constexpr (Ib != Jb) Dm[col * LD + row] = acc[v];
-                        }
-                    }
                 });
             });
-        }
+        });
+        wave_lds_sync(); // all reads of D are done: Dm is free for Ps[t]
+        sfor<0, NB>(MK_LAMBDA(ib) {
+            constexpr int Ib = decltype(ib)::value;
+            sfor<Ib, NB>(MK_LAMBDA(jb) {
+                constexpr int Jb = decltype(jb)::value;
+                const v4d acc = Pt[Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib)];
+                const int col = 16 * Jb + l15;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * Ib + l4 + 4 * v;
+                    if (16 * Ib + 4 * v + 3 < n && 16 * Jb + 15 < n) { // interior: no mask (compile-time)
+                        Dm[row * LD + col] = acc[v];
+                        if constexpr (Ib != Jb) Dm[col * LD + row] = acc[v];
+                    } else if (row < n && col < n) {
+                        Dm[row * LD + col] = acc[v];
+                        if constexpr (Ib != Jb) Dm[col * LD + row] = acc[v];
+                    }
+                }
+            });
+        });
         wave_lds_sync();
-        load_row<n>(Dr, Psn);
-        store(xs, Psn);
+        {
+            double Psn[n]; // transient: the row goes to the store path / the epilogues; Dm keeps it for the next step
+            load_row<n>(Dr, Psn);
+            store(xs, Psn);
+        }
     }
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }

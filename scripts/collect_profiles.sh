@@ -1,17 +1,39 @@
 #!/bin/bash
-# Box-side: rocprofv3 kernel-trace stats + HBM PMC passes of the default bench command; reduced
-# summaries land in gpurun_out/ (copy them into profiles/<round>/ afterwards).
+# Box-side: the round's profiles.  For every bench configuration: rocprofv3 kernel-trace stats, HBM traffic from two
+# separate PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains), the bench line of the same
+# command; SQ counters for c2 and c4.  Everything lands in gpurun_out/prof_r02/ -- copy into profiles/r02/.
+#   bash scripts/collect_profiles.sh [configs...]        (default: c2 c2sym c3 c3sym c4 c5)
 set -u
-cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof; mkdir -p $OUT
-CMD="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $CMD > $OUT/bench_kt.log 2>&1
-cp /tmp/kt/*/*kernel_stats.csv $OUT/kernel_stats_full.csv
-head -1 $OUT/kernel_stats_full.csv > $OUT/kernel_stats.csv; grep "mk::" $OUT/kernel_stats_full.csv >> $OUT/kernel_stats.csv; rm $OUT/kernel_stats_full.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- $CMD > /dev/null 2>&1
-python scripts/pmc_extract.py /tmp/pf $OUT/pmc_fetch.json > /dev/null
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- $CMD > /dev/null 2>&1
-python scripts/pmc_extract.py /tmp/pw $OUT/pmc_write.json > /dev/null
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d /tmp/ps -- $CMD > /dev/null 2>&1
-python scripts/pmc_extract.py /tmp/ps $OUT/pmc_sq.json > /dev/null
-cat $OUT/kernel_stats.csv; tail -1 $OUT/bench_kt.log | cut -c1-300
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02; mkdir -p $OUT
+CFGS="${@:-c2 c2sym c3 c3sym c4 c5}"
+for tag in $CFGS; do
+  cfg=${tag%sym}; symflag=""; sym=0
+  if [ "$tag" != "$cfg" ]; then symflag="--packed-sym"; sym=1; fi
+  steps=12; [ $cfg = c4 ] && steps=2; [ $cfg = c5 ] && steps=2
+  CMD="python $GRAFT_REPO_ROOT/bench.py --config $cfg $symflag --steps $steps --warmup 1 --no-cpu-baseline"
+  cd /tmp
+  rm -rf /tmp/kt /tmp/pf /tmp/pw
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $CMD > $OUT/${tag}_bench_under_rocprof.json 2> $OUT/${tag}_kt.err
+  f=$(ls /tmp/kt/*/*kernel_stats.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then head -1 $f > $OUT/${tag}_kernel_stats.csv; grep "mk::" $f >> $OUT/${tag}_kernel_stats.csv; fi
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -- $CMD > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -- $CMD > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT
+  python scripts/pmc_extract.py /tmp/pf /tmp/${tag}_fetch.json > /dev/null
+  python scripts/pmc_extract.py /tmp/pw /tmp/${tag}_write.json > /dev/null
+  python scripts/merge_pmc.py $cfg $sym /tmp/${tag}_fetch.json /tmp/${tag}_write.json $OUT/pmc_hbm_${tag}.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (two separate passes) -- $CMD"
+  if [ $cfg = c2 ] || [ $cfg = c4 ]; then
+    cd /tmp; rm -rf /tmp/ps1 /tmp/ps2
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d /tmp/ps1 -- $CMD > /dev/null 2>&1
+    rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d /tmp/ps2 -- $CMD > /dev/null 2>&1
+    cd $GRAFT_REPO_ROOT
+    python scripts/pmc_extract.py /tmp/ps1 $OUT/pmc_sq_${tag}_a.json > /dev/null
+    python scripts/pmc_extract.py /tmp/ps2 $OUT/pmc_sq_${tag}_b.json > /dev/null
+  fi
+  # the bench line of the plain command (with the CPU baselines for the headline configuration), reading the traffic just taken
+  mkdir -p profiles/r02; cp $OUT/pmc_hbm_${tag}.json profiles/r02/
+  extra="--no-cpu-baseline"; [ $tag = c2 ] && extra=""
+  python bench.py --config $cfg $symflag $extra > $OUT/bench_${tag}.json 2> $OUT/bench_${tag}.err
+  echo "== $tag"; cat $OUT/${tag}_kernel_stats.csv | cut -c1-150; tail -c 400 $OUT/bench_${tag}.json | head -c 400; echo
+done
