@@ -82,6 +82,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 #pragma unroll
     for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
     const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
+    // WIDE and too many loadings to replicate in registers: a wave-private LDS copy read at wavefront-uniform
+    // addresses (two 16-byte reads per update for K = 4) instead of 2 K v_readlane per update
+    constexpr bool GTAB = WIDE && !HOIST;
+    __shared__ __attribute__((aligned(16))) double lds_gam[GTAB ? (256 / G) * N * K : 1];
+    double *gtab = lds_gam + (GTAB ? (threadIdx.x / G) * N * K : 0);
+    if constexpr (GTAB) {
+        if (lane < N) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) gtab[lane * K + k] = gam[k];
+        }
+        wave_lds_sync();
+    }
     double Gh[HOIST ? N : 1][K]; // Gh[j][k] = loadings[j,k] in every lane
     if constexpr (HOIST) {
         sfor<0, N>(MK_LAMBDA(j) {
@@ -251,6 +263,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
                 constexpr int kk = decltype(k)::value;
                 double g;
                 if constexpr (HOIST) g = Gh[j][kk];
+                else if constexpr (GTAB) g = gtab[j * K + kk];
                 else g = Gp::template bcast<j>(gam[kk]);
                 dr = fma(P[N + kk], g, dr);
             });
