@@ -364,7 +364,10 @@ def main():
             f_avg = float(np.mean(filt_ms))
             s_avg = float(np.mean(smooth_ms)) if mode != "solver" else 0.0
             fname = "filter_kernel"
-            sname = {"full": "smoother_record_kernel", "project": "smoother_wave_kernel" if N + K > 16 else "smoother_record_kernel"}.get(mode)
+            wide = N + K > 16   # one model per wavefront: mk_wide.hip (MK_WIDE_SMOOTHER=v1 selects the round-1 kernel)
+            sname = None if mode == "solver" else (
+                ("smoother_wave_kernel" if os.environ.get("MK_WIDE_SMOOTHER", "") == "v1" else "smoother_mfma_kernel") if wide
+                else "smoother_record_kernel")
             kernels = {fname: {"ms": f_avg, "algorithmic_GB": ab["filter"] * B / 1e9, "GBps": ab["filter"] * B / 1e9 / (f_avg / 1e3)}}
             if sname:
                 kernels[sname] = {"ms": s_avg, "algorithmic_GB": ab["smoother"] * B / 1e9, "GBps": ab["smoother"] * B / 1e9 / (s_avg / 1e3)}
