@@ -148,6 +148,10 @@ MK_API int mk_destroy(mk_context *ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
 MK_API int mk_set_stream(mk_context *ctx, void *hip_stream);
 MK_API int mk_sync(mk_context *ctx);
+/* Tell the context that the CONTENTS of an observation buffer it has seen changed in place (same pointer): per-record
+ * data derived from it (the observed-step list of the sparse objective, see mk_loglik) is rebuilt on the next call.
+ * Not needed when a different buffer is passed. */
+MK_API int mk_observations_changed(mk_context *ctx);
 /* 1 if a kernel for (N,K) is compiled into the library. */
 MK_API int mk_shape_supported(int64_t N, int64_t K);
 /* Register a run-time shape module: a shared object built from metran_amd/csrc/mk_kernels.hip with
@@ -186,7 +190,8 @@ MK_API int mk_filter(mk_context *ctx, const mk_problem *prob, const mk_outputs *
 MK_API int mk_loglik(mk_context *ctx, const mk_problem *prob, double *d_mle);
 /* (When every instance shares ONE record -- n_records == 1, the solver's finite-difference points -- and
  * N+K <= 16, mk_loglik walks only the record's observed steps and applies the runs of empty steps in closed
- * form; real Metran records are sparse: examples/data observes 343 of 6255 daily steps.) */
+ * form; real Metran records are sparse: examples/data observes 343 of 6255 daily steps.  The list of observed steps is
+ * built once per record (pointer, shape, layout) and reused by the following calls: mk_observations_changed.) */
 
 /* Objective AND its gradient in two launches (the reference has no gradient: scipy differences P+1
  * objective evaluations, metran/solver.py:248-255).  Forward: mk_filter writing only the filtered

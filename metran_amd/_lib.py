@@ -79,6 +79,7 @@ API = {
     "mk_destroy": (c_int, [c_void_p]),
     "mk_set_stream": (c_int, [c_void_p, c_void_p]),
     "mk_sync": (c_int, [c_void_p]),
+    "mk_observations_changed": (c_int, [c_void_p]),
     "mk_shape_supported": (c_int, [c_int64, c_int64]),
     "mk_register_shape_module": (c_int, [c_char_p]),
     "mk_record_stride": (c_int64, [c_int64]),

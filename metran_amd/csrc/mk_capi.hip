@@ -21,6 +21,10 @@ struct mk_context {
     bool have_filter_time, have_smooth_time;
     int *tlist;      // workspace of the sparse objective (observed-step list), grown on demand
     long tlist_cap;
+    // the list is rebuilt only when the record it was built from changes: same pointer, shape and layout, and no
+    // mk_observations_changed() since (the solver evaluates the objective ~80 times on one uploaded record)
+    const double *tlist_obs;
+    long tlist_T, tlist_N, tlist_ostep;
 };
 
 static thread_local char g_err[512] = "";
@@ -185,6 +189,8 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->have_filter_time = ctx->have_smooth_time = false;
     ctx->tlist = nullptr;
     ctx->tlist_cap = 0;
+    ctx->tlist_obs = nullptr;
+    ctx->tlist_T = ctx->tlist_N = ctx->tlist_ostep = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
             delete ctx;
@@ -209,6 +215,13 @@ MK_API int mk_set_stream(mk_context *ctx, void *s)
 {
     MK_CTX(ctx);
     ctx->stream = (hipStream_t)s;
+    return MK_OK;
+}
+
+MK_API int mk_observations_changed(mk_context *ctx)
+{
+    MK_CTX(ctx);
+    ctx->tlist_obs = nullptr;
     return MK_OK;
 }
 
@@ -479,6 +492,7 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
             ctx->tlist_cap = 0;
             MK_HIP(hipMalloc((void **)&ctx->tlist, sizeof(int) * (size_t)(p->T + 1)));
             ctx->tlist_cap = p->T + 1;
+            ctx->tlist_obs = nullptr;
         }
         mk::SparseArgs a;
         a.B = p->n_instances;
@@ -493,6 +507,11 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
         a.x0 = p->d_x0;
         a.P0 = p->d_P0;
         a.tlist = ctx->tlist;
+        a.rebuild = !(ctx->tlist_obs == p->d_obs && ctx->tlist_T == p->T && ctx->tlist_N == p->N && ctx->tlist_ostep == a.ostep);
+        ctx->tlist_obs = p->d_obs;
+        ctx->tlist_T = p->T;
+        ctx->tlist_N = p->N;
+        ctx->tlist_ostep = a.ostep;
         a.mle = d_mle;
         a.status = nullptr;
         if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[0], ctx->stream));

@@ -48,6 +48,7 @@ struct SmootherArgs {
     const double *F, *Pf;
     double *S, *Ps;
     unsigned *status;
+    long tune;           // wide smoother: start-up phase shift between the wavefronts of a SIMD (launcher-set)
 };
 
 struct AdjointArgs {
@@ -66,6 +67,7 @@ struct SparseArgs { // objective of ONE record (all instances share it), observe
     const double *obs;               // the record: step t at obs + t*ostep
     const double *phi, *q, *loadings, *obsvar, *x0, *P0;
     int *tlist;                      // workspace [T+1]: count, then the observed steps (built by the launch)
+    int rebuild;                     // 0: tlist still describes this record (mk_capi caches it per uploaded record)
     double *mle;
     unsigned *status;
 };

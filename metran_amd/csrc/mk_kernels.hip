@@ -32,6 +32,10 @@ struct RecordIO;
 #ifndef MK_WIDE_FILTER_WAVES
 #define MK_WIDE_FILTER_WAVES 2
 #endif
+// wide filter: scalar updates as a run-time loop over the observed series (1) or fully unrolled (0)
+#ifndef MK_WIDE_FILTER_LOOP
+#define MK_WIDE_FILTER_LOOP 1
+#endif
 #ifndef MK_FILTER_LDS_STORES
 #define MK_FILTER_LDS_STORES 1
 #endif
@@ -65,9 +69,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     constexpr bool WIDE = (G == 64);
     double pp[WIDE ? 1 : n], qd[WIDE ? 1 : n];
     constexpr int NP = n + (n & 1); // even: rows of 16-byte pieces
-    __shared__ __attribute__((aligned(16))) double lds_phi[WIDE ? (256 / G) * 2 * NP : 1];
-    double *phim = lds_phi + (WIDE ? (threadIdx.x / G) * 2 * NP : 0); // diag(Phi)
+    __shared__ __attribute__((aligned(16))) double lds_phi[WIDE ? (256 / G) * 3 * NP : 1];
+    double *phim = lds_phi + (WIDE ? (threadIdx.x / G) * 3 * NP : 0); // diag(Phi)
     double *dvec = phim + (WIDE ? NP : 0);                             // d = P Z_j^T of the current update
+    double *dvec2 = dvec;                                              // (loop filter: two buffers, alternating)
     if constexpr (WIDE) {
         phim[r] = phi_r;
         wave_lds_sync();
@@ -108,6 +113,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     double P[n];
 #pragma unroll
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
+
+    // wide loop filter: the K common-factor states (and their phi) replicated in every lane, updated with the gain
+    // elements broadcast at the END of an update (next to the rank-one update) -- the innovation of the next update
+    // then starts from registers instead of K dependent readlane pairs at the head of its chain
+    constexpr bool XREP = WIDE && MK_WIDE_FILTER_LOOP;
+    double xk[XREP ? K : 1], phik[XREP ? K : 1];
+    if constexpr (XREP) {
+        sfor<0, K>(MK_LAMBDA(k) {
+            xk[decltype(k)::value] = Gp::template bcast<N + decltype(k)::value>(x);
+            phik[decltype(k)::value] = Gp::template bcast<N + decltype(k)::value>(phi_r);
+        });
+    }
 
     // outputs: (b, t) lives at block index b*bs + t*ts -- (T, 1) model-major or (1, B) time-major
     constexpr bool RECF = (OUT == 1 || OUT == 3); // filtered moments go to packed records
@@ -217,6 +234,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 
         // ---- predict (:318-331; Phi diagonal) ----
         x = phi_r * x;
+        if constexpr (XREP) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) xk[k] = phik[k] * xk[k];
+        }
         if constexpr (WIDE) {
             int rv = r; // opaque copies: keeps the n selects inside the loop (hoisted, they are 2n VGPRs)
             double qv = q_r;
@@ -301,7 +322,87 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             }
             fmin_seen = min_f64(fmin_seen, f);
         };
-        if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
+        if constexpr (WIDE && MK_WIDE_FILTER_LOOP) {
+            // One model per wavefront: the mask of observed series is wavefront-uniform, so the updates run as a
+            // RUN-TIME loop over its set bits with ONE update body (the series index lives in an SGPR: v_readlane with a
+            // scalar lane select, loadings at a scalar LDS offset, P[j] through a uniform switch) instead of 2 x 32
+            // unrolled bodies -- 64 KB of code whose merged live ranges spilled the covariance row around the masked
+            // path (PMC: 399 GB of traffic per launch against 89 GB algorithmic at configs[3]).
+            unsigned long long m = (unsigned long long)vm;
+            int nupd = 0;
+            while (m) {
+                const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
+                m &= m - 1;
+                double vl = y - x, vl2 = 0.0;
+                sfor<0, K>(MK_LAMBDA(k) { // vl = y_l - x_l - sum_k gam_k x_{N+k}, two chains, factor states from registers
+                    constexpr int kk = decltype(k)::value;
+                    if constexpr (kk % 2 == 0) vl = fma(-gam[kk], xk[kk], vl);
+                    else vl2 = fma(-gam[kk], xk[kk], vl2);
+                });
+                vl += vl2;
+                const double v = readlane_f64(vl, j);
+                double dr = 0.0;
+                switch (j) {
+#define MK_CASE_P(c) \
+    case c:          \
+        if constexpr (c < N) dr = P[c]; \
+        break;
+                    MK_CASE_P(0) MK_CASE_P(1) MK_CASE_P(2) MK_CASE_P(3) MK_CASE_P(4) MK_CASE_P(5) MK_CASE_P(6) MK_CASE_P(7)
+                    MK_CASE_P(8) MK_CASE_P(9) MK_CASE_P(10) MK_CASE_P(11) MK_CASE_P(12) MK_CASE_P(13) MK_CASE_P(14) MK_CASE_P(15)
+                    MK_CASE_P(16) MK_CASE_P(17) MK_CASE_P(18) MK_CASE_P(19) MK_CASE_P(20) MK_CASE_P(21) MK_CASE_P(22) MK_CASE_P(23)
+                    MK_CASE_P(24) MK_CASE_P(25) MK_CASE_P(26) MK_CASE_P(27) MK_CASE_P(28) MK_CASE_P(29) MK_CASE_P(30) MK_CASE_P(31)
+                    MK_CASE_P(32) MK_CASE_P(33) MK_CASE_P(34) MK_CASE_P(35) MK_CASE_P(36) MK_CASE_P(37) MK_CASE_P(38) MK_CASE_P(39)
+                    MK_CASE_P(40) MK_CASE_P(41) MK_CASE_P(42) MK_CASE_P(43) MK_CASE_P(44) MK_CASE_P(45) MK_CASE_P(46) MK_CASE_P(47)
+                    MK_CASE_P(48) MK_CASE_P(49) MK_CASE_P(50) MK_CASE_P(51) MK_CASE_P(52) MK_CASE_P(53) MK_CASE_P(54) MK_CASE_P(55)
+                    MK_CASE_P(56) MK_CASE_P(57) MK_CASE_P(58) MK_CASE_P(59) MK_CASE_P(60) MK_CASE_P(61) MK_CASE_P(62) MK_CASE_P(63)
+#undef MK_CASE_P
+                default: break;
+                }
+                const double *gj = (GTAB ? gtab : dvec) + j * K; // loadings of series j (wavefront-uniform address)
+                sfor<0, K>(MK_LAMBDA(k) {
+                    constexpr int kk = decltype(k)::value;
+                    double g;
+                    if constexpr (GTAB) g = gj[kk];
+                    else g = readlane_f64(gam[kk], j);
+                    dr = fma(P[N + kk], g, dr);
+                });
+                double *dv = dvec2 + (nupd & 1) * NP; // two buffers: no second fence per update
+                dv[r] = dr;
+                double fl = rvar + dr, fl2 = 0.0;
+                double dk[K];
+                sfor<0, K>(MK_LAMBDA(k) { dk[decltype(k)::value] = Gp::template bcast<N + decltype(k)::value>(dr); });
+                sfor<0, K>(MK_LAMBDA(k) {
+                    constexpr int kk = decltype(k)::value;
+                    if constexpr (kk % 2 == 0) fl = fma(dk[kk], gam[kk], fl);
+                    else fl2 = fma(dk[kk], gam[kk], fl2);
+                });
+                fl += fl2;
+                const double f = readlane_f64(fl, j);
+                const double rf = rcp_nr(f);
+                const double kr = dr * rf;
+                wave_lds_sync();
+                {
+                    double dc[n];
+                    load_row<n>(dv, dc);
+#pragma unroll
+                    for (int c = 0; c < n; ++c) P[c] = fma(-dc[c], kr, P[c]);
+                }
+                sfor<0, K>(MK_LAMBDA(k) { // factor-state replicas: gain elements of lanes N+k (off the critical path)
+                    constexpr int kk = decltype(k)::value;
+                    xk[kk] = fma(Gp::template bcast<N + kk>(kr), v, xk[kk]);
+                });
+                x = fma(kr, v, x);
+                sigma = fma(v * v, rf, sigma);
+                fmant *= f;
+                if ((++nupd & 3) == 0) { // keep the product of innovation variances normalised (exact: powers of two)
+                    fexp += __builtin_amdgcn_frexp_exp(fmant);
+                    fmant = __builtin_amdgcn_frexp_mant(fmant);
+                }
+                fmin_seen = min_f64(fmin_seen, f);
+            }
+            fexp += __builtin_amdgcn_frexp_exp(fmant);
+            fmant = __builtin_amdgcn_frexp_mant(fmant);
+        } else if (ball == Gp::full_mask(N)) { // every model of this wavefront observes all N series: no masking
             sfor<0, N>(update);
         } else {
             sfor<0, N>(MK_LAMBDA(jc) {
@@ -1506,7 +1607,7 @@ static hipError_t launch_sparse_nk(const SparseArgs &a, hipStream_t s)
     constexpr int n = N + K;
     if constexpr (n <= 16) {
         constexpr int GPB = 256 / 16;
-        hipLaunchKernelGGL(observed_steps_kernel, dim3(1), dim3(256), 0, s, a.T, N, a.ostep, a.obs, a.tlist);
+        if (a.rebuild) hipLaunchKernelGGL(observed_steps_kernel, dim3(1), dim3(256), 0, s, a.T, N, a.ostep, a.obs, a.tlist);
         hipLaunchKernelGGL((loglik_sparse_kernel<N, K, 16>), dim3((unsigned)((a.B + GPB - 1) / GPB)), dim3(256), 0, s, a);
         return hipGetLastError();
     } else {

@@ -160,6 +160,14 @@ struct Group<64> {
     static constexpr unsigned long long full_mask(int N) { return N >= 64 ? ~0ull : (1ull << N) - 1ull; }
 };
 
+// value of `v` in lane `l`, l wavefront-uniform at run time (v_readlane_b32 with a scalar lane select)
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 typedef double v2d __attribute__((ext_vector_type(2))); // native <2 x double> (stays in VGPRs)
 
 template <int n>
@@ -238,6 +246,41 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// LDS stores executed by the lanes of a COMPILE-TIME mask only: exec is swapped around the store inside one asm block
+// (scalar moves with literal masks; an `if (lane ...)` costs a compare on the vector ALU and, worse, splits the basic block -- hipcc
+// then sinks whole dependency chains across the branch and spills what they keep alive).  The stores are untracked by
+// the compiler's lgkmcnt bookkeeping, which stays correct: LDS operations of a wavefront complete in order, so an
+// extra operation in the queue can only make a counted wait more conservative.
+typedef __attribute__((address_space(3))) double lds_double;
+template <unsigned long long MASK, int BYTE_OFFSET>
+__device__ __forceinline__ void lds_store_masked(double *p, double v)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %4\n\tds_write_b64 %1, %2 offset:%5\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"((unsigned)(unsigned long)(lds_double *)p), "v"(v), "n"((int)(unsigned)(MASK & 0xffffffffull)),
+                   "n"((int)(unsigned)(MASK >> 32)), "n"(BYTE_OFFSET)
+                 : "memory");
+}
+template <unsigned long long MASK, int BYTE_OFFSET>
+__device__ __forceinline__ void lds_store_masked(double *p, v2d v)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %4\n\tds_write_b128 %1, %2 offset:%5\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"((unsigned)(unsigned long)(lds_double *)p), "v"(v), "n"((int)(unsigned)(MASK & 0xffffffffull)),
+                   "n"((int)(unsigned)(MASK >> 32)), "n"(BYTE_OFFSET)
+                 : "memory");
+}
+
+// offset of row c of a lower triangle (diagonal excluded) packed by rows, every row padded to an even count
+constexpr int tri_off(int c)
+{
+    int s = 0;
+    for (int i = 0; i < c; ++i) s += (i + 1) & ~1;
+    return s;
 }
 
 constexpr int record_payload(int n) { return n + n * n; }

@@ -246,6 +246,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int NB = (n + 15) / 16; // 16-wide tile rows / columns
     constexpr int KS = (n + 3) / 4;   // k-steps
     constexpr int LD = (n + 3) & ~1;  // LDS row stride: even (16-byte rows), n + 2 or n + 3
+    constexpr int PADC = (n + 1) & ~1; // first of the (at least two) padding columns of a row of Dm: (phi_c, q_c)
+    // second LDS region: U = L D packed by rows (row c: its c elements k < c, padded to an even count) during the
+    // sweeps, then a 16-row staging buffer for J.  A full second n x LD matrix made the wavefront's share 22.4 KB:
+    // 7 wavefronts per CU instead of the 8 its registers allow, and 4096 models = 2.3 rounds of 1792 instead of 2
+    // of 2048 (measured at T = 500: 35.9 ms for 4096 models against 2 x 13.9 ms for 2 x 1792).
+    constexpr int USZ = tri_off(n), JSZ = 16 * LD, RSZ = USZ > JSZ ? USZ : JSZ;
     using Gp = Group<G>;
     const int lane = threadIdx.x;
     long inst = (long)blockIdx.x;
@@ -253,15 +259,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (!live) inst = a.B - 1;
     const int r = lane < n ? lane : n - 1;
     const long T = a.T;
-    __shared__ __attribute__((aligned(16))) double lds_m[2 * n * LD + 64];
-    double *Dm = lds_m;           // D = Ps[t+1] - Pp[t+1] row-major; after product 1: J V^T
-    double *Lm = Dm + n * LD;     // L (unit lower, 1/d_j in the diagonal slot); after the substitutions: J
-    double *dl = Lm + n * LD;     // delta = xs[t+1] - Xp[t+1]
+    __shared__ __attribute__((aligned(16))) double lds_m[n * LD + RSZ + 64];
+    double *Dm = lds_m;           // D = Ps[t+1] - Pp[t+1] row-major; after product 2: Ps[t]
+    double *Um = Dm + n * LD;     // U packed; then 16 rows of J at a time
+    double *dl = Um + RSZ;        // delta = xs[t+1] - Xp[t+1]
     double *Dr = Dm + r * LD;
-    double *Lr = Lm + r * LD;
+    double *Ur = Um + ((r & 1) ? 2 * (r >> 1) * ((r >> 1) + 1) : 2 * (r >> 1) * (r >> 1)); // = Um + tri_off(r)
 
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
+    Dr[PADC] = phi_r; // diag(Phi), diag(Q) as wavefront-uniform LDS operands (the padding columns are never overwritten)
+    Dr[PADC + 1] = q_r;
 
     const long blkT = inst * a.bs + (T - 1) * a.ts;
     MomentPtr iF = moment_ptr<n>(const_cast<double *>(a.F), const_cast<double *>(a.Pf), blkT, a.ts, a.rs, r);
@@ -336,9 +344,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int b = 0; b < NB; ++b) pt_col[b] = 16 * b + l15 < n ? 16 * b + l15 : n - 1;
     const double *recU = a.F + (inst * a.bs + (T - 1) * a.ts) * a.rs; // uniform (one model per wavefront); rs > 0 only
     const long recUstep = a.ts * a.rs;
-    int jt_row[NB]; // LDS row (of J) this lane reads the J^T tile column-block Ib from: i = 16 Ib + l15, clamped
-#pragma unroll
-    for (int b = 0; b < NB; ++b) jt_row[b] = (16 * b + l15 < n ? 16 * b + l15 : n - 1) * LD;
+    // row of the J staging buffer this lane reads its J^T tile elements from: i = 16 Ib + l15 (the last block clamped to row n-1)
+    const int jt_row = l15 * LD;
+    const int jt_last = (16 * (NB - 1) + l15 < n ? l15 : n - 1 - 16 * (NB - 1)) * LD;
 
     // last step: smoothed = filtered (:450-451)
     // Ps[t+1] lives in the LDS matrix Dm between iterations (row r in lane r's row), NOT in registers: with the
@@ -361,95 +369,83 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         {
             double Pfc[n];
             load_pf_rows(Pfc);
-            wave_lds_sync(); // previous iteration's reads of Dm / Lm are complete
-            double dprev = 0.0;
-            int rv = r; // opaque copies: keeps the n selects inside the loop (hoisted, they are 2n VGPRs)
-            double qv = q_r;
-            asm volatile("" : "+v"(rv), "+v"(qv));
-            sfor<0, n>(MK_LAMBDA(cc) { // D = Ps[t+1] - Pp[t+1], in place in this lane's row of Dm, pair by pair
-                constexpr int c = decltype(cc)::value;
-                z[c] = Pfc[c] * Gp::template bcast<c>(phi_r); // W = Pf Phi
-                A[c] = fma(phi_r, z[c], c == rv ? qv : 0.0);   // Pp[t+1] row
-                if constexpr (c % 2 == 1) {
-                    const v2d ps = *reinterpret_cast<const v2d *>(Dr + c - 1);
-                    *reinterpret_cast<v2d *>(Dr + c - 1) = v2d{ps.x - dprev, ps.y - A[c]};
-                } else if constexpr (c == n - 1) {
-                    Dr[c] = Dr[c] - A[c];
+            wave_lds_sync(); // previous iteration's reads of Dm / the J buffer are complete
+            sfor<0, n / 2 + n % 2>(MK_LAMBDA(pp) { // two columns at a time; phi_c is a wavefront-uniform LDS read
+                constexpr int c0 = 2 * decltype(pp)::value;
+                const double ph0 = Dm[c0 * LD + PADC];
+                z[c0] = Pfc[c0] * ph0;         // W = Pf Phi
+                A[c0] = phi_r * z[c0];         // row of Phi Pf Phi: Pp[t+1] WITHOUT q on the diagonal (added to the pivots)
+                if constexpr (c0 + 1 < n) {
+                    const double ph1 = Dm[(c0 + 1) * LD + PADC];
+                    z[c0 + 1] = Pfc[c0 + 1] * ph1;
+                    A[c0 + 1] = phi_r * z[c0 + 1];
+                    const v2d ps = *reinterpret_cast<const v2d *>(Dr + c0); // D = Ps[t+1] - Pp[t+1], in place
+                    *reinterpret_cast<v2d *>(Dr + c0) = v2d{ps.x - A[c0], ps.y - A[c0 + 1]};
                 } else {
-                    dprev = A[c];
+                    Dr[c0] = Dr[c0] - A[c0];
                 }
-                if constexpr (c % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c0 % 8 == 6) __builtin_amdgcn_sched_barrier(0);
             });
         }
+        Dr[r] -= q_r; // the diagonal of Q (replica lanes >= n rewrite row n-1 with the same value)
         dl[lane] = xs - phi_r * xfc; // delta (lanes >= n: replicas of lane n-1, never read)
         __builtin_amdgcn_sched_barrier(0);
-        // ---- A = L D L^T, rows distributed over the lanes (as smoother_wave_kernel) ----
-        sfor<0, n>(MK_LAMBDA(jc) {
-            constexpr int j = decltype(jc)::value;
-            const double piv = Gp::template bcast<j>(A[j]);
-            pivmin = min_f64(pivmin, piv);
-            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_j <= 0: null direction dropped (see ldlt_factor)
-            const double lr = A[j] * ij;
-            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
-            A[j] = j == r ? ij : lr; // (r, not lane: the replica lanes >= n write row n-1 too)
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        store_row<n>(Lr, A); // row r of L (entries above the diagonal are dead values, never read)
-        wave_lds_sync();
-
-        // ---- lane i solves A z = W_i: operands L(c,k) from the LDS copy, wavefront-uniform addresses ----
-        // forward (dot form): y_c = w_c - sum_{k<c} L(c,k) y_k, then y_c *= 1/d_c (diagonal slot of row c).
-        // The 16-byte reads of a row are issued as a BATCH ahead of the multiply-adds that consume them (left
-        // to itself hipcc emits read / s_waitcnt lgkmcnt(0) / 2 FMAs per pair: one LDS round trip per pair).
-        sfor<1, n>(MK_LAMBDA(cc) {
+        // ---- A = L D L^T and the forward substitution of W, ONE sweep over the columns (dot form) ----
+        // Lane r carries row r of A and row r of W through the same forward substitution: with U = L D (row c,
+        // k < c, in the LDS matrix) and the lane's own L(r, k) in registers,
+        //     u_c = A(r,c) - sum_{k<c} U(c,k) L(r,k)   = d_c L(r,c)   (lane c: the pivot d_c, once q_c is added)
+        //     y_c = W(r,c) - sum_{k<c} U(c,k) z~_k ,   z~_c = y_c / d_c
+        // The operands U(c, .) are wavefront-uniform LDS reads shared by both sums: the factorization costs no
+        // cross-lane traffic at all (the right-looking form it replaces moved row j to every lane with 2(n-j)
+        // readlanes per column, 1332 VALU instructions a step at n = 36, on a kernel that is VALU-issue bound).
+        // u_c goes to LDS BEFORE the reciprocal: the write -> read round trip of row c+1 overlaps the pivot chain.
+        if (!(a.tune & 4))
+        sfor<0, n>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
-            constexpr int NP = (c + 1) / 2; // pairs covering elements 0 .. c-1 (the last may reach the diagonal slot)
-            const double *Lc = Lm + c * LD;
-            v2d buf[NP];
+            constexpr int NPR = (c + 1) / 2; // pairs covering elements 0 .. c-1 (the last may reach the diagonal slot)
+            constexpr int PB = 4;            // pairs per batch of reads
+            const double *Uc = Um + tri_off(c);
+            double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
+            sfor<0, (NPR + PB - 1) / PB>(MK_LAMBDA(bb) {
+                constexpr int p0 = PB * decltype(bb)::value, p1 = p0 + PB < NPR ? p0 + PB : NPR;
+                v2d buf[PB];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) buf[p] = *reinterpret_cast<const v2d *>(Lc + 2 * p);
-            __builtin_amdgcn_sched_barrier(0);
-            double s0 = z[c], s1 = 0.0, s2 = 0.0, s3 = 0.0; // four chains: a lone wavefront's dependent f64 FMAs are slow
+                for (int p = p0; p < p1; ++p) buf[p - p0] = *reinterpret_cast<const v2d *>(Uc + 2 * p);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                if (p % 2 == 0) {
-                    s0 = fma(-buf[p].x, z[2 * p], s0);
-                    if (2 * p + 1 < c) s1 = fma(-buf[p].y, z[2 * p + 1], s1);
-                } else {
-                    s2 = fma(-buf[p].x, z[2 * p], s2);
-                    if (2 * p + 1 < c) s3 = fma(-buf[p].y, z[2 * p + 1], s3);
+                for (int p = p0; p < p1; ++p) {
+                    a0 = fma(-buf[p - p0].x, A[2 * p], a0);
+                    s0 = fma(-buf[p - p0].x, z[2 * p], s0);
+                    if (2 * p + 1 < c) {
+                        a1 = fma(-buf[p - p0].y, A[2 * p + 1], a1);
+                        s1 = fma(-buf[p - p0].y, z[2 * p + 1], s1);
+                    }
                 }
-            }
-            z[c] = (s0 + s1) + (s2 + s3);
+            });
+            const double u = a0 + a1;
+            if constexpr (c + 1 < n) // U(r, c), lanes r > c only: the rows are packed (replica lanes >= n rewrite row n-1)
+                lds_store_masked<~0ull << (c + 1), 8 * c>(Ur, u);
+            wave_lds_sync();
+            const double piv = readlane_f64(u, c) + Dm[c * LD + PADC + 1]; // d_c = u_c(lane c) + q_c
+            pivmin = min_f64(pivmin, piv);
+            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
+            A[c] = u * ij;          // L(r, c)
+            z[c] = (s0 + s1) * ij;  // z~_c
         });
-        {
-            double dv[n];
-#pragma unroll
-            for (int c = 0; c < n; ++c) dv[c] = Lm[c * LD + c];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < n; ++c) z[c] *= dv[c];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // backward (axpy form): for k = n-1 .. 1: z_c -= L(k,c) z_k, c < k
+        wave_lds_sync();
+        // backward: x_c = z~_c - sum_{k>c} L(k,c) x_k, axpy form over the rows k = n-1 .. 1 of L.  Row k of L is
+        // what lane k still holds in A[] after the forward sweep: its elements reach every lane as readlane
+        // pairs (scalar operands of the multiply-add) -- no LDS traffic, which is what bounds this kernel
+        if (!(a.tune & 2))
         sfor_down<1, n>(MK_LAMBDA(kc) {
-            constexpr int k = decltype(kc)::value + 1; // sfor_down<1,n> yields n-2 .. 0; rows n-1 .. 1
-            constexpr int NP = (k + 1) / 2;
-            const double *Lk = Lm + k * LD;
-            v2d buf[NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) buf[p] = *reinterpret_cast<const v2d *>(Lk + 2 * p);
-            __builtin_amdgcn_sched_barrier(0);
+            constexpr int k = decltype(kc)::value + 1; // n-1 .. 1
             const double zk = z[k];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                z[2 * p] = fma(-buf[p].x, zk, z[2 * p]);
-                if (2 * p + 1 < k) z[2 * p + 1] = fma(-buf[p].y, zk, z[2 * p + 1]);
-            }
+            sfor<0, k>(MK_LAMBDA(c2) {
+                constexpr int c = decltype(c2)::value;
+                z[c] = fma(-Gp::template bcast<k>(A[c]), zk, z[c]);
+            });
         });
         // z = J[r, :]
-        wave_lds_sync();        // every lane is done with L
-        store_row<n>(Lr, z);    // Lm now holds J row-major
         // smoothed mean (:461-464): xs[t] = F[t] + J delta, delta from LDS (uniform reads)
         {
             double a0 = xfc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -476,7 +472,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             xs = (a0 + a1) + (a2 + a3);
             asm volatile("" : "+v"(xs)); // finished HERE: deferred behind the products, its delta operands were spilled
         }
-        wave_lds_sync(); // Dm (D) and Lm (J) visible to the whole wavefront
+        wave_lds_sync(); // Dm (D) visible to the whole wavefront
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- MFMA tiles ----
@@ -511,17 +507,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 });
             });
         }
-        // J^T in C-layout: JT[Ib][ks] = J[16 Ib + l15][4 ks + l4] (k >= n only when n % 4 != 0: zero)
+        // J^T in C-layout: JT[Ib][ks] = J[16 Ib + l15][4 ks + l4] (k >= n only when n % 4 != 0: zero).  The rows of J
+        // go from the lanes' registers through the staging buffer 16 at a time (LDS operations of one wavefront
+        // execute in order: the fences are compiler fences)
         double JT[NB][KS];
         sfor<0, NB>(MK_LAMBDA(ib) {
+            constexpr int Ib = decltype(ib)::value;
+            wave_lds_sync(); // the reads of the previous 16 rows (Ib = 0: of U) are complete
+            {
+                constexpr unsigned long long rows = 0xffffull << (16 * Ib); // lanes = rows 16 Ib .. 16 Ib + 15 (those >= n: row n-1 again)
+                double *dst = Um + (r - 16 * Ib) * LD; // (masked-off lanes: never dereferenced)
+                sfor<0, n / 2>(MK_LAMBDA(pp) {
+                    constexpr int c0 = 2 * decltype(pp)::value;
+                    lds_store_masked<rows, 8 * c0>(dst, v2d{z[c0], z[c0 + 1]});
+                });
+                if constexpr (n % 2 == 1) lds_store_masked<rows, 8 * (n - 1)>(dst, z[n - 1]);
+            }
+            wave_lds_sync();
+            const int jrow = Ib == NB - 1 ? jt_last : jt_row;
             sfor<0, KS>(MK_LAMBDA(ks) {
                 constexpr int kb = 4 * decltype(ks)::value;
                 if constexpr (kb + 3 < n) {
-                    JT[decltype(ib)::value][decltype(ks)::value] = Lm[jt_row[decltype(ib)::value] + kb + l4];
+                    JT[Ib][decltype(ks)::value] = Um[jrow + kb + l4];
                 } else {
                     const int k = kb + l4;
-                    const double v = Lm[jt_row[decltype(ib)::value] + (k < n ? k : n - 1)];
-                    JT[decltype(ib)::value][decltype(ks)::value] = k < n ? v : 0.0;
+                    const double v = Um[jrow + (k < n ? k : n - 1)];
+                    JT[Ib][decltype(ks)::value] = k < n ? v : 0.0;
                 }
             });
         });
@@ -531,6 +542,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // Product 2 may not overwrite Dm before every block row of D has been read: the accumulators stay in
         // registers until the end.  A operand of product 2: J[i][k] = JT[Ib][ks]; B operand: the V^T rows just made.
         __builtin_amdgcn_sched_barrier(0);
+        if (!(a.tune & 1))
         sfor<0, NB>(MK_LAMBDA(kb) {
             constexpr int Kb = decltype(kb)::value;
             __builtin_amdgcn_sched_barrier(0); // keeps the next block row's operand loads from being hoisted (registers)
@@ -609,9 +621,20 @@ static bool use_v1()
     return v != 0;
 }
 
-template <int N, int K>
-static hipError_t launch_wide_nk(const SmootherArgs &a, hipStream_t s)
+static long wide_tune()
 {
+    static const long v = [] {
+        const char *e = getenv("MK_WIDE_TUNE");
+        return e ? atol(e) : 0L;
+    }();
+    return v;
+}
+
+template <int N, int K>
+static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
+{
+    SmootherArgs a = a0;
+    a.tune = wide_tune();
     if constexpr (N + K > 16) {
         const unsigned grid = (unsigned)a.B;
         const bool proj = a.sim_means || a.sim_vars;

@@ -127,6 +127,7 @@ class BatchedKalman:
         self.obs = self._layout(obs)
         self._obs_unmasked = None
         self.R, self.T, self.N = (int(s) for s in self.obs.shape)
+        check(self._L.mk_observations_changed(self._ctx))  # a recycled allocation may carry a new record at an old address
         return self
 
     # ------------------------------------------------------------------ ingestion
@@ -150,6 +151,7 @@ class BatchedKalman:
                                      self._p(self.obs), self._p(mean), self._p(std)))
         self._obs_unmasked = None
         self.scale, self.offset = std, mean
+        check(self._L.mk_observations_changed(self._ctx))  # standardised in place
         return mean, std
 
     def mask_observations(self, mask):
@@ -173,6 +175,7 @@ class BatchedKalman:
         check(self._L.mk_mask_observations(self._ctx, int(base.numel()), self._p(base), self._p(mask), self._p(out)))
         self._obs_unmasked = base
         self.obs = out
+        check(self._L.mk_observations_changed(self._ctx))
         return self
 
     def unmask_observations(self):
@@ -180,6 +183,7 @@ class BatchedKalman:
         if getattr(self, "_obs_unmasked", None) is not None:
             self.obs = self._obs_unmasked
             self._obs_unmasked = None
+            check(self._L.mk_observations_changed(self._ctx))
         return self
 
     def pack_observations(self):

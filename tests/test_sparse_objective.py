@@ -63,3 +63,36 @@ def test_sparse_objective_on_examples_data(g1):
     assert abs(mle[0] - 2332.327069381027) < 1e-8 and abs(mle[1] - 2384.792799342231) < 1e-8
     ms, _ = kf.last_kernel_ms()
     assert ms < 3.0, ms     # the step-by-step filter needs ~9 ms for the 6255 steps of this record
+
+
+def test_observed_step_list_is_cached_per_record_and_invalidated(g1):
+    """The list of observed steps is built once per uploaded record (the solver evaluates the objective ~80 times
+    on it) and rebuilt when the record changes: a new buffer, or the same buffer changed in place followed by
+    mk_observations_changed (which every mutating engine call issues)."""
+    from metran_amd._lib import check
+    from metran_amd.engine import BatchedKalman
+
+    kf = BatchedKalman(0).set_observations(g1["obs"][None]).set_loadings(g1["loadings"][None])
+    phi, q = kf.params_from_alpha(g1["alpha_star"][None])
+    first = float(kf.loglik(phi, q)[0])
+    assert float(kf.loglik(phi, q)[0]) == first == float(kf.loglik(phi, q)[0])     # cached list: same value
+    # mask one observation through the engine (new buffer + notification): the reference's masked value
+    import torch
+
+    mask = torch.zeros((1,) + g1["obs"].shape, dtype=torch.uint8)
+    mask[0, int(g1["mask_t"]), 4] = 1
+    kf.mask_observations(mask)
+    assert abs(float(kf.loglik(phi, q)[0]) - float(g1["masked_mle_star"])) < 1e-8
+    kf.unmask_observations()
+    assert float(kf.loglik(phi, q)[0]) == first
+    # in-place change of the SAME buffer (an empty step receives an observation): stale until the context is told
+    t_new = int(np.nonzero(~np.isfinite(g1["obs"]).any(1))[0][100])
+    kf.obs[0, t_new, 2] = 0.4
+    stale = float(kf.loglik(phi, q)[0])
+    check(kf._L.mk_observations_changed(kf._ctx))
+    fresh = float(kf.loglik(phi, q)[0])
+    y = g1["obs"].copy()
+    y[t_new, 2] = 0.4
+    ph, qq = phi.cpu().numpy(), q.cpu().numpy()
+    ref = oracle.dfm_batch(y[None], ph, qq, g1["loadings"][None], smooth=False, outputs="mle")["mle"][0]
+    assert abs(fresh - ref) < 1e-8 and stale == first and abs(first - ref) > 1e-3
