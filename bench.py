@@ -46,7 +46,8 @@ EVALS_PER_STEP = 50  # c5: "50 parameter evaluations x batch=8192"
 def kernel_source_sha():
     """Identity of the kernels a PMC profile belongs to (stamped into profiles/*/pmc_hbm.json)."""
     h = hashlib.sha256()
-    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_internal.h"):
+    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_wide.hip", "metran_amd/csrc/mk_prims.h",
+              "metran_amd/csrc/mk_internal.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -307,19 +308,18 @@ def main():
         step()
     sync()
     if kf is not None:
-        kf.enable_timing(True)
+        kf.enable_timing(True, accumulate=True)   # one hipEvent pair per launch on the launch stream, read AFTER the loop
         torch.cuda.synchronize()
-    filt_ms, smooth_ms = [], []
+    f_avg = s_avg = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-        if kf is not None:
-            f_ms, s_ms = kf.last_kernel_ms()   # hipEvents on the launch stream
-            filt_ms.append(f_ms)
-            smooth_ms.append(s_ms)
     sync()
     elapsed = time.perf_counter() - t0
     if kf is not None:
+        f_tot, f_n, s_tot, s_n = kf.kernel_ms_totals()   # every launch of the timed region
+        f_avg = f_tot / max(f_n, 1)
+        s_avg = s_tot / max(s_n, 1)
         kf.enable_timing(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nranks = torch.ones(1, dtype=torch.float64, device=dev)
@@ -361,8 +361,8 @@ def main():
             res["models_per_s"] = models_per_s
             res["models_per_s_per_gpu"] = models_per_s / world
             ab = algorithmic_bytes(N, K, T, mode, sym=args.packed_sym)
-            f_avg = float(np.mean(filt_ms))
-            s_avg = float(np.mean(smooth_ms)) if mode != "solver" else 0.0
+            if mode == "solver":
+                s_avg = 0.0
             fname = "filter_kernel"
             wide = N + K > 16   # one model per wavefront: mk_wide.hip (MK_WIDE_SMOOTHER=v1 selects the round-1 kernel)
             sname = None if mode == "solver" else (

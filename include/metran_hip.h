@@ -284,10 +284,16 @@ MK_API int mk_fa_rotate(mk_context *ctx, int64_t B, int64_t N, int64_t KMAX, con
 MK_API int mk_fa_eigh(mk_context *ctx, int64_t B, int64_t N, const double *d_sym, double *d_val, double *d_vec);
 
 /* ---- instrumentation --------------------------------------------------------------------- */
-/* When enabled, every kernel launch is bracketed by hipEvents on the context's stream. */
+/* When enabled, every kernel launch is bracketed by hipEvents on the context's stream.  enable = 1: the most recent
+ * launch of each kind is kept (mk_last_kernel_ms); enable = 2: EVERY launch keeps its own event pair until
+ * mk_kernel_ms_totals collects them -- no host synchronisation inside a timed loop. */
 MK_API int mk_enable_timing(mk_context *ctx, int enable);
 /* Duration of the most recent filter / smoother kernel (ms); synchronises on their events. */
 MK_API int mk_last_kernel_ms(mk_context *ctx, float *filter_ms, float *smoother_ms);
+/* enable = 2: summed duration (ms) and number of the filter (or objective) and smoother launches since the previous
+ * call (or since timing was enabled); synchronises on their events and recycles them. */
+MK_API int mk_kernel_ms_totals(mk_context *ctx, double *filter_ms, int64_t *filter_launches, double *smoother_ms,
+                               int64_t *smoother_launches);
 
 #ifdef __cplusplus
 }

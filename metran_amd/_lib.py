@@ -116,6 +116,7 @@ API = {
     "mk_fa_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mk_enable_timing": (c_int, [c_void_p, c_int]),
     "mk_last_kernel_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
+    "mk_kernel_ms_totals": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
 }
 
 _lib = None

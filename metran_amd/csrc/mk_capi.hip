@@ -16,9 +16,11 @@
 struct mk_context {
     int device;
     hipStream_t stream;
-    bool timing;
-    hipEvent_t ev[4]; // filter start/stop, smoother start/stop
+    int timing;       // 0 off, 1 the most recent launch of each kind, 2 every launch until mk_kernel_ms_totals
+    hipEvent_t ev[4]; // filter start/stop, smoother start/stop (mode 1)
     bool have_filter_time, have_smooth_time;
+    std::vector<hipEvent_t> ev_pool;                              // mode 2: recycled events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending[2]; // mode 2: one (start, stop) pair per launch; 0 filter, 1 smoother
     int *tlist;      // workspace of the sparse objective (observed-step list), grown on demand
     long tlist_cap;
     // the list is rebuilt only when the record it was built from changes: same pointer, shape and layout, and no
@@ -47,6 +49,34 @@ static int fail(int code, const char *fmt, ...)
 #define MK_CTX(ctx)                                              \
     if (!(ctx)) return fail(MK_ERR_INVALID, "null mk_context"); \
     MK_HIP(hipSetDevice((ctx)->device))
+
+// ---- hipEvent timing of the hot kernels: kind 0 = filter / objective, 1 = smoother ----
+static hipError_t timing_start(mk_context *ctx, int kind)
+{
+    if (!ctx->timing) return hipSuccess;
+    if (ctx->timing == 2) {
+        hipEvent_t e[2];
+        for (auto &x : e) {
+            if (!ctx->ev_pool.empty()) {
+                x = ctx->ev_pool.back();
+                ctx->ev_pool.pop_back();
+            } else {
+                const hipError_t err = hipEventCreate(&x);
+                if (err != hipSuccess) return err;
+            }
+        }
+        ctx->ev_pending[kind].push_back({e[0], e[1]});
+        return hipEventRecord(e[0], ctx->stream);
+    }
+    return hipEventRecord(ctx->ev[2 * kind], ctx->stream);
+}
+static hipError_t timing_stop(mk_context *ctx, int kind)
+{
+    if (!ctx->timing) return hipSuccess;
+    if (ctx->timing == 2) return hipEventRecord(ctx->ev_pending[kind].back().second, ctx->stream);
+    (kind ? ctx->have_smooth_time : ctx->have_filter_time) = true;
+    return hipEventRecord(ctx->ev[2 * kind + 1], ctx->stream);
+}
 
 // ---- run-time shape modules (see the MK_SHAPE_MODULE block of mk_kernels.hip and metran_amd/jit.py) ----
 namespace {
@@ -185,7 +215,7 @@ MK_API int mk_create(int device, mk_context **out)
     if (!ctx) return fail(MK_ERR_ALLOC, "out of host memory");
     ctx->device = device;
     ctx->stream = nullptr;
-    ctx->timing = false;
+    ctx->timing = 0;
     ctx->have_filter_time = ctx->have_smooth_time = false;
     ctx->tlist = nullptr;
     ctx->tlist_cap = 0;
@@ -206,6 +236,12 @@ MK_API int mk_destroy(mk_context *ctx)
     if (!ctx) return MK_OK;
     (void)hipSetDevice(ctx->device);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto &v : ctx->ev_pending)
+        for (auto &pr : v) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     delete ctx;
     return MK_OK;
@@ -398,12 +434,9 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.Xp = o->d_Xp;
     a.Pp = o->d_Pp;
     a.status = o->d_status;
-    if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    MK_HIP(timing_start(ctx, 0));
     MK_HIP(dispatch_filter((int)p->N, (int)p->K, a, ctx->stream));
-    if (ctx->timing) {
-        MK_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-        ctx->have_filter_time = true;
-    }
+    MK_HIP(timing_stop(ctx, 0));
     return MK_OK;
 }
 
@@ -461,12 +494,9 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
         a.state_vars = o->d_Ps;
     }
     a.status = o->d_status;
-    if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    MK_HIP(timing_start(ctx, 1));
     MK_HIP(dispatch_smoother((int)p->N, (int)p->K, a, ctx->stream));
-    if (ctx->timing) {
-        MK_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-        ctx->have_smooth_time = true;
-    }
+    MK_HIP(timing_stop(ctx, 1));
     return MK_OK;
 }
 
@@ -514,12 +544,9 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
         ctx->tlist_ostep = a.ostep;
         a.mle = d_mle;
         a.status = nullptr;
-        if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        MK_HIP(timing_start(ctx, 0));
         MK_HIP(dispatch_sparse((int)p->N, (int)p->K, a, ctx->stream));
-        if (ctx->timing) {
-            MK_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-            ctx->have_filter_time = true;
-        }
+        MK_HIP(timing_stop(ctx, 0));
         return MK_OK;
     }
     mk_outputs o;
@@ -620,12 +647,9 @@ MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *p, double *d_work, 
     a.sigmacount = (const long long *)d_sigmacount;
     a.gphi = d_gphi;
     a.gq = d_gq;
-    if (ctx->timing) MK_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    MK_HIP(timing_start(ctx, 1));
     MK_HIP(dispatch_adjoint((int)p->N, (int)p->K, a, ctx->stream));
-    if (ctx->timing) {
-        MK_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
-        ctx->have_smooth_time = true; // reported in the smoother slot of mk_last_kernel_ms
-    }
+    MK_HIP(timing_stop(ctx, 1)); // reported in the smoother slot of mk_last_kernel_ms / mk_kernel_ms_totals
     return MK_OK;
 }
 
@@ -719,8 +743,40 @@ MK_API int mk_fa_eigh(mk_context *ctx, int64_t B, int64_t N, const double *sym, 
 MK_API int mk_enable_timing(mk_context *ctx, int enable)
 {
     MK_CTX(ctx);
-    ctx->timing = enable != 0;
+    ctx->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     ctx->have_filter_time = ctx->have_smooth_time = false;
+    for (auto &v : ctx->ev_pending) { // pairs nobody asked for: back to the pool
+        for (auto &pr : v) {
+            ctx->ev_pool.push_back(pr.first);
+            ctx->ev_pool.push_back(pr.second);
+        }
+        v.clear();
+    }
+    return MK_OK;
+}
+
+MK_API int mk_kernel_ms_totals(mk_context *ctx, double *filter_ms, int64_t *filter_launches, double *smoother_ms,
+                               int64_t *smoother_launches)
+{
+    MK_CTX(ctx);
+    double tot[2] = {0.0, 0.0};
+    int64_t cnt[2] = {0, 0};
+    for (int kind = 0; kind < 2; ++kind) {
+        for (auto &pr : ctx->ev_pending[kind]) {
+            float ms = 0.f;
+            MK_HIP(hipEventSynchronize(pr.second));
+            MK_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            tot[kind] += ms;
+            ++cnt[kind];
+            ctx->ev_pool.push_back(pr.first);
+            ctx->ev_pool.push_back(pr.second);
+        }
+        ctx->ev_pending[kind].clear();
+    }
+    if (filter_ms) *filter_ms = tot[0];
+    if (filter_launches) *filter_launches = cnt[0];
+    if (smoother_ms) *smoother_ms = tot[1];
+    if (smoother_launches) *smoother_launches = cnt[1];
     return MK_OK;
 }
 

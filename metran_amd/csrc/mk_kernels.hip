@@ -13,6 +13,9 @@
 //   smoother_kernel : kalmansmoother   metran/kalmanfilter.py:403-476
 //   simulate/decompose kernels : SPKalmanFilter.simulate/decompose :569-644
 //   params kernel   : Metran._phi / get_transition_* metran/metran.py:246-322
+#include <cstdlib>
+#include <cstring>
+
 #include "mk_prims.h"
 
 namespace mk {
@@ -635,9 +638,8 @@ struct RecordIO {
 #pragma unroll
         for (int m = 0; m < PER; ++m) buf[m] = *reinterpret_cast<const chunk_t *>(base + mp.off[m]);
     }
-    // registers -> LDS image -> x element r and row r of this model
-    static __device__ __forceinline__ void load_finish(double *img, const chunk_t (&buf)[PER], const Map &mp, int g,
-                                                       int r, double &x, double (&row)[n])
+    // registers -> LDS image (the wavefront's records of one step, full-square layout)
+    static __device__ __forceinline__ void to_image(double *img, const chunk_t (&buf)[PER], const Map &mp)
     {
         wave_lds_sync();
         if constexpr (SYM) {
@@ -654,6 +656,12 @@ struct RecordIO {
             for (int m = 0; m < PER; ++m) l[mp.lq[m]] = buf[m];
         }
         wave_lds_sync();
+    }
+    // registers -> LDS image -> x element r and row r of this model
+    static __device__ __forceinline__ void load_finish(double *img, const chunk_t (&buf)[PER], const Map &mp, int g,
+                                                       int r, double &x, double (&row)[n])
+    {
+        to_image(img, buf, mp);
         x = img[g * RS + r];
         load_row<n>(img + g * RS + n + r * n, row);
     }
@@ -858,6 +866,337 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
 
         store(xs, Psn);
         xfc = xf_next;
+    }
+    if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// smoother_blk_kernel: the record smoother with its two n^3 products on the matrix pipe (n <= 15, packed records).
+// Measured on MI355X (scripts/ubench/power_probe.hip, mfma44.hip): at full-chip occupancy a v_fmac_f64_dpp costs ~3.3 ns
+// of SIMD time (2.3 ns without DPP) whatever the number of resident wavefronts, and f64 MFMA shares that pipe (it does
+// NOT overlap another wavefront's f64 vector work) -- but v_mfma_f64_4x4x4_4b_f64 retires 4 x 64 multiply-adds in 7.9 ns,
+// 1.7x the DPP rate, and its four independent 4x4x4 products are exactly "one block of each of the wavefront's four
+// models".  So the factorisation and the substitutions stay in the row-per-lane DPP form (their operands are
+// broadcasts of single elements), and
+//     D~ = Ps~[t+1] - (pp o Pf~ + Q~),   V^T = D J^T,   Ps~[t] = Pf~ + J V^T                      (kalmanfilter.py:461-474)
+// run on 4x4 blocks: lane l = x0 + 4 b + 16 x2 holds element (x2, x0) of a block of model b; such a C/D block is the B
+// operand as it stands and acts as its TRANSPOSE when passed as the A operand, so J's blocks (read once from LDS in
+// transposed form) serve both products, V^T never leaves the registers and D~ is formed elementwise in the layout the
+// previous step's result already has (its transposed blocks are its own mirror blocks: D is symmetric).  The smoothed
+// mean rides as column n of the covariance: Pf~ = [Pf | F], D~'s column n = S[t+1] - Phi F[t] passes through the
+// accumulator of product 1, column n of the result is S[t].  Padding (rows >= n, columns > n) is zero in the LDS images
+// and stays zero (J's padding rows read a zero row).
+// LDS per wavefront: a load image and a store image in tile layout (row r of model g at g IM + r TS: 16-byte row reads
+// for the DPP part, conflict-free 8-byte block accesses for the MFMA part; mean of row r in column n) and J's rows.
+template <int N, int K, bool SYM>
+struct BlkLayout {
+    static constexpr int n = N + K;
+    using RIO = RecordIO<n, 16, SYM>;             // chunk geometry of the HBM records (RSO, RC, CW, PER) and locate()
+    static constexpr int NBR = (n + 3) / 4;       // row (and k) blocks
+    static constexpr int NBC = (n + 4) / 4;       // column blocks, the mean column included
+    static constexpr int TR = 4 * NBR;            // tile rows kept in the image (rows >= n stay zero)
+    static constexpr int TS = 20;                 // row stride, doubles (160 B: 16-byte aligned rows; block reads of the two
+                                                  // x2 values of a half-wavefront land 40 banks apart)
+    static constexpr int IM = ((TR * TS - 8 + 31) / 32) * 32 + 8; // doubles per model, = 8 mod 32: the four models' blocks
+                                                                  // start 16 banks apart
+    static constexpr int DUMP = 4 * IM, ZERO = 4 * IM + 2; // where loaded pads go / where stored pads come from
+    static constexpr int IMG = 4 * IM + 4;        // doubles per image
+    static constexpr int JR = 4 * NBR;            // J row stride: columns padded to the block boundary (zeros)
+    static constexpr int JM = (n + 1) * JR;       // rows 0..n-1 and one zero row (every padding row reads it)
+    static constexpr int WAVE = 2 * IMG + 4 * JM; // doubles per wavefront
+    static_assert(n <= 15 && 4 * NBC <= TS, "the mean rides as column n of the tile");
+    static_assert(IM % 2 == 0 && IMG % 2 == 0 && JM % 2 == 0 && JR % 2 == 0, "16-byte alignment of the row accesses");
+
+    struct Map {           // loop-invariant per-lane addressing of its PER 16-byte chunks of the wavefront's 4 records
+        long off[RIO::PER]; // element offset of the chunk inside the record ARRAY at t = 0
+        int l0[RIO::PER], l1[RIO::PER];                     // load side: image positions of the chunk's two doubles
+        int s0[RIO::PER], s1[RIO::PER];                     // store side (pads and the smoothed set's sigma/detf: zeros)
+        int m0[SYM ? RIO::PER : 1], m1[SYM ? RIO::PER : 1]; // SYM loads: mirror positions of off-diagonal elements
+    };
+    // index p of a record -> position inside ONE model's tile image; kind: 0 payload, 1 sigma/detf, 2 zero pad
+    static __device__ __forceinline__ void locate(int p, int &pos, int &mirror, int &kind)
+    {
+        if constexpr (SYM) {
+            int rp, rm;
+            RIO::locate(p, rp, rm, kind); // positions in the full-square record layout
+            pos = rp < n ? rp * TS + n : ((rp - n) / n) * TS + (rp - n) % n;
+            mirror = rm < n ? rm * TS + n : ((rm - n) / n) * TS + (rm - n) % n;
+        } else {
+            kind = p < RIO::NV ? 0 : (p < RIO::NV + 2 ? 1 : 2);
+            pos = p < n ? p * TS + n : ((p - n) / n) * TS + (p - n) % n;
+            mirror = pos;
+        }
+    }
+    static __device__ __forceinline__ Map make_map(int lane64, long inst0, long B, long bs)
+    {
+        Map mp;
+#pragma unroll
+        for (int m = 0; m < RIO::PER; ++m) {
+            int q = lane64 + 64 * m;
+            if (q > RIO::CW - 1) q = RIO::CW - 1; // surplus lanes duplicate the last chunk (same bytes, same address)
+            const int g = q / RIO::RC, w = q - g * RIO::RC;
+            long ig = inst0 + g;
+            if (ig > B - 1) ig = B - 1; // surplus groups replicate the last model
+            mp.off[m] = ig * bs * RIO::RSO + 2 * w;
+            int pos, mir, kind;
+            locate(2 * w, pos, mir, kind);
+            mp.l0[m] = kind == 0 ? g * IM + pos : DUMP;
+            mp.s0[m] = kind == 0 ? g * IM + pos : ZERO;
+            if constexpr (SYM) mp.m0[m] = kind == 0 ? g * IM + mir : DUMP;
+            locate(2 * w + 1, pos, mir, kind);
+            mp.l1[m] = kind == 0 ? g * IM + pos : DUMP + 1;
+            mp.s1[m] = kind == 0 ? g * IM + pos : ZERO + 1;
+            if constexpr (SYM) mp.m1[m] = kind == 0 ? g * IM + mir : DUMP + 1;
+        }
+        return mp;
+    }
+};
+
+template <int N, int K, int EPI, bool SYM>
+__global__ void __launch_bounds__(128) smoother_blk_kernel(SmootherArgs a)
+{
+    constexpr bool PROJ = (EPI == 1), VAR = (EPI == 2);
+    constexpr int n = N + K, G = 16;
+    using Gp = Group<G>;
+    using BL = BlkLayout<N, K, SYM>;
+    using RIO = typename BL::RIO;
+    constexpr int PER = RIO::PER, NBR = BL::NBR, NBC = BL::NBC, TS = BL::TS, IM = BL::IM, JR = BL::JR, JM = BL::JM;
+    __shared__ __attribute__((aligned(16))) double lds_blk[2 * BL::WAVE];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane64 = threadIdx.x & 63;
+    const long inst0 = (long)blockIdx.x * 8 + wave * 4; // first of the wavefront's four models
+    const long T = a.T;
+    double *imgL = lds_blk + wave * BL::WAVE, *imgS = imgL + BL::IMG, *jar = imgS + BL::IMG;
+    const long rstep = a.ts * RIO::RSO;
+
+    // ---- row mapping (DPP part, epilogues): lane r of group gw owns row r of model inst0 + gw
+    const int lane = lane64 & 15, gw = lane64 >> 4;
+    long inst = inst0 + gw;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1; // surplus groups replicate the last model (identical stores)
+    const int r = lane < n ? lane : n - 1; // lanes >= n replicate lane n-1
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+    double phic[n], qd[n]; // diag(Phi) replicated; row r of Q = diag(q)
+    sfor<0, n>(MK_LAMBDA(c) {
+        phic[decltype(c)::value] = Gp::template bcast<decltype(c)::value>(phi_r);
+        qd[decltype(c)::value] = (decltype(c)::value == r) ? q_r : 0.0;
+    });
+
+    // ---- block mapping (MFMA part): lane = x0 + 4 b + 16 x2 holds element (x2, x0) of a 4x4 block of model inst0 + b
+    const int x0 = lane64 & 3, bm = (lane64 >> 2) & 3, x2 = lane64 >> 4;
+    const int ibase = bm * IM + x2 * TS + x0; // block (ib, jb) of the image at ibase + 4 ib TS + 4 jb
+    int jbase[NBC];                           // block (kb, jb) of J^T at jbase[jb] + 4 kb: J[4 jb + x0][4 kb + x2]
+#pragma unroll
+    for (int jb = 0; jb < NBC; ++jb) jbase[jb] = bm * JM + (4 * jb + x0 < n ? 4 * jb + x0 : n) * JR + x2;
+    double npp[NBR][NBC], qb[NBR], msk[NBR]; // -(pp o .) factors, diagonal of Q, "column n" mask, in block layout
+    {
+        long ib_ = inst0 + bm;
+        if (ib_ > a.B - 1) ib_ = a.B - 1;
+        const double *ph = a.phi + ib_ * n, *qq = a.q + ib_ * n;
+#pragma unroll
+        for (int ib = 0; ib < NBR; ++ib) {
+            const int row = 4 * ib + x2;
+            const bool rv = row < n;
+            const double ph_row = ph[rv ? row : 0];
+#pragma unroll
+            for (int jb = 0; jb < NBC; ++jb) {
+                const int col = 4 * jb + x0;
+                const double ph_col = col < n ? ph[col] : (col == n ? 1.0 : 0.0); // column n: Xp[t+1] = Phi F[t]
+                npp[ib][jb] = rv ? -(ph_row * ph_col) : 0.0;
+            }
+            qb[ib] = (rv && x2 == x0) ? qq[row] : 0.0;
+            msk[ib] = (rv && x0 == n % 4) ? 1.0 : 0.0;
+        }
+    }
+
+    const typename BL::Map rmap = BL::make_map(lane64, inst0, a.B, a.bs);
+    typename RIO::chunk_t prer[PER]; // chunks of the next filtered record
+    for (int i = lane64; i < BL::WAVE; i += 64) imgL[i] = 0.0; // tile padding, J padding, the zero slots
+
+    const double *recF = a.F + (T - 1) * rstep;            // record array positioned at the step being fetched
+    double *recS = a.S ? a.S + (T - 1) * rstep : nullptr; // smoothed records are optional when projecting
+    const long rec_id = inst % a.R;
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K], pscale = 1.0, poffset = 0.0;
+    double *pM = nullptr, *pV = nullptr;
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
+        if (a.scale) pscale = a.scale[rec_id * N + jr];
+        if (a.offset) poffset = a.offset[rec_id * N + jr];
+        const long pidx = (inst * a.bs + (T - 1) * a.ts) * N + jr;
+        pM = a.sim_means ? a.sim_means + pidx : nullptr;
+        pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
+    }
+    double *sM = nullptr, *sV = nullptr; // VAR: state means / variances [., n]
+    if constexpr (VAR) {
+        const long sidx = (inst * a.bs + (T - 1) * a.ts) * n + r;
+        sM = a.state_means + sidx;
+        sV = a.state_vars + sidx;
+    }
+
+    auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < PER; ++m) prer[m] = *reinterpret_cast<const typename RIO::chunk_t *>(recF + rmap.off[m]);
+        recF -= rstep;
+    };
+    auto to_image = [&]() __attribute__((always_inline)) { // chunks -> load image (tile layout)
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            imgL[rmap.l0[m]] = prer[m].x;
+            imgL[rmap.l1[m]] = prer[m].y;
+            if constexpr (SYM) { // mirror of an off-diagonal element; means and diagonals rewrite themselves
+                imgL[rmap.m0[m]] = prer[m].x;
+                imgL[rmap.m1[m]] = prer[m].y;
+            }
+        }
+        wave_lds_sync();
+    };
+    // `img` holds the smoothed moments of this step: emit the record, run the epilogues
+    auto store = [&](const double *img) __attribute__((always_inline)) {
+        wave_lds_sync();
+        if (recS) {
+            typename RIO::chunk_t tmp[PER];
+#pragma unroll
+            for (int m = 0; m < PER; ++m) tmp[m] = typename RIO::chunk_t{img[rmap.s0[m]], img[rmap.s1[m]]};
+#pragma unroll
+            for (int m = 0; m < PER; ++m) *reinterpret_cast<typename RIO::chunk_t *>(recS + rmap.off[m]) = tmp[m];
+            recS -= rstep;
+        }
+        if constexpr (PROJ || VAR) {
+            double row[n];
+            const double xv = img[gw * IM + r * TS + n];
+            load_row<n>(img + gw * IM + r * TS, row);
+            if constexpr (PROJ) {
+                double mean, var;
+                project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
+                if (lane < N && live) { // factor rows hold other values: mask (one exec region per step)
+                    if (pM) *pM = mean;
+                    if (pV) *pV = var;
+                }
+                if (pM) pM -= a.ts * N;
+                if (pV) pV -= a.ts * N;
+            }
+            if constexpr (VAR) {
+                double diag = 0.0;
+                sfor<0, n>(MK_LAMBDA(c) { diag = (decltype(c)::value == lane) ? row[decltype(c)::value] : diag; });
+                if (lane < n && live) {
+                    *sM = xv;
+                    *sV = diag;
+                }
+                sM -= a.ts * n;
+                sV -= a.ts * n;
+            }
+        }
+    };
+
+    // last step: smoothed = filtered (:450-451): the load image as it stands
+    double Ps[NBR][NBC];
+    issue();
+    to_image();
+#pragma unroll
+    for (int ib = 0; ib < NBR; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < NBC; ++jb) Ps[ib][jb] = imgL[ibase + 4 * ib * TS + 4 * jb];
+    store(imgL);
+    double pivmin = 1.0;
+
+    // Software pipeline: at the top of iteration t the load image holds record t, row r of Pf[t] is in registers and
+    // the chunks of record t-1 are in flight; they are consumed (image, row) at the END of the iteration, after the
+    // image's last reader and BEFORE this iteration's stores are issued (loads and stores share vmcnt).
+    double Pfc[n];
+    if (T >= 2) {
+        issue();
+        to_image();
+        load_row<n>(imgL + gw * IM + r * TS, Pfc);
+        if (T >= 3) issue();
+    }
+    for (long t = T - 2; t >= 0; --t) {
+        // ======== row mapping: J[t] = Pf Phi^T Pp[t+1]^-1 (:453-460) ========
+        {
+            double A[n], zz[n];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                zz[c] = Pfc[c] * phic[c]; // W = Pf Phi, the right-hand side of the solve
+                A[c] = fma(phi_r, zz[c], qd[c]); // Pp[t+1] = Phi Pf Phi + Q (row r)
+            }
+            dpp_guard(A); // A is compiler-produced (build-time hazard check)
+            double dinv[n];
+            ldlt_factor<n, G, false>(A, dinv, pivmin);
+            if (__builtin_expect(__ballot(!(pivmin > 0.0)) != 0ull, 0)) { // a null direction (cold): pinv-like redo
+#pragma unroll
+                for (int c = 0; c < n; ++c) A[c] = fma(phi_r, Pfc[c] * phic[c], qd[c]);
+                dpp_guard(A);
+                ldlt_factor<n, G, true>(A, dinv, pivmin);
+            }
+            sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
+                constexpr int k = decltype(kc)::value;
+                Gp::template axpy_col<k + 1, n, true, n>(zz, A[k], zz[k]);
+            });
+#pragma unroll
+            for (int c = 0; c < n; ++c) zz[c] *= dinv[c]; // D^{-1}
+            sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y;  z[c] -= L(k,c) z_k, L(k,c) lives in lane k
+                constexpr int k = decltype(kc)::value;
+                Gp::template axpy_lane<k, 0, k, true, n>(zz, A, zz[k]);
+            });
+            store_row<n>(jar + gw * JM + r * JR, zz); // row r of J[t]
+        }
+        wave_lds_sync();
+        // ======== block mapping: the recursion (:461-474) on 4x4 blocks ========
+        {
+            double JT[NBR][NBC], D[NBR][NBC], acc[NBR][NBC], out[NBR][NBC];
+#pragma unroll
+            for (int ib = 0; ib < NBR; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < NBC; ++jb) {
+                    out[ib][jb] = imgL[ibase + 4 * ib * TS + 4 * jb]; // Pf~ block: the accumulator of product 2
+                    JT[ib][jb] = jar[jbase[jb] + 4 * ib];
+                }
+            // D~ = Ps~[t+1] - Pp~[t+1]; column n: S[t+1] - Xp[t+1]
+#pragma unroll
+            for (int ib = 0; ib < NBR; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < NBC; ++jb) {
+                    const double d = fma(npp[ib][jb], out[ib][jb], Ps[ib][jb]);
+                    D[ib][jb] = jb == ib ? d - qb[ib] : d;
+                    acc[ib][jb] = jb == n / 4 ? D[ib][jb] * msk[ib] : 0.0; // D~'s column n passes through product 1
+                }
+            // V^T (ib, jb) (+)= sum_kb D(ib, kb) J^T(kb, jb): the A operand D(ib, kb) is the block D[kb][ib] (transposed by
+            // the operand layout, D symmetric)
+#pragma unroll
+            for (int kb = 0; kb < NBR; ++kb)
+#pragma unroll
+                for (int ib = 0; ib < NBR; ++ib)
+#pragma unroll
+                    for (int jb = 0; jb < NBC; ++jb)
+                        acc[ib][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(D[kb][ib], JT[kb][jb], acc[ib][jb], 0, 0, 0);
+            // Ps~(ib, jb) = Pf~(ib, jb) + sum_kb J(ib, kb) V^T(kb, jb): the A operand J(ib, kb) is the block JT[kb][ib]
+#pragma unroll
+            for (int kb = 0; kb < NBR; ++kb)
+#pragma unroll
+                for (int ib = 0; ib < NBR; ++ib)
+#pragma unroll
+                    for (int jb = 0; jb < NBC; ++jb)
+                        out[ib][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(JT[kb][ib], acc[kb][jb], out[ib][jb], 0, 0, 0);
+#pragma unroll
+            for (int ib = 0; ib < NBR; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < NBC; ++jb) {
+                    Ps[ib][jb] = out[ib][jb];
+                    imgS[ibase + 4 * ib * TS + 4 * jb] = out[ib][jb];
+                }
+        }
+        // consume the chunks of step t-1, request those of step t-2 -- before this iteration's stores are issued
+        if (t >= 1) {
+            to_image();
+            load_row<n>(imgL + gw * IM + r * TS, Pfc);
+            if (t >= 2) issue();
+        }
+        store(imgS);
     }
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
@@ -1461,6 +1800,17 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+// n <= 15, packed records: smoother_blk_kernel (products as 4x4x4 f64 MFMA blocks) or smoother_record_kernel (all DPP).
+// MK_SMOOTHER16 = blk | record overrides the choice (A/B measurements).
+static bool smoother16_blk()
+{
+    static const int forced = [] {
+        const char *e = getenv("MK_SMOOTHER16");
+        return !e ? 0 : (!strcmp(e, "blk") ? 1 : (!strcmp(e, "record") ? 2 : 0));
+    }();
+    return forced == 1; // default: smoother_record_kernel (measured faster at every batch size)
+}
+
 template <int N, int K>
 static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
 {
@@ -1472,6 +1822,23 @@ static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
         constexpr int GPB = 256 / G;
         const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
         const int epi = (a.sim_means || a.sim_vars) ? 1 : (a.state_means ? 2 : 0);
+        if constexpr (n <= 15) {
+            if (a.rs > 0 && smoother16_blk()) {
+                const unsigned bgrid = (unsigned)((a.B + 7) / 8);
+#define MK_LAUNCH_BLK(E, S) hipLaunchKernelGGL((smoother_blk_kernel<N, K, E, S>), dim3(bgrid), dim3(128), 0, s, a)
+                if (a.sym) {
+                    if (epi == 1) MK_LAUNCH_BLK(1, true);
+                    else if (epi == 2) MK_LAUNCH_BLK(2, true);
+                    else MK_LAUNCH_BLK(0, true);
+                } else {
+                    if (epi == 1) MK_LAUNCH_BLK(1, false);
+                    else if (epi == 2) MK_LAUNCH_BLK(2, false);
+                    else MK_LAUNCH_BLK(0, false);
+                }
+#undef MK_LAUNCH_BLK
+                return hipGetLastError();
+            }
+        }
         if (a.rs > 0) {
 #define MK_LAUNCH_REC(E, S) hipLaunchKernelGGL((smoother_record_kernel<N, K, G, E, S>), dim3(grid), dim3(256), 0, s, a)
             if (a.sym) {

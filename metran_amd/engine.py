@@ -562,9 +562,19 @@ class BatchedKalman:
         return out[0]
 
     # ------------------------------------------------------------------ instrumentation
-    def enable_timing(self, enable=True):
+    def enable_timing(self, enable=True, accumulate=False):
+        """hipEvents around every hot-kernel launch.  ``accumulate``: every launch keeps its own event pair until
+        ``kernel_ms_totals`` collects them (no host synchronisation inside a timed loop); otherwise only the most
+        recent launch of each kind is kept (``last_kernel_ms``)."""
         self._timing = bool(enable)
-        check(self._L.mk_enable_timing(self._ctx, 1 if enable else 0))
+        check(self._L.mk_enable_timing(self._ctx, (2 if accumulate else 1) if enable else 0))
+
+    def kernel_ms_totals(self):
+        """(filter_ms, filter_launches, smoother_ms, smoother_launches) since the previous call (accumulate mode)."""
+        f, s = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        nf, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._L.mk_kernel_ms_totals(self._ctx, ctypes.byref(f), ctypes.byref(nf), ctypes.byref(s), ctypes.byref(ns)))
+        return float(f.value), int(nf.value), float(s.value), int(ns.value)
 
     def last_kernel_ms(self):
         """(filter_ms, smoother_ms) of the most recent launches, measured with hipEvents on the launch stream."""
