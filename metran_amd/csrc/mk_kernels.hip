@@ -512,6 +512,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 // square layout (the lanes still put / read whole rows); only the chunk maps change: a 16-byte chunk of the packed
 // record is two doubles gathered from (scattered to) two image positions, and a loaded off-diagonal element is
 // written to its mirror position as well.
+// Record traffic is a pure stream (every byte written once, read at most once by the next kernel): the 16-byte record
+// stores / loads are marked non-temporal (MK_NT_IO=0 builds the plain form; measured at configs[1] / 8192 models:
+// filter 1.44 -> 1.39 ms / 2.55 -> 2.53 ms, smoother 1.76 -> 1.73 ms / 3.2 -> 3.2 ms).
+#ifndef MK_NT_IO
+#define MK_NT_IO 1
+#endif
+template <class V>
+__device__ __forceinline__ void rec_store(V *p, V v)
+{
+#if MK_NT_IO
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <class V>
+__device__ __forceinline__ V rec_load(const V *p)
+{
+#if MK_NT_IO
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <int n, int G, bool SYM>
 struct RecordIO {
     static constexpr int NV = n + n * n;                    // payload doubles of the IMAGE (full square)
@@ -615,7 +640,7 @@ struct RecordIO {
 #pragma unroll
         for (int m = 0; m < PER; ++m) tmp[m] = gather(img, mp, m);
 #pragma unroll
-        for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base + mp.off[m]) = tmp[m];
+        for (int m = 0; m < PER; ++m) rec_store(reinterpret_cast<chunk_t *>(base + mp.off[m]), tmp[m]);
     }
     static __device__ __forceinline__ void emit2(const double *img0, double *base0, const double *img1, double *base1,
                                                  const Map &mp)
@@ -628,15 +653,15 @@ struct RecordIO {
             t1[m] = gather(img1, mp, m);
         }
 #pragma unroll
-        for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base0 + mp.off[m]) = t0[m];
+        for (int m = 0; m < PER; ++m) rec_store(reinterpret_cast<chunk_t *>(base0 + mp.off[m]), t0[m]);
 #pragma unroll
-        for (int m = 0; m < PER; ++m) *reinterpret_cast<chunk_t *>(base1 + mp.off[m]) = t1[m];
+        for (int m = 0; m < PER; ++m) rec_store(reinterpret_cast<chunk_t *>(base1 + mp.off[m]), t1[m]);
     }
     // HBM records -> registers (issued one step ahead of use)
     static __device__ __forceinline__ void load_issue(const double *base, const Map &mp, chunk_t (&buf)[PER])
     {
 #pragma unroll
-        for (int m = 0; m < PER; ++m) buf[m] = *reinterpret_cast<const chunk_t *>(base + mp.off[m]);
+        for (int m = 0; m < PER; ++m) buf[m] = rec_load(reinterpret_cast<const chunk_t *>(base + mp.off[m]));
     }
     // registers -> LDS image (the wavefront's records of one step, full-square layout)
     static __device__ __forceinline__ void to_image(double *img, const chunk_t (&buf)[PER], const Map &mp)
@@ -813,45 +838,68 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             ldlt_factor<n, G, true>(A, dinv, pivmin);
         }
 
+        // Sweeps<n>::fused (16-lane groups, n <= 10): every sweep below is ONE asm statement (mk_sweeps.h) -- written as one
+        // statement per broadcast-FMA, hipcc pads every sweep boundary with an s_nop (31 issue slots per step at n = 10)
+        constexpr bool FUSED = (G == 16) && Sweeps<n>::fused;
         // ---- lane i solves A z = W_i  (row i of J = Pf Phi^T A^{-1}, :458-460) ----
-        sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
-            constexpr int k = decltype(kc)::value;
-            Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
-        });
+        if constexpr (FUSED) {
+            Sweeps<n>::forward(z, A);
+        } else {
+            sfor<0, n>(MK_LAMBDA(kc) { // forward: L y = b;  z[c] -= L(c,k) y_k, L(c,k) lives in lane c
+                constexpr int k = decltype(kc)::value;
+                Gp::template axpy_col<k + 1, n, true, n>(z, A[k], z[k]);
+            });
+        }
 #pragma unroll
         for (int c = 0; c < n; ++c) z[c] *= dinv[c]; // D^{-1}
-        sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y;  z[c] -= L(k,c) z_k, L(k,c) lives in lane k
-            constexpr int k = decltype(kc)::value;
-            Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
-        });
+        if constexpr (FUSED) {
+            Sweeps<n>::backward(z, A);
+        } else {
+            sfor_down<0, n>(MK_LAMBDA(kc) { // backward: L^T z = y;  z[c] -= L(k,c) z_k, L(k,c) lives in lane k
+                constexpr int k = decltype(kc)::value;
+                Gp::template axpy_lane<k, 0, k, true, n>(z, A, z[k]);
+            });
+        }
         // z = J[r, :]
 
         // ---- smoothed mean (:461-464): xs[t] = F[t] + J (xs[t+1] - Phi F[t]) ----
         double acc0 = xfc, acc1 = 0.0;
-        sfor<0, n>(MK_LAMBDA(cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
-            else Gp::template fmac<c>(acc1, delta, z[c]);
-        });
+        if constexpr (FUSED) {
+            Sweeps<n>::mean(acc0, acc1, delta, z);
+        } else {
+            sfor<0, n>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c % 2 == 0) Gp::template fmac<c>(acc0, delta, z[c]);
+                else Gp::template fmac<c>(acc1, delta, z[c]);
+            });
+        }
         xs = acc0 + acc1;
 
         // ---- smoothed covariance (:465-474): Ps[t] = Pf[t] + J (Ps[t+1] - Pp[t+1]) J^T ----
         double V[n]; // V = J D (row r):  V[c] += J[r][k] * D[k][c], D[k][:] broadcast from lane k
-#pragma unroll
-        for (int c = 0; c < n; ++c) V[c] = 0.0;
         if constexpr (G == 16) dpp_guard(D); // D is compiler-produced (build-time hazard check)
-        sfor<0, n>(MK_LAMBDA(kc) {
-            constexpr int k = decltype(kc)::value;
-            Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
-        });
+        if constexpr (FUSED) {
+            Sweeps<n>::jd(V, D, z);
+        } else {
+#pragma unroll
+            for (int c = 0; c < n; ++c) V[c] = 0.0;
+            sfor<0, n>(MK_LAMBDA(kc) {
+                constexpr int k = decltype(kc)::value;
+                Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
+            });
+        }
 #pragma unroll
         for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
 
         // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
-        sfor<0, n>(MK_LAMBDA(kc) {
-            constexpr int k = decltype(kc)::value;
-            Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
-        });
+        if constexpr (FUSED) {
+            Sweeps<n>::vjt(Psn, z, V);
+        } else {
+            sfor<0, n>(MK_LAMBDA(kc) {
+                constexpr int k = decltype(kc)::value;
+                Gp::template axpy_col<0, n, false, n>(Psn, z[k], V[k]);
+            });
+        }
 
         // Consume the chunks of step t-1 (requested 1.5 iterations ago) and request those of step t-2 BEFORE
         // this iteration's stores are issued.  Loads and stores share vmcnt and complete out of order with

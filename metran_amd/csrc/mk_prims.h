@@ -160,6 +160,8 @@ struct Group<64> {
     static constexpr unsigned long long full_mask(int N) { return N >= 64 ? ~0ull : (1ull << N) - 1ull; }
 };
 
+#include "mk_sweeps.h" // Sweeps<n>: whole sweeps as single asm statements (generated, n <= 10)
+
 // value of `v` in lane `l`, l wavefront-uniform at run time (v_readlane_b32 with a scalar lane select)
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
