@@ -635,10 +635,19 @@ struct RecordIO {
     // LDS image -> HBM records of this step (base = record array + t*ts*RSO)
     static __device__ __forceinline__ void emit(const double *img, double *base, const Map &mp)
     {
-        wave_lds_sync();
         chunk_t tmp[PER];
+        gather_all(img, mp, tmp);
+        store_all(base, mp, tmp);
+    }
+    // the two halves of emit, for callers that put useful work between the LDS reads and the stores they feed
+    static __device__ __forceinline__ void gather_all(const double *img, const Map &mp, chunk_t (&tmp)[PER])
+    {
+        wave_lds_sync();
 #pragma unroll
         for (int m = 0; m < PER; ++m) tmp[m] = gather(img, mp, m);
+    }
+    static __device__ __forceinline__ void store_all(double *base, const Map &mp, const chunk_t (&tmp)[PER])
+    {
 #pragma unroll
         for (int m = 0; m < PER; ++m) rec_store(reinterpret_cast<chunk_t *>(base + mp.off[m]), tmp[m]);
     }
@@ -769,12 +778,12 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
     auto finish = [&](double &xv, double(&row)[n]) __attribute__((always_inline)) {
         RIO::load_finish(imgL, prer, rmap, gw, r, xv, row);
     };
+    // The smoothed record of a step goes into the store image at the END of its iteration and leaves it in the MIDDLE
+    // of the next one: the image's write -> read round trip and the reads' latency (~250 cycles a step, exposed with one
+    // wavefront per SIMD) hide behind the factorisation, and the stores are still a full iteration older than the next
+    // consumed load (the vmcnt rule below).
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
-        if (recS) {
-            RIO::put(imgS, gw, r, xv, row);
-            RIO::emit(imgS, recS, rmap);
-            recS -= rstep;
-        }
+        if (recS) RIO::put(imgS, gw, r, xv, row);
         if constexpr (PROJ) {
             double mean, var;
             project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
@@ -796,6 +805,7 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             sV -= a.ts * n;
         }
     };
+    typename RIO::chunk_t etmp[RIO::PER]; // chunks of the record being emitted
 
     // last step: smoothed = filtered (:450-451)
     double xs, Psn[n];
@@ -823,9 +833,12 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             z[c] = Pfc[c] * phic[c]; // W, the right-hand side of the solve
             A[c] = fma(phi_r, z[c], qd[c]);
             D[c] = Psn[c] - A[c];
+            Psn[c] = Pfc[c]; // the accumulator of the second product; row r of Pf[t] is not needed beyond this point
         }
         double delta = xs - phi_r * xfc; // xs[t+1] - Xp[t+1]; formed early so that it is "old" when DPP-read
         if constexpr (G == 16) dpp_pin(delta);
+
+        if (recS) RIO::gather_all(imgS, rmap, etmp); // the record of step t+1, put there at the end of its iteration
 
         // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
         if constexpr (G == 16) dpp_guard(A); // A is compiler-produced (build-time hazard check)
@@ -836,6 +849,20 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             for (int c = 0; c < n; ++c) A[c] = fma(phi_r, z[c], qd[c]);
             if constexpr (G == 16) dpp_guard(A);
             ldlt_factor<n, G, true>(A, dinv, pivmin);
+        }
+        // Consume the chunks of step t-1 (requested one iteration ago) and request those of step t-2 BEFORE this
+        // iteration's stores are issued.  Loads and stores share vmcnt and complete out of order with respect to each
+        // other, so the compiler waits for vmcnt(0) whenever both are pending: here every pending operation is one full
+        // iteration old.  The LDS transposition (chunks -> image -> row) has the substitutions and both products to
+        // complete in.
+        double xf_next = xfn;
+        if (t >= 1) {
+            finish(xf_next, Pfc);
+            if (t >= 2) issue(xfn);
+        }
+        if (recS) {
+            RIO::store_all(recS, rmap, etmp);
+            recS -= rstep;
         }
 
         // Sweeps<n>::fused (16-lane groups, n <= 10): every sweep below is ONE asm statement (mk_sweeps.h) -- written as one
@@ -888,9 +915,6 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
                 Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
             });
         }
-#pragma unroll
-        for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
-
         // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
         if constexpr (FUSED) {
             Sweeps<n>::vjt(Psn, z, V);
@@ -901,20 +925,10 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             });
         }
 
-        // Consume the chunks of step t-1 (requested 1.5 iterations ago) and request those of step t-2 BEFORE
-        // this iteration's stores are issued.  Loads and stores share vmcnt and complete out of order with
-        // respect to each other, so the compiler waits for vmcnt(0) whenever both are pending: consumed in
-        // mid-iteration (as before) that drained the stores issued half an iteration earlier; here every
-        // pending operation is at least one full iteration old.
-        double xf_next = xfn;
-        if (t >= 1) {
-            finish(xf_next, Pfc);
-            if (t >= 2) issue(xfn);
-        }
-
         store(xs, Psn);
         xfc = xf_next;
     }
+    if (recS) RIO::emit(imgS, recS, rmap); // the record of step 0 (T = 1: of the only step)
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
