@@ -243,8 +243,8 @@ def main():
     B, N, K, T, missing, mode = CONFIGS[args.config]
     B = args.batch or B
     T = args.T or T
-    steps = args.steps if args.steps is not None else (10 if mode == "full" else 3)
-    warmup = args.warmup if args.warmup is not None else (3 if mode == "full" else 1)
+    steps = args.steps if args.steps is not None else (50 if mode == "full" else 3)
+    warmup = args.warmup if args.warmup is not None else (10 if mode == "full" else 1)
 
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: one rank per GPU

@@ -10,8 +10,10 @@ CFGS="${@:-c2 c2sym c3 c3sym c4 c5}"
 for tag in $CFGS; do
   cfg=${tag%sym}; symflag=""; sym=0
   if [ "$tag" != "$cfg" ]; then symflag="--packed-sym"; sym=1; fi
-  steps=12; [ $cfg = c4 ] && steps=2; [ $cfg = c5 ] && steps=2
-  CMD="python $GRAFT_REPO_ROOT/bench.py --config $cfg $symflag --steps $steps --warmup 1 --no-cpu-baseline"
+  # the default bench.py run of each configuration (c2/c3: 50 timed + 10 warm-up steps -- the GPU needs ~10 launches after
+  # idling to reach its steady clocks, scripts/probe_ramp.py; the kernel-trace averages include those warm-up launches)
+  steps=50; warm=10; [ $cfg = c4 ] && steps=3 && warm=1; [ $cfg = c5 ] && steps=3 && warm=1
+  CMD="python $GRAFT_REPO_ROOT/bench.py --config $cfg $symflag --steps $steps --warmup $warm --no-cpu-baseline"
   cd /tmp
   rm -rf /tmp/kt /tmp/pf /tmp/pw
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $CMD > $OUT/${tag}_bench_under_rocprof.json 2> $OUT/${tag}_kt.err
