@@ -440,10 +440,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sfor_down<1, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value + 1; // n-1 .. 1
             const double zk = z[k];
-            sfor<0, k>(MK_LAMBDA(c2) {
-                constexpr int c = decltype(c2)::value;
-                z[c] = fma(-Gp::template bcast<k>(A[c]), zk, z[c]);
-            });
+            // batches of readlane pairs ahead of their multiply-adds (Group<64>::axpy_lane): one pair straight before its
+            // FMA costs an `s_nop 1` each (630 a step at n = 36; 113 -> 109 ms at configs[3]).  Rows of L written back to
+            // LDS and read at wavefront-uniform addresses instead (1 260 readlanes -> 190 LDS operations) measured the same.
+            Gp::template axpy_lane<k, 0, k, true, n>(z, A, zk);
         });
         // z = J[r, :]
         // smoothed mean (:461-464): xs[t] = F[t] + J delta, delta from LDS (uniform reads)
