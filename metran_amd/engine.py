@@ -244,6 +244,20 @@ class BatchedKalman:
             self.obsvar = None
         return self
 
+    def subset(self, index):
+        """A new engine holding the records ``index`` (1-D integer tensor / array of record numbers) of this one: the
+        observations, loadings and observation variances are gathered on the device (what ``calibrate_batch`` does when
+        most of its models have converged: the remaining iterations run on the still-active records only)."""
+        torch = _torch()
+        index = torch.as_tensor(index, dtype=torch.long, device=self.device)
+        sub = BatchedKalman(self.device.index, layout="time_major" if self.time_major else "model_major",
+                            packed_sym=self.packed_sym)
+        sub.set_observations(self.obs[index])
+        sub.set_loadings(self.loadings[index], None if self.obsvar is None else self.obsvar[index])
+        if self.scale is not None:
+            sub.scale, sub.offset = self.scale[index].contiguous(), self.offset[index].contiguous()
+        return sub
+
     @property
     def n(self):
         return self.N + self.K
