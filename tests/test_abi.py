@@ -113,3 +113,20 @@ def test_shape_module_builds_and_passes_hazard_check(tmp_path, monkeypatch):
     monkeypatch.setenv("METRAN_HIP_JIT", "0")
     with pytest.raises(jit.MetranHipError):
         jit.build_shape_module(6, 3)
+
+
+def test_generated_sweeps_header_is_current():
+    """metran_amd/csrc/mk_sweeps.h is generated (scripts/gen_sweeps.py) and committed: the committed file must be what
+    the generator writes, and every statement must respect the 30-operand limit of an asm statement ("+v" counts twice)."""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("gen_sweeps", os.path.join(ROOT, "scripts", "gen_sweeps.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.render()
+    assert open(os.path.join(ROOT, "metran_amd", "csrc", "mk_sweeps.h")).read() == text
+    for stmt in re.findall(r"asm volatile\((.*?)\);", text, flags=re.S):
+        outs, ins = stmt.split("\n            : ")[1:3] if stmt.count("\n            : ") >= 2 else (stmt.split("\n            : ")[1], "")
+        n_ops = 2 * outs.count('"+v"') + outs.count('"=&v"') + ins.count('"v"')
+        assert 0 < n_ops <= 30, (n_ops, stmt[:120])

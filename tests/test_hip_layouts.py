@@ -142,3 +142,25 @@ def test_raw_c_abi_without_torch():
     np.testing.assert_allclose(host["smooth"][..., :n], ref["S"], atol=1e-9)
     np.testing.assert_allclose(host["smooth"][..., n:nv], ref["Ps"][..., iu[0], iu[1]], atol=1e-9)
     assert not host["smooth"][..., nv:].any()    # pad doubles are written as zeros (whole cache lines)
+
+
+def test_accumulating_kernel_timing():
+    """mk_enable_timing(ctx, 2) + mk_kernel_ms_totals: one hipEvent pair per launch, summed when asked (what bench.py
+    reads after its timed loop), next to the mode-1 'most recent launch' query."""
+    from metran_amd.engine import BatchedKalman
+
+    d = make_dfm_batch(64, 8, 2, 200, seed=5, missing=0.1)
+    kf = BatchedKalman()
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    kf.enable_timing(True, accumulate=True)
+    for _ in range(3):
+        kf.filter_smooth(d["phi"], d["q"])
+    kf.loglik(d["phi"], d["q"])
+    f_ms, f_n, s_ms, s_n = kf.kernel_ms_totals()
+    assert (f_n, s_n) == (4, 3) and 0.0 < f_ms < 100.0 and 0.0 < s_ms < 100.0
+    assert kf.kernel_ms_totals() == (0.0, 0, 0.0, 0)          # collected pairs are recycled
+    kf.enable_timing(True)                                    # mode 1: the most recent launch of each kind
+    kf.filter_smooth(d["phi"], d["q"])
+    f1, s1 = kf.last_kernel_ms()
+    assert 0.0 < f1 < 100.0 and 0.0 < s1 < 100.0
+    kf.enable_timing(False)
