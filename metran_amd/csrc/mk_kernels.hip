@@ -6,7 +6,9 @@
 // model per DPP row; cross-lane traffic is `row_newbcast` DPP, no LDS, no barriers);
 // G = 64 gives one model per wavefront (cross-lane traffic is v_readlane).
 // The time recursion is sequential per model; parallelism comes from the batch.
-// No MFMA: n is tiny and the path is bound by HBM traffic of the state outputs.
+// No MFMA in the default kernels: n is tiny, the broadcast-FMA count is the floor of this mapping and the f64 vector
+// pipe -- not HBM, not issue -- is what bounds them; smoother_blk_kernel (opt-in) runs the two
+// n^3 products of the smoother as 4x4x4 f64 MFMA blocks and measures slower.
 //
 // Reference semantics restated here (file:line in /root/reference):
 //   filter_kernel   : seqkalmanfilter  metran/kalmanfilter.py:236-400  + get_mle :550-567
