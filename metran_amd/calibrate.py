@@ -31,7 +31,7 @@ class CalibrationResult(dict):
 
 def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
                     ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto",
-                    stderr=False, compact=0.5, compact_min=256):
+                    stderr=False, compact=0.5, compact_min=256, fd_below=0):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
@@ -45,6 +45,10 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     models are fewer than ``compact`` x the models in flight (and more than ``compact_min`` are in flight), the active
     records are gathered into a smaller engine (``BatchedKalman.subset``) and the iteration continues on those.
     Every model sees exactly the iterates it would have seen without it.  0 disables.
+    ``fd_below``: with the adjoint gradient, switch to forward differences once (n+1) x the models in flight fit in
+    ``fd_below`` instances (0 = never).  A handful of stragglers is latency-bound: one objective launch over (n+1) R
+    instances takes as long as one over R, the forward + backward pair of the adjoint 4-5 times as long; the price is
+    the differencing error in the last iterations (what scipy's L-BFGS-B works with throughout).
     """
     import torch
 
@@ -112,6 +116,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
             S, Y, rho = [t[keep] for t in S], [t[keep] for t in Y], [t[keep] for t in rho]
             R = n_act
             active = torch.ones(R, dtype=torch.bool, device=dev)
+        if gradient == "adjoint" and fd_below and (n + 1) * R <= fd_below:
+            gradient = "fd"
         # two-loop recursion, all models at once
         qv = pg.clone()
         al = []

@@ -23,6 +23,8 @@ ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--batch", type=int, default=8192, help="models per GPU")
 ap.add_argument("--T", type=int, default=1000)
 ap.add_argument("--maxiter", type=int, default=200)
+ap.add_argument("--fd-below", type=int, default=4096,
+                help="switch from the adjoint gradient to batched forward differences once (n+1) x active models <= this (0: never)")
 a = ap.parse_args()
 
 if a.gpus > 1 and "RANK" not in os.environ:
@@ -54,7 +56,7 @@ torch.cuda.synchronize()
 if world > 1:
     torch.distributed.barrier()
 t0 = time.perf_counter()
-res = calibrate_sharded(total, lambda lo_, hi_: kf, maxiter=a.maxiter)  # this rank's engine holds exactly [lo, hi)
+res = calibrate_sharded(total, lambda lo_, hi_: kf, maxiter=a.maxiter, fd_below=a.fd_below)  # this rank's engine holds exactly [lo, hi)
 torch.cuda.synchronize()
 if world > 1:
     torch.distributed.barrier()
@@ -69,6 +71,7 @@ ok_local = (res.obj[lo:hi] <= true_obj + 1e-6).double().mean()
 if rank == 0:
     print(json.dumps({"workload": "calibrate_sharded: %d x (8 series, 2 factors) per GPU on %d GPU(s), T=%d, fp64" % (a.batch, world, a.T),
                       "n_gpus": world, "models": int(res.alpha.shape[0]), "seconds": dt, "models_per_s": total / dt,
+                      "gradient": "adjoint" + (", forward differences once (n+1) x active models <= %d" % a.fd_below if a.fd_below else ""),
                       "iterations_rank0": int(res.nit), "nfev_all_ranks": int(nfev.item()), "evals_per_s": float(nfev.item()) / dt,
                       "converged_frac": float(res.converged.double().mean()),
                       "rank0_frac_at_or_below_true_parameter_objective": float(ok_local),

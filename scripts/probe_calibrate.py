@@ -14,7 +14,8 @@ calibrate_batch(kf, maxiter=2)
 torch.cuda.synchronize()
 kf.enable_timing(True, accumulate=True)
 t0 = time.perf_counter()
-res = calibrate_batch(kf, maxiter=200, verbose=True)
+res = calibrate_batch(kf, maxiter=200, verbose=bool(int(os.environ.get("VERBOSE", "0"))), fd_below=int(os.environ.get("FD_BELOW", "0")))
+print("frac at or below the generating parameters objective: %.4f; converged %.4f; median pgnorm %.2e" % (float((res.obj <= kf.loglik(d["phi"], d["q"]) + 1e-6).double().mean()), float(res.converged.double().mean()), float(res.pgnorm.median())))
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 f, nf, s, ns = kf.kernel_ms_totals()
