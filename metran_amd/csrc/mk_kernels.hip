@@ -780,12 +780,22 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
     auto finish = [&](double &xv, double(&row)[n]) __attribute__((always_inline)) {
         RIO::load_finish(imgL, prer, rmap, gw, r, xv, row);
     };
-    // The smoothed record of a step goes into the store image at the END of its iteration and leaves it in the MIDDLE
-    // of the next one: the image's write -> read round trip and the reads' latency (~250 cycles a step, exposed with one
-    // wavefront per SIMD) hide behind the factorisation, and the stores are still a full iteration older than the next
-    // consumed load (the vmcnt rule below).
+    // DEFER (records only, EPI = 0 -- the full-output path): the smoothed record of a step goes into the store image at
+    // the END of its iteration and leaves it in the MIDDLE of the next one, and the next filtered record is transposed
+    // through LDS right after the factorisation: the images' write -> read round trips and the reads' latency (~250 cycles
+    // a step each, exposed with one wavefront per SIMD) hide behind VALU work, and the stores are still a full iteration
+    // older than the next consumed load (the vmcnt rule below).  With an epilogue (projection / variances) the extra
+    // live registers of that schedule cost more than the hidden latency is worth (measured: 1.56 -> 1.63 ms): those
+    // variants emit at the end of the iteration.
+    constexpr bool DEFER = (EPI == 0);
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
-        if (recS) RIO::put(imgS, gw, r, xv, row);
+        if (recS) {
+            RIO::put(imgS, gw, r, xv, row);
+            if constexpr (!DEFER) {
+                RIO::emit(imgS, recS, rmap);
+                recS -= rstep;
+            }
+        }
         if constexpr (PROJ) {
             double mean, var;
             project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
@@ -835,12 +845,13 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             z[c] = Pfc[c] * phic[c]; // W, the right-hand side of the solve
             A[c] = fma(phi_r, z[c], qd[c]);
             D[c] = Psn[c] - A[c];
-            Psn[c] = Pfc[c]; // the accumulator of the second product; row r of Pf[t] is not needed beyond this point
+            if constexpr (DEFER) Psn[c] = Pfc[c]; // the accumulator of the second product; Pfc is refilled in mid-iteration
         }
         double delta = xs - phi_r * xfc; // xs[t+1] - Xp[t+1]; formed early so that it is "old" when DPP-read
         if constexpr (G == 16) dpp_pin(delta);
 
-        if (recS) RIO::gather_all(imgS, rmap, etmp); // the record of step t+1, put there at the end of its iteration
+        if constexpr (DEFER)
+            if (recS) RIO::gather_all(imgS, rmap, etmp); // the record of step t+1, put there at the end of its iteration
 
         // ---- A = L D L^T, right-looking; lane c ends up holding L(c, j) in A[j] for j < c ----
         if constexpr (G == 16) dpp_guard(A); // A is compiler-produced (build-time hazard check)
@@ -858,13 +869,15 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
         // iteration old.  The LDS transposition (chunks -> image -> row) has the substitutions and both products to
         // complete in.
         double xf_next = xfn;
-        if (t >= 1) {
-            finish(xf_next, Pfc);
-            if (t >= 2) issue(xfn);
-        }
-        if (recS) {
-            RIO::store_all(recS, rmap, etmp);
-            recS -= rstep;
+        if constexpr (DEFER) {
+            if (t >= 1) {
+                finish(xf_next, Pfc);
+                if (t >= 2) issue(xfn);
+            }
+            if (recS) {
+                RIO::store_all(recS, rmap, etmp);
+                recS -= rstep;
+            }
         }
 
         // Sweeps<n>::fused (16-lane groups, n <= 10): every sweep below is ONE asm statement (mk_sweeps.h) -- written as one
@@ -917,6 +930,10 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
                 Gp::template axpy_lane<k, 0, n, false, n>(V, D, z[k]);
             });
         }
+        if constexpr (!DEFER) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) Psn[c] = Pfc[c];
+        }
         // Ps[r][c] = Pf[r][c] + sum_k V[r][k] J[c][k], J[c][k] broadcast from lane c
         if constexpr (FUSED) {
             Sweeps<n>::vjt(Psn, z, V);
@@ -927,10 +944,17 @@ __global__ void __launch_bounds__(256) smoother_record_kernel(SmootherArgs a)
             });
         }
 
+        if constexpr (!DEFER) { // consume the prefetched record BEFORE this iteration's stores are issued (vmcnt)
+            if (t >= 1) {
+                finish(xf_next, Pfc);
+                if (t >= 2) issue(xfn);
+            }
+        }
         store(xs, Psn);
         xfc = xf_next;
     }
-    if (recS) RIO::emit(imgS, recS, rmap); // the record of step 0 (T = 1: of the only step)
+    if constexpr (DEFER)
+        if (recS) RIO::emit(imgS, recS, rmap); // the record of step 0 (T = 1: of the only step)
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
