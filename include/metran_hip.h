@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define MK_API __attribute__((visibility("default")))
-#define MK_ABI_VERSION 2
+#define MK_ABI_VERSION 3
 
 typedef enum mk_status {
     MK_OK = 0,
@@ -271,10 +271,14 @@ MK_API int mk_fa_analyse(mk_context *ctx, int64_t B, int64_t N, int64_t maxfacto
                          double *d_psi0, uint32_t *d_status);
 /* _minresfun (:315-347), _minresgrad (:349-373) and _get_loadings (:375-401) for B vectors d_psi [B,N];
  * instance b uses correlation matrix and factor count b % R.  d_fval [B], d_grad [B,N], d_loadings [B,N,KMAX]
- * (columns >= nfactors zero); any output may be NULL. */
+ * (columns >= nfactors zero); any output may be NULL.
+ * d_order [B,KMAX] (may be NULL): _get_loadings takes eigvec[:, :nf] in the order numpy.linalg.eig (LAPACK dgeev)
+ * returns the pairs of psi^-1/2 S psi^-1/2 (:396-398), which is NOT sorted; d_order[b][f] is the rank (0 = largest
+ * eigenvalue, < N) of the pair that becomes column f of instance b.  NULL = ranks 0 .. nf-1 (the nf largest,
+ * descending).  The jacobian depends on it through the loadings; the objective does not. */
 MK_API int mk_fa_minres(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t KMAX, const double *d_corr,
-                        const int64_t *d_nfactors, const double *d_psi, double *d_fval, double *d_grad,
-                        double *d_loadings);
+                        const int64_t *d_nfactors, const double *d_psi, const int64_t *d_order, double *d_fval,
+                        double *d_grad, double *d_loadings);
 /* Communality normalisation + varimax rotation (_rotate, :121-171; gamma = 1, maxiter = 20, tol = 1e-6 in the
  * reference) + sign convention of FactorAnalysis.solve (:84-108), in place on d_loadings [B,N,KMAX]. */
 MK_API int mk_fa_rotate(mk_context *ctx, int64_t B, int64_t N, int64_t KMAX, const int64_t *d_nfactors,

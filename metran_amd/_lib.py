@@ -111,7 +111,7 @@ API = {
     "mk_fa_analyse": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "mk_fa_minres": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_void_p]),
+                             c_void_p, c_void_p]),
     "mk_fa_rotate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double, c_int, c_double]),
     "mk_fa_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mk_enable_timing": (c_int, [c_void_p, c_int]),
@@ -119,6 +119,7 @@ API = {
     "mk_kernel_ms_totals": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
 }
 
+ABI_VERSION = 3  # MK_ABI_VERSION of include/metran_hip.h
 _lib = None
 
 
@@ -148,8 +149,8 @@ def lib():
             raise MetranHipError("%s does not export %s (stale build?)" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if L.mk_abi_version() != 2:
-        raise MetranHipError("ABI version mismatch: library %d, binding 2" % L.mk_abi_version())
+    if L.mk_abi_version() != ABI_VERSION:
+        raise MetranHipError("ABI version mismatch: library %d, binding %d" % (L.mk_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

@@ -712,13 +712,14 @@ MK_API int mk_fa_analyse(mk_context *ctx, int64_t B, int64_t N, int64_t maxfacto
 }
 
 MK_API int mk_fa_minres(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t KMAX, const double *corr,
-                        const int64_t *nfactors, const double *psi, double *fval, double *grad, double *loadings)
+                        const int64_t *nfactors, const double *psi, const int64_t *order, double *fval, double *grad,
+                        double *loadings)
 {
     MK_CTX(ctx);
     if (B <= 0 || R <= 0 || R > B || N < 2 || N > 64 || KMAX < 1 || KMAX > N || !corr || !nfactors || !psi)
         return fail(MK_ERR_INVALID, "mk_fa_minres: bad argument (2 <= N <= 64, 1 <= KMAX <= N)");
-    MK_HIP(mk::launch_fa_minres(B, R, (int)N, (int)KMAX, corr, (const long long *)nfactors, psi, fval, grad, loadings,
-                                ctx->stream));
+    MK_HIP(mk::launch_fa_minres(B, R, (int)N, (int)KMAX, corr, (const long long *)nfactors, psi, (const long long *)order,
+                                fval, grad, loadings, ctx->stream));
     return MK_OK;
 }
 

@@ -280,12 +280,18 @@ __global__ void __launch_bounds__(64) fa_analyse_kernel(long B, int N, long maxf
 // matrix b % R and its factor count).  Restated exactly as the reference has them -- including that the
 // OBJECTIVE (:334-347) builds its model from the nf SMALLEST eigenpairs of S with diagonal 1 - psi (numpy.eigh
 // is ascending and the code takes [:nf]) while the JACOBIAN (:370-372) is that of the proper minres fit,
-// diag(L L^T + diag(psi) - S) / psi^2 with L from the nf LARGEST eigenpairs of psi^-1/2 S psi^-1/2 (:396-400).
+// diag(L L^T + diag(psi) - S) / psi^2 with L = _get_loadings(psi) (:396-400).
+// _get_loadings takes eigvec[:, :nf] of numpy.linalg.eig(psi^-1/2 S psi^-1/2) -- LAPACK dgeev's order, which is NOT
+// sorted (for a quarter of 20- and 32-series two-factor models the first nf pairs are not the nf largest).  Which
+// pairs those are is an INPUT here: order [B,KMAX], the rank (0 = largest eigenvalue) of the pair that becomes
+// column f; the host obtains it from the very routine the reference calls (metran_amd/factoranalysis.py::
+// eig_order), the arithmetic stays here.  order == nullptr: ranks 0 .. nf-1 (the nf largest, descending).
 // loadings [B,N,KMAX], columns >= nf zero.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) fa_minres_kernel(long B, long R, int N, int KMAX, const double *corr,
-                                                       const long long *nfact, const double *psi, double *fval,
-                                                       double *grad, double *loadings)
+                                                       const long long *nfact, const double *psi,
+                                                       const long long *order, double *fval, double *grad,
+                                                       double *loadings)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = N, lane = threadIdx.x;
@@ -296,7 +302,7 @@ __global__ void __launch_bounds__(64) fa_minres_kernel(long B, long R, int N, in
     const double *ps = psi + b * n;
     long nf = nfact[rec];
     if (nf > KMAX) nf = KMAX;
-    // ---- _get_loadings: eig of sstar = psi^-1/2 S psi^-1/2, nf largest ----
+    // ---- _get_loadings: eig of sstar = psi^-1/2 S psi^-1/2, the pairs of rank order[b][0 .. nf-1] ----
     for (int i = lane; i < n * n; i += 64) A[i] = S[i] / sqrt(ps[i / n] * ps[i % n]);
     wsync();
     jacobi_eigh(A, V, n, lane);
@@ -306,7 +312,9 @@ __global__ void __launch_bounds__(64) fa_minres_kernel(long B, long R, int N, in
         const int row = i / KMAX, f = i % KMAX;
         double v = 0.0;
         if (f < nf) {
-            const int col = perm[f];
+            long rk = order ? order[b * KMAX + f] : f;
+            if (rk < 0 || rk >= n) rk = f; // never index outside perm; the C ABI documents the valid range
+            const int col = perm[rk];
             const double ev = A[col * n + col] - 1.0;
             v = sqrt(ps[row]) * V[row * n + col] * sqrt(ev > 0.0 ? ev : 0.0);
         }
@@ -483,11 +491,11 @@ hipError_t launch_fa_analyse(long B, int N, long maxfactors, const double *corr,
     return hipGetLastError();
 }
 hipError_t launch_fa_minres(long B, long R, int N, int KMAX, const double *corr, const long long *nfact, const double *psi,
-                            double *fval, double *grad, double *loadings, hipStream_t s)
+                            const long long *order, double *fval, double *grad, double *loadings, hipStream_t s)
 {
     const size_t sh = sizeof(double) * (2 * N * N + N + N * KMAX) + sizeof(int) * N + 16;
-    hipLaunchKernelGGL(fa_minres_kernel, dim3((unsigned)B), dim3(64), sh, s, B, R, N, KMAX, corr, nfact, psi, fval, grad,
-                       loadings);
+    hipLaunchKernelGGL(fa_minres_kernel, dim3((unsigned)B), dim3(64), sh, s, B, R, N, KMAX, corr, nfact, psi, order, fval,
+                       grad, loadings);
     return hipGetLastError();
 }
 hipError_t launch_fa_rotate(long B, int N, int KMAX, const long long *nfact, double *loadings, double gamma, int maxiter,

@@ -101,7 +101,7 @@ hipError_t launch_fa_corr(long R, long T, int N, int time_major, const double *o
 hipError_t launch_fa_analyse(long B, int N, long maxfactors, const double *corr, double *eigval, long long *nfact,
                              long long *nfact_map, long long *nfact_map4, double *psi0, unsigned *status, hipStream_t s);
 hipError_t launch_fa_minres(long B, long R, int N, int KMAX, const double *corr, const long long *nfact, const double *psi,
-                            double *fval, double *grad, double *loadings, hipStream_t s);
+                            const long long *order, double *fval, double *grad, double *loadings, hipStream_t s);
 hipError_t launch_fa_rotate(long B, int N, int KMAX, const long long *nfact, double *loadings, double gamma, int maxiter,
                             double tol, hipStream_t s);
 hipError_t launch_fa_eigh(long B, int N, const double *sym, double *val, double *vec, hipStream_t s);

@@ -21,12 +21,22 @@ and 4 of the 6 synthetic models of tests/golden/factor_analysis.npz.  The loadin
 and must fail the sufficient-decrease test at each.  A model that does not stall (the seeded notebook model ``g2`` and
 ``s6k1`` of the fixture) is handed to the SAME scipy routine on the host, objective and jacobian evaluated by the
 kernels, so that it follows the reference's iteration path there too (host-driven scipy with device objectives is how
-``HipSolve`` works as well).  ``_get_loadings`` takes ``eigvec[:, :nf]`` of LAPACK's UNSORTED ``eig`` (:396-398); the
-kernels take the nf largest pairs, which is what ``eig`` returns first for every fixture (and for 95 % of random
-matrices); where it does not, the reference's loadings are those of a non-dominant eigenvector and are not reproduced.
+``HipSolve`` works as well); all models that may move run in LOCK-STEP: one scipy minimisation per model on its own
+host thread, the objective/jacobian requests of every model still running served by ONE ``mk_fa_minres`` launch per
+step (``_lockstep_minres``).  The stall check has a safety band: a model whose best trial point comes within a factor
+1000 of the sufficient-decrease threshold is treated as moving (over 300 random models the ratio is <= 1e-12 for the
+models scipy leaves at their start vector and >= 0.07 for the others; the threshold is 1e-3, the band starts at 1e-6).
+
+``_get_loadings`` takes ``eigvec[:, :nf]`` of LAPACK's UNSORTED ``eig`` (:396-398).  For a quarter of random 20- and
+32-series models with two factors those are not the nf largest pairs, and the reference's loadings (and, through
+``_minresgrad``, its optimiser path) are then those of a non-dominant eigenvector.  The order in which a 64 x 64
+``dgeev`` deflates its eigenvalues is not something to emulate on the device: ``eig_order`` asks the very routine the
+reference calls (one batched ``numpy.linalg.eig`` on the host) for the ORDER only -- the rank of each of its first nf
+eigenvalues -- and ``mk_fa_minres`` builds the loadings from the device's own decomposition of those pairs.
 """
-import ctypes
 import logging
+import queue
+import threading
 
 import numpy as np
 
@@ -34,9 +44,32 @@ from ._lib import MetranHipError, check
 
 logger = logging.getLogger(__name__)
 
-__all__ = ["FactorAnalysisBatch", "FactorAnalysis", "FactorResult", "install", "uninstall"]
+__all__ = ["FactorAnalysisBatch", "FactorAnalysis", "FactorResult", "eig_order", "install", "uninstall"]
 
 _PSI_LO, _PSI_HI = 0.005, 1.0  # bounds of the reference's minimisation (:205-207)
+_LOCKSTEP_THREADS = 512        # scipy minimisations in flight at once (one host thread each)
+
+
+def eig_order(corr, psi, kmax):
+    """ORDER in which ``numpy.linalg.eig`` (LAPACK dgeev: the routine ``_get_loadings`` calls, :396) returns the
+    eigenpairs of ``psi^-1/2 S psi^-1/2``: ``[B,kmax]`` int64, entry f = the rank (0 = largest eigenvalue) of the
+    f-th pair returned.  ``corr [R,N,N]``, ``psi [B,N]`` host arrays; instance b uses matrix b % R.  The matrix is
+    formed exactly as the reference forms it (:394-395, products with diagonal matrices) so that the routine sees the
+    same input; only the order of its result is used (the loadings themselves are computed by ``mk_fa_minres``)."""
+    corr = np.asarray(corr, dtype=np.float64)
+    psi = np.asarray(psi, dtype=np.float64)
+    B, N = psi.shape
+    sc = 1.0 / np.sqrt(psi)
+    sstar = (corr[np.arange(B) % corr.shape[0]] * sc[:, None, :]) * sc[:, :, None]
+    out = np.tile(np.arange(kmax, dtype=np.int64), (B, 1))
+    good = np.isfinite(sstar).all(axis=(1, 2))
+    if good.any():
+        w = np.linalg.eig(sstar[good])[0].real
+        pos = np.argsort(-w, axis=1, kind="stable")
+        rank = np.empty_like(pos)
+        np.put_along_axis(rank, pos, np.broadcast_to(np.arange(N), pos.shape), axis=1)
+        out[good] = rank[:, :kmax]
+    return out
 
 
 class FactorResult(dict):
@@ -106,8 +139,13 @@ class FactorAnalysisBatch:
                    kf._p(out["status"]))
         return out
 
-    def minres_eval(self, corr, nfactors, psi, kmax, want=("f", "g", "loadings")):
-        """``(_minresfun, _minresgrad, _get_loadings)`` (:315-401) at ``psi [B,N]``; instance b uses model b % R."""
+    def minres_eval(self, corr, nfactors, psi, kmax, want=("f", "g", "loadings"), order="lapack", corr_host=None):
+        """``(_minresfun, _minresgrad, _get_loadings)`` (:315-401) at ``psi [B,N]``; instance b uses model b % R.
+
+        ``order``: which eigenpairs ``_get_loadings`` uses as its columns -- ``"lapack"`` (default): the first nf in
+        ``numpy.linalg.eig``'s order, as the reference (``eig_order``; only evaluated when the jacobian or the
+        loadings are wanted, the objective does not depend on it); ``None``: the nf largest, descending; or an
+        explicit ``[B,kmax]`` array of ranks.  ``corr_host``: a host copy of ``corr`` (saves the download)."""
         import torch
 
         kf = self.kf
@@ -117,7 +155,15 @@ class FactorAnalysisBatch:
         f = torch.empty(B, dtype=torch.float64, device=kf.device) if "f" in want else None
         g = torch.empty((B, N), dtype=torch.float64, device=kf.device) if "g" in want else None
         ld = torch.empty((B, N, kmax), dtype=torch.float64, device=kf.device) if "loadings" in want else None
-        self._call("mk_fa_minres", B, R, N, int(kmax), kf._p(corr), kf._p(nfactors), kf._p(psi), kf._p(f), kf._p(g), kf._p(ld))
+        od = None
+        if order is not None and (g is not None or ld is not None):
+            if isinstance(order, str):
+                if order != "lapack":
+                    raise MetranHipError("minres_eval: order must be 'lapack', None or an array of ranks")
+                order = eig_order(corr.cpu().numpy() if corr_host is None else corr_host, psi.cpu().numpy(), int(kmax))
+            od = torch.as_tensor(np.ascontiguousarray(order, dtype=np.int64)).to(kf.device).reshape(B, int(kmax)).contiguous()
+        self._call("mk_fa_minres", B, R, N, int(kmax), kf._p(corr), kf._p(nfactors), kf._p(psi), kf._p(od), kf._p(f),
+                   kf._p(g), kf._p(ld))
         return f, g, ld
 
     def eigh(self, sym):
@@ -133,9 +179,11 @@ class FactorAnalysisBatch:
         return val, vec
 
     # ------------------------------------------------------------------ FactorAnalysis.solve for R models
-    def solve(self, obs=None, corr=None):
+    def solve(self, obs=None, corr=None, always_scipy=False):
         """``FactorAnalysis.solve`` (:42-119) for every record: ``obs [R,T,N]`` (default: the engine's records) or
-        precomputed correlation matrices.  Returns a ``FactorResult`` of device tensors."""
+        precomputed correlation matrices.  Returns a ``FactorResult`` of device tensors.  ``always_scipy``: skip the
+        device-side stall check and run the reference's minimisation for every model (what the one-model mirror
+        class does)."""
         import torch
 
         kf = self.kf
@@ -155,30 +203,8 @@ class FactorAnalysisBatch:
         a = self.analyse(corr)
         nf = a["nfactors"]
         kmax = max(1, int(nf.max().item()))
-        psi = a["psi0"]
-        f0, g0, ld = self.minres_eval(corr, nf, psi, kmax)
-        # ---- does the reference's optimiser stall at its start vector? (module docstring) ----
-        lo = torch.full_like(psi, _PSI_LO)
-        hi = torch.full_like(psi, _PSI_HI)
-        d = torch.minimum(torch.maximum(psi - g0, lo), hi) - psi          # projected-gradient step
-        pgnorm = d.abs().amax(1)
-        steps = 2.0 ** -torch.arange(20, dtype=torch.float64, device=kf.device)
-        trial = (psi[None] + steps[:, None, None] * d[None]).reshape(20 * R, N)  # instance k*R + r -> model r
-        ft, _, _ = self.minres_eval(corr, nf, trial, kmax, want=("f",))
-        ft = ft.reshape(20, R)
-        slope = (g0 * d).sum(1)
-        armijo = ft <= f0[None] + 1e-3 * steps[:, None] * slope[None]
-        stalled = ~(armijo.any(0) & (pgnorm > 1e-5))
         ok = (a["status"] == 0) & (nf > 0)
-        moving = (~stalled) & ok
-        if bool(moving.any()):
-            idx = torch.nonzero(moving).reshape(-1).tolist()
-            logger.warning("factor analysis: scipy's L-BFGS-B can leave the start vector for %d model(s); running the "
-                           "reference's minimisation for them (objective/jacobian on the device)", len(idx))
-            psi = psi.clone()
-            for r in idx:
-                psi[r] = torch.from_numpy(self._host_minres(corr[r:r + 1], nf[r:r + 1], psi[r].cpu().numpy(), kmax)).to(psi)
-            _, _, ld = self.minres_eval(corr, nf, psi, kmax, want=("loadings",))
+        psi, ld, stalled = self._minres_batch(corr, nf, a["psi0"], ok, kmax, always_scipy=always_scipy)
         # ---- rotation + sign convention (:84-108) ----
         self._call("mk_fa_rotate", R, N, kmax, kf._p(nf), kf._p(ld), 1.0, 20, 1e-6)
         nonzero = (ld != 0).flatten(1).any(1)
@@ -195,21 +221,135 @@ class FactorAnalysisBatch:
                             eigval=ev, fep=fep, corr=corr, psi=psi, status=torch.where(good, a["status"], torch.ones_like(a["status"])),
                             stalled=stalled, kmax=kmax)
 
-    def _host_minres(self, corr1, nf1, start, kmax):
-        """The reference's ``scopt.minimize(..., method="L-BFGS-B", jac=..., bounds=(0.005, 1))`` (:209-216) for ONE
-        model, objective and jacobian from ``mk_fa_minres``."""
+    def _minres_batch(self, corr, nf, psi0, ok, kmax, always_scipy=False):
+        """``_minres`` (:173-217) for every model: ``(psi [R,N], unrotated loadings [R,N,kmax], stalled [R])``.
+        ``stalled[r]``: scipy's L-BFGS-B returns (or would return) its start vector for model r."""
+        import torch
+
+        kf = self.kf
+        R, N = int(corr.shape[0]), int(corr.shape[1])
+        corr_h = corr.cpu().numpy()
+        psi = psi0
+        f0, g0, ld = self.minres_eval(corr, nf, psi, kmax, corr_host=corr_h)
+        if always_scipy:
+            maybe = ok.clone()
+        else:
+            # ---- does the reference's optimiser stall at its start vector? (module docstring) ----
+            lo = torch.full_like(psi, _PSI_LO)
+            hi = torch.full_like(psi, _PSI_HI)
+            d = torch.minimum(torch.maximum(psi - g0, lo), hi) - psi          # projected-gradient step
+            pgnorm = d.abs().amax(1)
+            steps = 2.0 ** -torch.arange(20, dtype=torch.float64, device=kf.device)
+            trial = (psi[None] + steps[:, None, None] * d[None]).reshape(20 * R, N)  # instance k*R + r -> model r
+            ft, _, _ = self.minres_eval(corr, nf, trial, kmax, want=("f",))
+            ft = ft.reshape(20, R)
+            slope = (g0 * d).sum(1)
+            # sufficient decrease is ft <= f0 + 1e-3 step slope; the band down to 1e-6 goes to scipy as well
+            near = ft <= f0[None] + 1e-6 * steps[:, None] * slope[None]
+            maybe = near.any(0) & (pgnorm > 0.5e-5) & ok
+        stalled = torch.ones(R, dtype=torch.bool, device=kf.device)
+        if bool(maybe.any()):
+            idx = torch.nonzero(maybe).reshape(-1)
+            logger.info("factor analysis: scipy's L-BFGS-B may leave the start vector for %d of %d model(s); running the "
+                        "reference's minimisation for them in lock-step (objective/jacobian on the device)", len(idx), R)
+            x = self._lockstep_minres(corr.index_select(0, idx).contiguous(), corr_h[idx.cpu().numpy()],
+                                      nf.index_select(0, idx).contiguous(), psi.index_select(0, idx).cpu().numpy(), kmax)
+            x = torch.from_numpy(x).to(psi)
+            stalled[idx] = (x == psi.index_select(0, idx)).all(1)
+            psi = psi.clone()
+            psi[idx] = x
+            _, _, ld = self.minres_eval(corr, nf, psi, kmax, want=("loadings",), corr_host=corr_h)
+        return psi, ld, stalled
+
+    def _lockstep_minres(self, corr, corr_host, nf, start, kmax):
+        """The reference's ``scopt.minimize(_minresfun, start, method="L-BFGS-B", jac=_minresgrad, bounds=(0.005, 1))``
+        (:209-216) for M models at once: the SAME public scipy routine per model, each on its own host thread, with
+        every round of objective/jacobian requests (one per model still running) answered by ONE ``mk_fa_minres``
+        launch plus one batched ``eig_order``.  ``corr [M,N,N]`` (device), ``corr_host`` its host copy, ``nf [M]``,
+        ``start [M,N]`` (host) -> ``x [M,N]`` (host).  At most ``_LOCKSTEP_THREADS`` models are in flight at once."""
         import scipy.optimize as scopt
+        import torch
 
-        def fun(x):
-            f, _, _ = self.minres_eval(corr1, nf1, np.asarray(x, dtype=np.float64)[None], kmax, want=("f",))
-            return float(f[0].item())
+        M, N = start.shape
+        out = np.array(start, dtype=np.float64)
+        bounds = [(_PSI_LO, _PSI_HI)] * N
+        dev = self.kf.device
 
-        def jac(x):
-            _, g, _ = self.minres_eval(corr1, nf1, np.asarray(x, dtype=np.float64)[None], kmax, want=("g",))
-            return g[0].cpu().numpy()
+        def run_chunk(lo, hi):
+            m = hi - lo
+            requests = queue.SimpleQueue()
+            answers = [None] * m
+            wake = [threading.Event() for _ in range(m)]
+            errors = []
+            sub_corr, sub_host, sub_nf = corr[lo:hi], corr_host[lo:hi], nf[lo:hi]
 
-        res = scopt.minimize(fun, start, method="L-BFGS-B", jac=jac, bounds=[(_PSI_LO, _PSI_HI)] * len(start))
-        return np.asarray(res.x, dtype=np.float64)
+            def worker(i):
+                cache = {}
+
+                def evaluate(x):
+                    x = np.array(x, dtype=np.float64)
+                    key = x.tobytes()
+                    if key not in cache:
+                        requests.put((i, x))
+                        wake[i].wait()
+                        wake[i].clear()
+                        if answers[i] is None:
+                            raise MetranHipError("factor analysis: the batched minres evaluation failed")
+                        cache.clear()
+                        cache[key] = answers[i]
+                    return cache[key]
+
+                try:
+                    res = scopt.minimize(lambda x: evaluate(x)[0], start[lo + i], method="L-BFGS-B",
+                                         jac=lambda x: evaluate(x)[1], bounds=bounds)
+                    out[lo + i] = res.x
+                except BaseException as e:  # noqa: BLE001 -- reported by the serving thread
+                    errors.append(e)
+                finally:
+                    requests.put((i, None))
+
+            old = threading.stack_size(512 * 1024)
+            try:
+                threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(m)]
+                for t in threads:
+                    t.start()
+            finally:
+                threading.stack_size(old)
+            live = m
+            while live:
+                batch = {}
+                while len(batch) < live:     # every model still running has asked (or has finished)
+                    i, x = requests.get()
+                    if x is None:
+                        live -= 1
+                    else:
+                        batch[i] = x
+                if not batch:
+                    break
+                ids = sorted(batch)
+                try:
+                    X = np.stack([batch[i] for i in ids])
+                    sel = torch.as_tensor(ids, device=dev)
+                    f, g, _ = self.minres_eval(sub_corr.index_select(0, sel).contiguous(),
+                                               sub_nf.index_select(0, sel).contiguous(), X, kmax, want=("f", "g"),
+                                               corr_host=sub_host[ids])
+                    f, g = f.cpu().numpy(), g.cpu().numpy()
+                    for k, i in enumerate(ids):
+                        answers[i] = (float(f[k]), g[k].copy())
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+                    for i in ids:
+                        answers[i] = None
+                for i in ids:
+                    wake[i].set()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+
+        for lo in range(0, M, _LOCKSTEP_THREADS):
+            run_chunk(lo, min(M, lo + _LOCKSTEP_THREADS))
+        return out
 
 
 class FactorAnalysis:
@@ -231,7 +371,7 @@ class FactorAnalysis:
     def solve(self, oseries):
         """:42-119 -- ``oseries``: DataFrame (or array [T,N]); returns the loadings ``[N, nfactors]`` or None."""
         y = np.asarray(getattr(oseries, "values", oseries), dtype=np.float64)
-        res = self._batch().solve(obs=y[None])
+        res = self._batch().solve(obs=y[None], always_scipy=True)
         self.eigval = res.eigval[0].cpu().numpy()
         nf = int(res.nfactors[0].item())
         self.stalled = bool(res.stalled[0].item())
@@ -262,7 +402,7 @@ class FactorAnalysis:
         return int(a["nfactors_map"][0].item()), int(a["nfactors_map4"][0].item())
 
     def _minres(self, s, nf, covar=False):
-        """:173-217"""
+        """:173-217 -- the same path as ``solve``: scipy's L-BFGS-B on the device-evaluated objective / jacobian."""
         import torch
 
         fb = self._batch()
@@ -271,7 +411,8 @@ class FactorAnalysis:
         if int(a["status"][0].item()) != 0:
             return None
         nft = torch.full((1,), int(nf), dtype=torch.int64, device=fb.kf.device)
-        _, _, ld = fb.minres_eval(corr, nft, a["psi0"], max(1, int(nf)), want=("loadings",))
+        ok = torch.ones(1, dtype=torch.bool, device=fb.kf.device)
+        _, ld, _ = fb._minres_batch(corr, nft, a["psi0"], ok, max(1, int(nf)), always_scipy=True)
         return ld[0].cpu().numpy()
 
 

@@ -1,8 +1,10 @@
 """CPU oracle for the factor analysis (row f4) -- TEST INFRASTRUCTURE ONLY, never imported by ``metran_amd``.
 
 A numpy restatement of /root/reference/metran/factoranalysis.py, each function citing the lines it follows.
-Parity status: PINNED against ``tests/golden/factor_analysis.npz`` (generated from the reference itself by
-``tests/golden/make_golden.py factor_analysis``; ``tests/test_factor_oracle.py``).
+Parity status: PINNED against ``tests/golden/factor_analysis.npz`` and ``tests/golden/factor_multi.npz`` (49 multi-factor
+models, 23 of them with ``eig`` returning its pairs out of order) generated from the reference itself by
+``tests/golden/make_golden.py factor_analysis factor_multi`` (``tests/test_factor_oracle.py``), and differentially
+against the live reference on 480 random models (``scripts/diff_factor_reference.py``: 0 mismatches).
 
 Third-party arithmetic, as in the reference: ``numpy.linalg`` (LAPACK eig / eigh / svd / inv) and
 ``scipy.optimize.minimize(method="L-BFGS-B")`` -- the optimiser is CALLED here exactly as the reference calls it
@@ -96,13 +98,25 @@ def minresfun(psi, s, nf):
 
 
 def get_loadings(psi, s, nf):
-    """_get_loadings (:375-401) with the nf LARGEST eigenpairs of psi^-1/2 S psi^-1/2 (what LAPACK's ``eig``
-    returns first for these matrices in every fixture; column signs are LAPACK's and are not reproduced)."""
-    sc = 1 / np.sqrt(psi)
-    w, v = np.linalg.eigh(s * sc[:, None] * sc[None, :])
-    order = np.argsort(-w)[:nf]
-    load = v[:, order] * np.sqrt(np.maximum(w[order] - 1, 0))[None, :]
-    return np.sqrt(psi)[:, None] * load
+    """_get_loadings (:375-401), exactly: ``np.linalg.eig`` of psi^-1/2 S psi^-1/2 and its FIRST nf pairs in the
+    order LAPACK's dgeev returns them (:396-398) -- NOT sorted.  For most matrices these are the nf largest, but
+    not always (8-21 % of random 20- and 32-series models with nf = 2: the round-2 verdict's differential), and
+    then the reference's loadings are built from a non-dominant eigenvector; the restatement follows it."""
+    sc = np.diag(1 / np.sqrt(psi))
+    sstar = np.dot(sc, np.dot(s, sc))
+    w, v = np.linalg.eig(sstar)
+    load = np.dot(v[:, :nf], np.diag(np.sqrt(np.maximum(np.subtract(w[:nf], 1), 0))))
+    return np.dot(np.diag(np.sqrt(psi)), load)
+
+
+def eig_order(sstar, nf):
+    """Which eigenpairs ``np.linalg.eig(sstar)[:, :nf]`` are, as RANKS in descending order of the eigenvalues
+    (0 = largest): what a sorted decomposition needs to know to pick the reference's columns."""
+    w = np.linalg.eig(sstar)[0].real
+    order = np.argsort(-w, kind="stable")
+    rank = np.empty(len(w), dtype=np.int64)
+    rank[order] = np.arange(len(w))
+    return rank[:nf]
 
 
 def minresgrad(psi, s, nf):
@@ -133,11 +147,13 @@ def rotate(phi, gamma=1.0, maxiter=20, tol=1e-6):
     return phi @ R
 
 
-def solve(y, maxfactors=None):
-    """FactorAnalysis.solve (:42-119) -> dict(corr, eigval, nfactors_map, nfactors_map4, nfactors, psi, factors, fep)."""
+def solve(y=None, maxfactors=None, corr=None):
+    """FactorAnalysis.solve (:42-119) -> dict(corr, eigval, nfactors_map, nfactors_map4, nfactors, psi, factors, fep);
+    from observations ``y [T,N]`` or from a correlation matrix."""
     import scipy.optimize as scopt
 
-    corr = correlations(y)
+    if corr is None:
+        corr = correlations(y)
     eigval, eigvec = get_eigval(corr)
     nfm, nfm4 = maptest(corr, eigvec, eigval)
     nf = nfm if nfm > 0 else int(np.sum(eigval > 1))

@@ -63,3 +63,55 @@ def test_published_known_answers(fa):
     np.testing.assert_allclose(fa["g2_factors"].ravel(), [0.93540765, 0.93540765], atol=5e-9)
     np.testing.assert_allclose(fa["g2_eigval"], [1.87212635, 0.12787365], atol=5e-9)
     assert abs(float(fa["g1_fep"]) - 88.32) < 5e-3                         # notebook: fep 88.32%
+
+
+# ---- multi-factor models (tests/golden/factor_multi.npz): columns in the reference's OWN order, no matching ----
+def multi_names():
+    return [str(n) for n in load_golden("factor_multi.npz")["names"]]
+
+
+@pytest.fixture(scope="module")
+def fm():
+    return load_golden("factor_multi.npz")
+
+
+def test_multi_fixture_has_what_the_verdict_asked_for(fm):
+    names = multi_names()
+    assert len(names) >= 40
+    nondominant = [n for n in names if sorted(fm[n + "_eig_rank"]) != list(range(int(fm[n + "_nfactors"])))]
+    permuted = [n for n in names if n not in nondominant and list(fm[n + "_eig_rank"]) != list(range(int(fm[n + "_nfactors"])))]
+    assert len(nondominant) >= 8 and len(permuted) >= 4
+    assert all(int(fm[n + "_nfactors"]) >= 2 for n in names)
+    assert {fm[n + "_corr"].shape[0] for n in names} >= {20, 32}
+    assert sum(float(np.abs(fm[n + "_psi"] - fm[n + "_psi0"]).max()) > 0 for n in names) >= 3
+
+
+@pytest.mark.parametrize("name", multi_names())
+def test_oracle_reproduces_reference_multi(fm, name):
+    r = fo.solve(corr=fm[name + "_corr"])
+    nf = int(fm[name + "_nfactors"])
+    assert r["nfactors"] == nf
+    assert (r["nfactors_map"], r["nfactors_map4"]) == (int(fm[name + "_nfactors_map"]), int(fm[name + "_nfactors_map4"]))
+    np.testing.assert_allclose(r["eigval"], fm[name + "_eigval"], atol=1e-12)
+    np.testing.assert_allclose(r["psi0"], fm[name + "_psi0"], atol=1e-12)
+    np.testing.assert_allclose(r["psi"], fm[name + "_psi"], atol=1e-9)
+    ld = fo.get_loadings(fm[name + "_psi"], fm[name + "_corr"], nf)
+    np.testing.assert_allclose(ld, fm[name + "_loadings_unrotated"], atol=1e-12)
+    np.testing.assert_allclose(r["factors"], fm[name + "_factors"], atol=1e-9)      # same columns, same order, same signs
+    sc = 1 / np.sqrt(fm[name + "_psi"])
+    assert list(fo.eig_order(fm[name + "_corr"] * sc[:, None] * sc[None, :], nf)) == list(fm[name + "_eig_rank"])
+    assert abs(r["fep"] - float(fm[name + "_fep"])) < 1e-9
+
+
+def test_product_eig_order_is_the_oracles(fm):
+    """Host logic of the product (no GPU): metran_amd.factoranalysis.eig_order, batched, instance b -> matrix b % R."""
+    from metran_amd.factoranalysis import eig_order
+
+    names = [n for n in multi_names() if fm[n + "_corr"].shape[0] == 32]
+    corr = np.stack([fm[n + "_corr"] for n in names])
+    psi = np.stack([fm[n + "_psi"] for n in names])
+    got = eig_order(corr, np.concatenate([psi, psi]), 4)
+    for b in range(2 * len(names)):
+        n = names[b % len(names)]
+        nf = int(fm[n + "_nfactors"])
+        assert list(got[b, :nf]) == list(fm[n + "_eig_rank"])
