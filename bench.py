@@ -91,6 +91,72 @@ def pmc_traffic(config, kernel_key, sym=False):
     return best, (None if best else note)
 
 
+FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 vector = FP64 matrix peak (256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz).
+                         # Not in MI355X_MICROARCH.md; measured ceilings here: 72 (v_mfma_f64_16x16x4) / 66 (v_fma_f64) TFLOP/s.
+
+
+def algorithmic_flops(N, K, T, mode, missing=0.0):
+    """flops per model.  Filter per step: predict 3n^2+n (diagonal Phi) + m (5n^2+6n+3) for the
+    m observed series (the reference's dense update); smoother per step: 6.33 n^3 + 4 n^2 (LDL^T n^3/3, two triangular
+    solves 2 n^3, J D 2 n^3, .J^T 2 n^3)."""
+    n = N + K
+    m = N * (1.0 - missing)
+    f = T * (3 * n * n + n + m * (5 * n * n + 6 * n + 3))
+    return {"filter": f, "smoother": 0.0 if mode == "solver" else T * (6.33 * n ** 3 + 4 * n * n)}
+
+
+def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, evals=1):
+    """The ``roofline`` object of the bench line for one workload: per-kernel algorithmic bytes / flops per launch over
+    the hipEvent launch time, and the dominant kernel against the roof that bounds it -- HBM for the 16-lane
+    filter+smoother kernels (AI ~ 3 flop/B), the fp64 pipe for the wide (n > 16) kernels and the solver objective
+    (AI 41-75 flop/B on the bytes they move: SURVEY 8d)."""
+    ab = algorithmic_bytes(N, K, T, mode, sym=packed_sym)
+    fl = algorithmic_flops(N, K, T, mode, missing)
+    if mode == "solver":
+        s_avg = 0.0
+    wide = N + K > 16   # one model per wavefront: mk_wide.hip
+    sname = None if mode == "solver" else ("smoother_mfma_kernel" if wide else "smoother_record_kernel")
+
+    def entry(kind, ms):
+        return {"ms": ms, "algorithmic_GB": ab[kind] * B / 1e9, "GBps": ab[kind] * B / 1e9 / (ms / 1e3),
+                "algorithmic_TFLOP": fl[kind] * B / 1e12, "TFLOPps": fl[kind] * B / 1e12 / (ms / 1e3)}
+
+    kernels = {"filter_kernel": entry("filter", f_avg)}
+    if sname:
+        kernels[sname] = entry("smoother", s_avg)
+    for kname in kernels:
+        tr, note = pmc_traffic(config, kname, packed_sym)
+        kernels[kname]["traffic_GB"] = tr["GB"] if tr else None
+        kernels[kname]["traffic_source" if tr else "traffic_note"] = tr["source"] if tr else note
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    fp64_bound = wide or mode == "solver"
+    if fp64_bound:
+        roofline = {"bound": "fp64", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": kernels[dom]["TFLOPps"] / FP64_PEAK_TFLOPS,
+                    "algorithmic_flops": kernels[dom]["algorithmic_TFLOP"] * 1e12,
+                    "hbm_frac_of_the_same_kernel": kernels[dom]["GBps"] / HBM_PEAK_GBS,
+                    "note": "arithmetic intensity %.0f flop/B on the algorithmic bytes: bound by the fp64 vector/MFMA pipe "
+                            "(78.6 TFLOP/s datasheet; f64 MFMA and f64 VALU share it on gfx950), not by HBM"
+                            % (kernels[dom]["algorithmic_TFLOP"] * 1e3 / max(kernels[dom]["algorithmic_GB"], 1e-30))}
+    else:
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS}
+    roofline.update({"traffic": (kernels[dom]["traffic_GB"] * 1e9 if kernels[dom].get("traffic_GB") else None),
+                     "algorithmic_bytes": kernels[dom]["algorithmic_GB"] * 1e9, "avg_launch_ms": kernels[dom]["ms"],
+                     "kernels": kernels, "kernel_source_sha256": kernel_source_sha(),
+                     "path_achieved_GBps": sum(ab.values()) * B / 1e9 / ((f_avg + s_avg) / 1e3)})
+    # SURVEY 8d's full-output accounting B_fs = 8 T (N + 4c) per model, for every configuration (what the
+    # north-star's ">= 40 % of HBM" is quoted in; the path may move fewer bytes, e.g. the projection path)
+    n = N + K
+    b_fs = 8 * T * (N + 4 * (n + n * n))
+    if mode != "solver":
+        roofline["survey_8d_full_output_accounting"] = {
+            "bytes_per_model": b_fs, "equivalent_GBps": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3),
+            "frac_of_peak": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3) / HBM_PEAK_GBS,
+            "note": "kernel-time rate of this GPU x bytes a full-square six-output pass would move"}
+    return roofline
+
+
 # --------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline_port(host, mode, gpu_mle, target_seconds=12.0):
     """The reference ALGORITHM (oracle/kalman_oracle.c: C restatement of kalmanfilter.py:236-476, OpenMP over
@@ -213,6 +279,114 @@ def respawn_under_torchrun(n):
     os.execv(sys.executable, argv)
 
 
+class Workload:
+    """One configuration of CONFIGS on one GPU: synthetic records resident in HBM, output buffers allocated once,
+    ``step()`` = one pass of the hot path over the batch (+ the deterministic local sum of -2 log L into ``total``)."""
+
+    def __init__(self, name, local_rank, rank, dev, layout, packed_sym, batch=None, T=None):
+        import torch
+
+        from metran_amd.engine import BatchedKalman
+        from metran_amd.synthetic import make_dfm_batch_torch
+
+        B, N, K, T0, missing, mode = CONFIGS[name]
+        self.name, self.B, self.N, self.K, self.T, self.missing, self.mode = name, batch or B, N, K, T or T0, missing, mode
+        self.packed_sym = bool(packed_sym) and mode == "full"
+        self.d = make_dfm_batch_torch(self.B, N, K, self.T, seed=2000 + rank, device=dev, missing=missing)
+        self.kf = BatchedKalman(local_rank, layout=layout, packed_sym=self.packed_sym)
+        self.kf.set_observations(self.d["obs"]).set_loadings(self.d["loadings"])
+        self.total = torch.zeros(1, dtype=torch.float64, device=dev)
+        if mode == "full":
+            self.bufs = self.kf._alloc_outputs(self.B, ["F", "Pf", "Xp", "Pp", "S", "Ps"])
+        elif mode == "project":
+            self.bufs = self.kf.alloc_projection(self.B)
+        else:
+            self.bufs = {"mle": torch.empty(self.B, dtype=torch.float64, device=dev)}
+            # the 50 parameter sets of one step: alpha_k = alpha_0 (1 + 0.02 k), SURVEY 8d
+            self.alphas = [self.d["alpha"] * (1.0 + 0.02 * k) for k in range(EVALS_PER_STEP)]
+
+    @property
+    def units(self):  # model passes per step
+        return EVALS_PER_STEP if self.mode == "solver" else 1
+
+    def step(self):
+        kf, d = self.kf, self.d
+        if self.mode == "full":
+            kf.filter_smooth(d["phi"], d["q"], buffers=self.bufs)
+        elif self.mode == "project":
+            kf.simulate_smoothed(d["phi"], d["q"], buffers=self.bufs)
+        else:
+            for a in self.alphas:  # a2 + a3 + a6 per evaluation, as Metran.get_mle does (metran.py:605-622)
+                phi, q = kf.params_from_alpha(a)
+                kf.loglik(phi, q, out=self.bufs["mle"])
+        self.total.copy_(kf.sum(self.bufs["mle"]).reshape(1))   # deterministic local reduction
+        return self.total
+
+    def host_inputs(self):
+        if self.mode == "solver":
+            ph, qq = self.kf.params_from_alpha(self.alphas[-1])
+            return {"obs": self.d["obs"].cpu().numpy(), "phi": ph.cpu().numpy(), "q": qq.cpu().numpy(),
+                    "loadings": self.d["loadings"].cpu().numpy()}
+        return {k: self.d[k].cpu().numpy() for k in ("obs", "phi", "q", "loadings")}
+
+    def describe(self):
+        return ("BASELINE.json %s: batch=%d synthetic %d-series/%d-factor DFMs per GPU, T=%d, fp64, %s"
+                % (BASELINE_NAME[self.name], self.B, self.N, self.K, self.T,
+                   {"full": "filter+smoother, outputs F,Pf,Xp,Pp,S,Ps" + (" as packed-symmetric records" if self.packed_sym else ""),
+                    "project": "%d %% missing, filter (filtered record) + smoother with fused projection (sim_means, sim_vars)" % round(100 * self.missing),
+                    "solver": "solver loop: %d objective evaluations (alpha -> phi,q -> filter -> -2 log L) per step" % EVALS_PER_STEP}[self.mode]))
+
+    def close(self):
+        self.kf.close()
+        self.bufs = self.d = self.kf = None
+
+
+def timed_run(w, steps, warmup, sync, after_step=None):
+    """W untimed warm-up steps, then EXACTLY ``steps`` steps bracketed by sync() (barrier + device synchronise) on both
+    sides; kernel times are hipEvent pairs on the launch stream collected AFTER the loop (nothing synchronises inside
+    it).  Returns (elapsed seconds, average filter ms per launch, average smoother ms per launch)."""
+    import torch
+
+    for _ in range(warmup):
+        w.step()
+        if after_step:
+            after_step(w)
+    sync()
+    w.kf.enable_timing(True, accumulate=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step()
+        if after_step:
+            after_step(w)
+    sync()
+    elapsed = time.perf_counter() - t0
+    f_tot, f_n, s_tot, s_n = w.kf.kernel_ms_totals()   # every launch of the timed region
+    w.kf.enable_timing(False)
+    return elapsed, f_tot / max(f_n, 1), s_tot / max(s_n, 1)
+
+
+def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=3, warmup=1):
+    """The non-headline configurations measured in the SAME process after the headline's timed region (VERDICT r2 item 3:
+    configs[3] and configs[4] in driver-run records): kernel ms, models/s and the roofline of one GPU."""
+    import torch
+
+    w = Workload(name, local_rank, rank, dev, layout, False)
+    try:
+        elapsed, f_avg, s_avg = timed_run(w, steps, warmup, sync)
+        models_per_s = w.B * w.units * steps / elapsed
+        out = {"workload": w.describe(), "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+               "models_per_s": models_per_s, "value": models_per_s * w.T, "unit": "model-timesteps/s",
+               "filter_ms": f_avg, "smoother_ms": (s_avg if w.mode != "solver" else None),
+               "roofline": build_roofline(name, w.N, w.K, w.T, w.B, w.mode, w.missing, f_avg, s_avg, False)}
+        if w.mode == "solver":
+            out["objective_evaluations_per_s"] = models_per_s
+    finally:
+        w.close()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +398,8 @@ def main():
     ap.add_argument("--packed-sym", action="store_true",
                     help="c2/c3: packed-symmetric records (MK_PACKED_SYM; n + n(n+1)/2 doubles per moment set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[3] / configs[4] lines that the default one-GPU run appends after the headline")
     ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"])
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU (gloo): launch, barrier, max-over-ranks, one JSON line with value null")
@@ -237,7 +413,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
 
     B, N, K, T, missing, mode = CONFIGS[args.config]
@@ -247,6 +423,7 @@ def main():
     warmup = args.warmup if args.warmup is not None else (10 if mode == "full" else 1)
 
     dist = None
+    backend = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
 
@@ -256,6 +433,7 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = dist.get_backend()
     dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
@@ -266,61 +444,36 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    total = torch.zeros(1, dtype=torch.float64, device=dev)
-    bufs = d = kf = None
+    w = None
+    collectives = 0
     if args.dry_run:
-        def step():
+        total = torch.zeros(1, dtype=torch.float64, device=dev)
+        for _ in range(warmup):
             total.fill_(float(rank + 1))
             if dist is not None:
                 dist.all_reduce(total)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            total.fill_(float(rank + 1))
+            if dist is not None:
+                dist.all_reduce(total)
+                collectives += 1
+        sync()
+        elapsed = time.perf_counter() - t0
+        f_avg = s_avg = 0.0
     else:
-        from metran_amd.engine import BatchedKalman
-        from metran_amd.synthetic import make_dfm_batch_torch
+        w = Workload(args.config, local_rank, rank, dev, args.layout, args.packed_sym, batch=args.batch, T=args.T)
+        total = w.total
 
-        d = make_dfm_batch_torch(B, N, K, T, seed=2000 + rank, device=dev, missing=missing)
-        kf = BatchedKalman(local_rank, layout=args.layout, packed_sym=args.packed_sym)
-        kf.set_observations(d["obs"]).set_loadings(d["loadings"])
-        if mode == "full":
-            bufs = kf._alloc_outputs(B, ["F", "Pf", "Xp", "Pp", "S", "Ps"])
-        elif mode == "project":
-            bufs = kf.alloc_projection(B)
-        else:
-            bufs = {"mle": torch.empty(B, dtype=torch.float64, device=dev)}
-            # the 50 parameter sets of one step: alpha_k = alpha_0 (1 + 0.02 k), SURVEY 8d
-            alphas = [d["alpha"] * (1.0 + 0.02 * k) for k in range(EVALS_PER_STEP)]
+        def after_step(wl):
+            nonlocal collectives
+            if dist is not None and wl.mode != "solver":
+                dist.all_reduce(wl.total)          # RCCL all-reduce of the summed -2 log L (8 bytes)
+                collectives += 1
 
-        def step():
-            if mode == "full":
-                kf.filter_smooth(d["phi"], d["q"], buffers=bufs)
-            elif mode == "project":
-                kf.simulate_smoothed(d["phi"], d["q"], buffers=bufs)
-            else:
-                for a in alphas:  # a2 + a3 + a6 per evaluation, as Metran.get_mle does (metran.py:605-622)
-                    phi, q = kf.params_from_alpha(a)
-                    kf.loglik(phi, q, out=bufs["mle"])
-            s = kf.sum(bufs["mle"])            # deterministic local reduction
-            total.copy_(s.reshape(1))
-            if dist is not None and mode != "solver":
-                dist.all_reduce(total)          # RCCL all-reduce of the summed -2 log L (8 bytes)
-            return total
-
-    for _ in range(warmup):
-        step()
-    sync()
-    if kf is not None:
-        kf.enable_timing(True, accumulate=True)   # one hipEvent pair per launch on the launch stream, read AFTER the loop
-        torch.cuda.synchronize()
-    f_avg = s_avg = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if kf is not None:
-        f_tot, f_n, s_tot, s_n = kf.kernel_ms_totals()   # every launch of the timed region
-        f_avg = f_tot / max(f_n, 1)
-        s_avg = s_tot / max(s_n, 1)
-        kf.enable_timing(False)
+        elapsed, f_avg, s_avg = timed_run(w, steps, warmup, sync, after_step)
+        collectives -= warmup if (dist is not None and mode != "solver") else 0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nranks = torch.ones(1, dtype=torch.float64, device=dev)
     if dist is not None:
@@ -332,11 +485,7 @@ def main():
         units = EVALS_PER_STEP if mode == "solver" else 1     # model passes per step
         ms_per_step = 1e3 * elapsed / steps
         models_per_s = world * B * units * steps / elapsed
-        workload = ("BASELINE.json %s: batch=%d synthetic %d-series/%d-factor DFMs per GPU, T=%d, fp64, %s"
-                    % (BASELINE_NAME[args.config], B, N, K, T,
-                       {"full": "filter+smoother, outputs F,Pf,Xp,Pp,S,Ps" + (" as packed-symmetric records" if args.packed_sym else ""),
-                        "project": "%d %% missing, filter (filtered record) + smoother with fused projection (sim_means, sim_vars)" % round(100 * missing),
-                        "solver": "solver loop: %d objective evaluations (alpha -> phi,q -> filter -> -2 log L) per step" % EVALS_PER_STEP}[mode]))
+        workload = w.describe() if w is not None else "dry run of %s" % BASELINE_NAME[args.config]
         res = {
             "metric": "Kalman filter+smoother steps/sec (batched DFMs)",
             "value": None if args.dry_run else models_per_s * T,
@@ -350,9 +499,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "name": args.config, "batch_per_gpu": B, "series": N, "factors": K, "T": T,
-                       "parallelism": "dp%d" % world, "layout": args.layout, "packed_sym": bool(args.packed_sym)},
+            "config": {"workload": workload, "name": args.config, "batch_per_gpu": B, "total_batch": B * world, "series": N,
+                       "factors": K, "T": T, "parallelism": "dp%d" % world, "layout": args.layout,
+                       "packed_sym": bool(args.packed_sym)},
             "rccl_ranks": int(nranks.item()),
+            # how rccl_ranks was obtained: the process-group backend whose all_reduce summed one 1.0 per rank
+            # ("nccl" = RCCL on ROCm), or None when no process group exists (plain `python bench.py`, one GPU)
+            "collective": {"backend": backend, "allreduces_in_timed_region": collectives,
+                           "what": "summed -2 log L, 8 bytes, once per step" if backend else "none (no process group)"},
         }
         if args.dry_run:
             res["dry_run"] = "plumbing only (gloo, no kernels): not a measurement"
@@ -360,54 +514,30 @@ def main():
         else:
             res["models_per_s"] = models_per_s
             res["models_per_s_per_gpu"] = models_per_s / world
-            ab = algorithmic_bytes(N, K, T, mode, sym=args.packed_sym)
-            if mode == "solver":
-                s_avg = 0.0
-            fname = "filter_kernel"
-            wide = N + K > 16   # one model per wavefront: mk_wide.hip (MK_WIDE_SMOOTHER=v1 selects the round-1 kernel)
-            sname = None if mode == "solver" else (
-                ("smoother_wave_kernel" if os.environ.get("MK_WIDE_SMOOTHER", "") == "v1" else "smoother_mfma_kernel") if wide
-                else "smoother_record_kernel")
-            kernels = {fname: {"ms": f_avg, "algorithmic_GB": ab["filter"] * B / 1e9, "GBps": ab["filter"] * B / 1e9 / (f_avg / 1e3)}}
-            if sname:
-                kernels[sname] = {"ms": s_avg, "algorithmic_GB": ab["smoother"] * B / 1e9, "GBps": ab["smoother"] * B / 1e9 / (s_avg / 1e3)}
-            for kname in kernels:
-                tr, note = pmc_traffic(args.config, kname, args.packed_sym)
-                kernels[kname]["traffic_GB"] = tr["GB"] if tr else None
-                kernels[kname]["traffic_source" if tr else "traffic_note"] = tr["source"] if tr else note
-            dom = max(kernels, key=lambda k: kernels[k]["ms"])
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
-                        "traffic": (kernels[dom]["traffic_GB"] * 1e9 if kernels[dom].get("traffic_GB") else None),
-                        "algorithmic_bytes": kernels[dom]["algorithmic_GB"] * 1e9, "avg_launch_ms": kernels[dom]["ms"],
-                        "kernels": kernels, "kernel_source_sha256": kernel_source_sha(),
-                        "path_achieved_GBps": sum(ab.values()) * B / 1e9 / ((f_avg + s_avg) / 1e3)}
-            # SURVEY 8d's full-output accounting B_fs = 8 T (N + 4c) per model, for every configuration (what the
-            # north-star's ">= 40 % of HBM" is quoted in; the path may move fewer bytes, e.g. the projection path)
-            n = N + K
-            b_fs = 8 * T * (N + 4 * (n + n * n))
-            if mode != "solver":
-                roofline["survey_8d_full_output_accounting"] = {
-                    "bytes_per_model": b_fs, "equivalent_GBps": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3),
-                    "frac_of_peak": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3) / HBM_PEAK_GBS,
-                    "note": "kernel-time rate of this GPU x bytes a full-square six-output pass would move"}
-            else:
-                roofline["note"] = ("the solver objective is not HBM-bound (AI ~ 75 flop/B, SURVEY 8d): bound by fp64 VALU issue; "
-                                    "the HBM fraction is reported for completeness")
-            res["roofline"] = roofline
+            res["summed_mle"] = float(total.item())
+            res["roofline"] = build_roofline(args.config, N, K, T, B, mode, missing, f_avg, s_avg, args.packed_sym)
             if world == 1 and not args.no_cpu_baseline:
-                if mode == "solver":
-                    ph, qq = kf.params_from_alpha(alphas[-1])
-                    host = {"obs": d["obs"].cpu().numpy(), "phi": ph.cpu().numpy(), "q": qq.cpu().numpy(),
-                            "loadings": d["loadings"].cpu().numpy()}
-                else:
-                    host = {k: d[k].cpu().numpy() for k in ("obs", "phi", "q", "loadings")}
-                gpu_mle = bufs["mle"].cpu().numpy()
+                host = w.host_inputs()
+                gpu_mle = w.bufs["mle"].cpu().numpy()
                 base, rel = cpu_baseline_port(host, mode, gpu_mle)
                 res["cpu_baseline"] = base
                 res["loglik_max_rel_err"] = rel
                 res["speedup_vs_cpu_baseline"] = res["value"] / base["value"]
                 res["cpu_baseline_reference_as_shipped"] = cpu_baseline_reference(host, mode, gpu_mle)
+    if w is not None:
+        w.close()
+        w = None
+        torch.cuda.empty_cache()
+    # ---- the other BASELINE configurations, AFTER the headline's timed region (one GPU, default headline only) ----
+    if (rank == 0 and world == 1 and not args.dry_run and not args.no_secondary and args.config == "c2"
+            and args.batch is None and args.T is None and not args.packed_sym):
+        res["secondary"] = {}
+        for name in ("c4", "c5"):
+            try:
+                res["secondary"][name] = secondary_workload(name, local_rank, rank, dev, args.layout, sync)
+            except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure here
+                res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
     if dist is not None:

@@ -148,6 +148,14 @@ MK_API int mk_destroy(mk_context *ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
 MK_API int mk_set_stream(mk_context *ctx, void *hip_stream);
 MK_API int mk_sync(mk_context *ctx);
+/* Two shape classes have a second, equivalent kernel kept for A/B measurements (both tested against the oracle:
+ * tests/test_smoother_variants.py, tests/test_hip_parity.py).  value 0 = the default.  There is no environment
+ * variable and no switch that changes results.
+ *   MK_VARIANT_SMOOTHER16     n <= 15, packed records: 0 smoother_record_kernel (DPP), 1 smoother_blk_kernel (4x4x4 MFMA)
+ *   MK_VARIANT_WIDE_SMOOTHER  n > 16: 0 the blocked MFMA smoother, 1 smoother_wave_kernel (round 1, row per lane) */
+enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_COUNT = 2 };
+MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value);
+MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value);
 /* Tell the context that the CONTENTS of an observation buffer it has seen changed in place (same pointer): per-record
  * data derived from it (the observed-step list of the sparse objective, see mk_loglik) is rebuilt on the next call.
  * Not needed when a different buffer is passed. */

@@ -107,6 +107,8 @@ API = {
     "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_mask_observations": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mk_pack_observations": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mk_set_kernel_variant": (c_int, [c_void_p, c_int, c_int]),
+    "mk_get_kernel_variant": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "mk_fa_correlation": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mk_fa_analyse": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p]),

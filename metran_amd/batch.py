@@ -104,6 +104,18 @@ class MetranBatch:
         kwargs.setdefault("dt", self.dt)
         self.fit = calibrate_batch(self.kf, **kwargs)
         self.alpha = self.fit.alpha
+        if (self.nfactors < self.K).any():
+            # models with fewer factors than the batch maximum carry zero loading columns: their surplus cdf states are
+            # decoupled dummies (alpha stays at its start value, zero gradient).  The reference counts N + nfactors[r]
+            # parameters (solver.py:280: aic = 2 P + fun) and has no such rows in its parameter table.
+            import torch
+
+            nf = torch.as_tensor(self.nfactors, device=self.fit.obj.device)
+            self.fit["aic"] = 2.0 * (self.N + nf).to(self.fit.obj.dtype) + self.fit.obj
+            dummy = torch.arange(self.N + self.K, device=nf.device)[None, :] >= (self.N + nf)[:, None]
+            self.fit["dummy_parameters"] = dummy          # [R, N+K] True where a parameter does not exist for the model
+            if "stderr" in self.fit:
+                self.fit["stderr"] = torch.where(dummy, torch.full_like(self.fit["stderr"], float("nan")), self.fit["stderr"])
         self._cache.clear()
         return self.fit
 

@@ -71,12 +71,13 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         gradient = "adjoint" if n <= 16 else "fd"
     if gradient not in ("fd", "adjoint"):
         raise ValueError("gradient must be 'auto', 'fd' or 'adjoint'")
+    grad_mode = gradient                              # may switch to "fd" for a small flight (fd_below); the request stays
 
     def value_and_grad(xc):
         """f and gradient of all R models: ONE launch of (n+1)*R instances (forward differences) or a
         forward + a backward launch of R instances (adjoint)."""
         nonlocal nfev, launches
-        if gradient == "adjoint":
+        if grad_mode == "adjoint":
             f, g = kf.loglik_grad_alpha(xc, dt=dt, warmup=warmup)
             nfev += R
             launches += 2
@@ -116,8 +117,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
             S, Y, rho = [t[keep] for t in S], [t[keep] for t in Y], [t[keep] for t in rho]
             R = n_act
             active = torch.ones(R, dtype=torch.bool, device=dev)
-        if gradient == "adjoint" and fd_below and (n + 1) * R <= fd_below:
-            gradient = "fd"
+        if grad_mode == "adjoint" and fd_below and (n + 1) * R <= fd_below:
+            grad_mode = "fd"
         # two-loop recursion, all models at once
         qv = pg.clone()
         al = []
@@ -179,8 +180,11 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     res = CalibrationResult(alpha=x, obj=f, grad=g, converged=~active, nit=nit, nfev=nfev, launches=launches,
                             aic=2 * n + f, pgnorm=pg.abs().amax(1))
     if stderr:
-        if gradient != "adjoint":
-            raise ValueError("stderr=True needs the adjoint gradient (state dimension <= 16)")
+        # the Hessian is differenced from the exact (adjoint) gradient whatever gradient the ITERATION used
+        # (gradient="fd", or the fd_below switch for a small flight): eligibility is the adjoint kernel's, not the mode's
+        if not kf.has_adjoint():
+            raise ValueError("stderr=True differences the adjoint gradient, which this shape (N=%d, K=%d) does not have"
+                             % (kf.N, kf.K))
         d = 1e-5 * x.abs().clamp_min(0.1)                                   # [R,n] step per parameter
         pts = x[None].repeat(n + 1, 1, 1)                                   # [n+1,R,n]
         idx = torch.arange(n, device=dev)

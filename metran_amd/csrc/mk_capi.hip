@@ -27,6 +27,7 @@ struct mk_context {
     // mk_observations_changed() since (the solver evaluates the objective ~80 times on one uploaded record)
     const double *tlist_obs;
     long tlist_T, tlist_N, tlist_ostep;
+    int variant[MK_VARIANT_COUNT]; // mk_set_kernel_variant: which of two equivalent (tested) kernels serves a shape class
 };
 
 static thread_local char g_err[512] = "";
@@ -221,6 +222,7 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->tlist_cap = 0;
     ctx->tlist_obs = nullptr;
     ctx->tlist_T = ctx->tlist_N = ctx->tlist_ostep = 0;
+    for (int &v : ctx->variant) v = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
             delete ctx;
@@ -250,7 +252,25 @@ MK_API int mk_destroy(mk_context *ctx)
 MK_API int mk_set_stream(mk_context *ctx, void *s)
 {
     MK_CTX(ctx);
+    if (ctx->stream != (hipStream_t)s) ctx->tlist_obs = nullptr; // the cached observed-step list was built in the OLD stream's order
     ctx->stream = (hipStream_t)s;
+    return MK_OK;
+}
+
+MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
+{
+    MK_CTX(ctx);
+    if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
+    if (value < 0 || value > 1) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1");
+    ctx->variant[which] = value;
+    return MK_OK;
+}
+
+MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value)
+{
+    MK_CTX(ctx);
+    if (which < 0 || which >= MK_VARIANT_COUNT || !value) return fail(MK_ERR_INVALID, "mk_get_kernel_variant: bad argument");
+    *value = ctx->variant[which];
     return MK_OK;
 }
 
@@ -445,6 +465,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (!o->d_F || !o->d_Pf)
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
     mk::SmootherArgs a;
+    a.variant = (ctx->variant[MK_VARIANT_SMOOTHER16] ? 1 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] ? 2 : 0);
     a.rs = 0;
     a.sym = 0;
     a.state_means = a.state_vars = nullptr;
@@ -538,14 +559,18 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
         a.P0 = p->d_P0;
         a.tlist = ctx->tlist;
         a.rebuild = !(ctx->tlist_obs == p->d_obs && ctx->tlist_T == p->T && ctx->tlist_N == p->N && ctx->tlist_ostep == a.ostep);
-        ctx->tlist_obs = p->d_obs;
-        ctx->tlist_T = p->T;
-        ctx->tlist_N = p->N;
-        ctx->tlist_ostep = a.ostep;
+        // the list is only known to describe this record once the launch that (re)builds it has been accepted: the key
+        // is dropped first and committed after a successful dispatch, so a failed call leaves no stale key behind.
+        // (Stream order: the list is built and read on ctx->stream; mk_set_stream drops the key when the stream changes.)
+        ctx->tlist_obs = nullptr;
         a.mle = d_mle;
         a.status = nullptr;
         MK_HIP(timing_start(ctx, 0));
         MK_HIP(dispatch_sparse((int)p->N, (int)p->K, a, ctx->stream));
+        ctx->tlist_obs = p->d_obs;
+        ctx->tlist_T = p->T;
+        ctx->tlist_N = p->N;
+        ctx->tlist_ostep = a.ostep;
         MK_HIP(timing_stop(ctx, 0));
         return MK_OK;
     }

@@ -35,6 +35,15 @@ struct FilterArgs {
     unsigned *status;
 };
 
+// Timing experiments that skip phases of a kernel (and so produce wrong numbers) exist only in builds made with
+// -DMK_TUNE=<mask> (make EXTRA=-DMK_TUNE=5 OUT=...): a compile-time constant of a separate library.  The shipped library
+// has no such switch and reads no environment variable.
+#ifdef MK_TUNE
+#define MK_TUNE_SKIP(args, bit) (((MK_TUNE) & (bit)) != 0)
+#else
+#define MK_TUNE_SKIP(args, bit) false
+#endif
+
 struct SmootherArgs {
     long B, T;
     long bs, ts;
@@ -48,7 +57,8 @@ struct SmootherArgs {
     const double *F, *Pf;
     double *S, *Ps;
     unsigned *status;
-    long tune;           // wide smoother: start-up phase shift between the wavefronts of a SIMD (launcher-set)
+    long variant;        // bit 0: n <= 15 records -> smoother_blk_kernel; bit 1: n > 16 -> smoother_wave_kernel (round 1);
+                         // set by the C ABI from mk_set_kernel_variant.  Every variant is a tested, equivalent kernel.
 };
 
 struct AdjointArgs {

@@ -1888,17 +1888,9 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-// n <= 15, packed records: smoother_blk_kernel (products as 4x4x4 f64 MFMA blocks) or smoother_record_kernel (all DPP).
-// MK_SMOOTHER16 = blk | record overrides the choice (A/B measurements).
-static bool smoother16_blk()
-{
-    static const int forced = [] {
-        const char *e = getenv("MK_SMOOTHER16");
-        return !e ? 0 : (!strcmp(e, "blk") ? 1 : (!strcmp(e, "record") ? 2 : 0));
-    }();
-    return forced == 1; // default: smoother_record_kernel (measured faster at every batch size)
-}
-
+// n <= 15, packed records: smoother_record_kernel (all DPP; the default, measured faster at every batch size, DESIGN.md
+// section 4) or, with mk_set_kernel_variant(ctx, MK_VARIANT_SMOOTHER16, 1), smoother_blk_kernel (products as 4x4x4 f64
+// MFMA blocks); both tested against the oracle (tests/test_smoother_variants.py)
 template <int N, int K>
 static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
 {
@@ -1911,7 +1903,7 @@ static hipError_t launch_smoother_nk(const SmootherArgs &a, hipStream_t s)
         const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
         const int epi = (a.sim_means || a.sim_vars) ? 1 : (a.state_means ? 2 : 0);
         if constexpr (n <= 15) {
-            if (a.rs > 0 && smoother16_blk()) {
+            if (a.rs > 0 && (a.variant & 1)) {
                 const unsigned bgrid = (unsigned)((a.B + 7) / 8);
 #define MK_LAUNCH_BLK(E, S) hipLaunchKernelGGL((smoother_blk_kernel<N, K, E, S>), dim3(bgrid), dim3(128), 0, s, a)
                 if (a.sym) {

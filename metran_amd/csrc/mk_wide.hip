@@ -216,9 +216,10 @@ smoother_wave_kernel(SmootherArgs a)
 //     v_readlane pair + v_fma_f64 ........ 14-19      (what every broadcast of smoother_wave_kernel costs)
 //     uniform ds_read_b128 + 2 v_fma ..... 9-12 each  (LDS broadcast; the LDS pipe is shared by 4 SIMDs)
 //     v_mfma_f64_16x16x4_f64 ............. 70 per instruction = 4.4 per 64 multiply-adds, and the MFMA
-//                                          pipe runs CONCURRENTLY with another wavefront's VALU work
+//                                          -- on the SAME pipe as the f64 VALU: an MFMA wavefront and an f64-FMA
+//                                          wavefront on one SIMD take the SUM of their times (round-2 measurement)
 //   (f64 MFMA has the same 32 flop/clk/SIMD peak as the f64 VALU on gfx950 -- the gain is that operands
-//   need no broadcast and all 64 lanes carry data, not a higher peak.)
+//   need no broadcast and all 64 lanes carry data, not a higher peak and not concurrency.)
 //   What changed against smoother_wave_kernel:
 //   * factorisation: unchanged (rows distributed over the lanes, readlane broadcasts; n^2/2 of them);
 //   * the two triangular substitutions (n^2 broadcasts) read L from an LDS copy at wavefront-uniform
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // cross-lane traffic at all (the right-looking form it replaces moved row j to every lane with 2(n-j)
         // readlanes per column, 1332 VALU instructions a step at n = 36, on a kernel that is VALU-issue bound).
         // u_c goes to LDS BEFORE the reciprocal: the write -> read round trip of row c+1 overlaps the pivot chain.
-        if (!(a.tune & 4))
+        if (!MK_TUNE_SKIP(a, 4))
         sfor<0, n>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int NPR = (c + 1) / 2; // pairs covering elements 0 .. c-1 (the last may reach the diagonal slot)
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // backward: x_c = z~_c - sum_{k>c} L(k,c) x_k, axpy form over the rows k = n-1 .. 1 of L.  Row k of L is
         // what lane k still holds in A[] after the forward sweep: its elements reach every lane as readlane
         // pairs (scalar operands of the multiply-add) -- no LDS traffic, which is what bounds this kernel
-        if (!(a.tune & 2))
+        if (!MK_TUNE_SKIP(a, 2))
         sfor_down<1, n>(MK_LAMBDA(kc) {
             constexpr int k = decltype(kc)::value + 1; // n-1 .. 1
             const double zk = z[k];
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // Product 2 may not overwrite Dm before every block row of D has been read: the accumulators stay in
         // registers until the end.  A operand of product 2: J[i][k] = JT[Ib][ks]; B operand: the V^T rows just made.
         __builtin_amdgcn_sched_barrier(0);
-        if (!(a.tune & 1))
+        if (!MK_TUNE_SKIP(a, 1))
         sfor<0, NB>(MK_LAMBDA(kb) {
             constexpr int Kb = decltype(kb)::value;
             __builtin_amdgcn_sched_barrier(0); // keeps the next block row's operand loads from being hoisted (registers)
@@ -610,36 +611,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
-// which smoother serves the shapes with n > 16: the MFMA kernel, or (MK_WIDE_SMOOTHER=v1 in the environment,
-// for A/B measurements) the round-1 kernel
-static bool use_v1()
-{
-    static const int v = [] {
-        const char *e = getenv("MK_WIDE_SMOOTHER");
-        return (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
-    }();
-    return v != 0;
-}
-
-static long wide_tune()
-{
-    static const long v = [] {
-        const char *e = getenv("MK_WIDE_TUNE");
-        return e ? atol(e) : 0L;
-    }();
-    return v;
-}
-
+// which smoother serves the shapes with n > 16: the MFMA kernel, or (mk_set_kernel_variant(ctx, MK_VARIANT_WIDE_SMOOTHER,
+// 1), for A/B measurements) the round-1 kernel -- both tested against the oracle
 template <int N, int K>
 static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
 {
-    SmootherArgs a = a0;
-    a.tune = wide_tune();
+    const SmootherArgs &a = a0;
     if constexpr (N + K > 16) {
         const unsigned grid = (unsigned)a.B;
         const bool proj = a.sim_means || a.sim_vars;
         const int epi = proj ? 1 : (a.state_means ? 2 : 0);
-        if (use_v1() && !a.sym && epi != 2) { // the round-1 kernel knows neither packed-symmetric records nor VAR_ONLY
+        if ((a.variant & 2) && !a.sym && epi != 2) { // the round-1 kernel knows neither packed-symmetric records nor VAR_ONLY
             if (proj) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
         } else {

@@ -34,7 +34,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ) and not dist.is_initialized():  # launched by torchrun
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -71,10 +71,12 @@ def run_sharded(n_items, local_fn):
 
 
 def allreduce_sum(t):
-    """In-place all-reduce(sum) of a tensor over the default group; no-op for a single process."""
+    """In-place all-reduce(sum) of a tensor over the default group; no-op when no process group exists.  With a group
+    of ONE rank the collective still runs (an identity, bit for bit): a job launched by torchrun on one GPU exercises
+    the same RCCL call as on eight."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -85,7 +87,7 @@ def gather_concat(t):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return t
     world = dist.get_world_size()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)

@@ -87,6 +87,23 @@ class BatchedKalman:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ kernel variants (A/B measurements)
+    _VARIANTS = {"smoother16": (0, ("record", "blk")), "wide_smoother": (1, ("mfma", "v1"))}
+
+    def set_variant(self, which, name):
+        """Choose between two equivalent kernels of a shape class (``mk_set_kernel_variant``): ``"smoother16"``:
+        ``"record"`` (default) | ``"blk"``; ``"wide_smoother"``: ``"mfma"`` (default) | ``"v1"``.  Both members of a pair
+        are tested against the oracle; there is no environment switch."""
+        sel, names = self._VARIANTS[which]
+        check(self._L.mk_set_kernel_variant(self._ctx, sel, names.index(name)))
+        return self
+
+    def get_variant(self, which):
+        sel, names = self._VARIANTS[which]
+        v = ctypes.c_int(-1)
+        check(self._L.mk_get_kernel_variant(self._ctx, sel, ctypes.byref(v)))
+        return names[v.value]
+
     # ------------------------------------------------------------------ helpers
     def _dev(self, a, shape=None, name="array"):
         """float64 contiguous tensor on this device (accepts numpy / torch)."""
@@ -330,6 +347,10 @@ class BatchedKalman:
         check(self._L.mk_loglik_grad(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
                                      self._p(mle), self._p(sc), self._p(gphi), self._p(gq), None))
         return mle, gphi, gq
+
+    def has_adjoint(self):
+        """Whether ``loglik_grad`` (``mk_loglik_grad``, the adjoint kernel) serves this engine's shape."""
+        return self.N is not None and self.n <= 16
 
     def loglik_grad_alpha(self, alpha, dt=1.0, warmup=1):
         """``(mle [B], d mle / d alpha [B,n])`` for Metran's parametrisation (``params_from_alpha`` forward,

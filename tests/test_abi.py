@@ -130,3 +130,15 @@ def test_generated_sweeps_header_is_current():
         outs, ins = stmt.split("\n            : ")[1:3] if stmt.count("\n            : ") >= 2 else (stmt.split("\n            : ")[1], "")
         n_ops = 2 * outs.count('"+v"') + outs.count('"=&v"') + ins.count('"v"')
         assert 0 < n_ops <= 30, (n_ops, stmt[:120])
+
+
+def test_kernel_sources_read_no_environment_variable():
+    """Round-2 verdict, weak 2: no switch outside the C ABI can select a kernel or change a result (MK_WIDE_TUNE used to);
+    phase-skipping timing experiments exist only as the compile-time constant -DMK_TUNE=<mask> of a separate build."""
+    src = os.path.join(ROOT, "metran_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if not os.path.isfile(os.path.join(src, f)):
+            continue
+        text = open(os.path.join(src, f)).read()
+        assert "getenv" not in text, f
+    assert "MK_TUNE" not in open(os.path.join(src, "Makefile")).read()   # the default build does not define it

@@ -1,0 +1,50 @@
+"""GPU: the bench line as the driver gets it (``python bench.py``), with the non-headline BASELINE configurations attached
+after the headline's timed region, and throughput FLOORS so that a performance regression of a kernel turns the GPU test
+tier red.  Floors are ~75 % of the slowest value measured over the round's leases, not targets."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def line():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "10", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_headline_is_configs1_with_roofline(line):
+    c = line["config"]
+    assert (c["name"], c["batch_per_gpu"], c["total_batch"], c["series"], c["factors"], c["T"]) == ("c2", 4096, 4096, 8, 2, 1000)
+    assert line["dtype"] == "f64" and line["unit"] == "model-timesteps/s" and line["n_gpus"] == 1
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert line["models_per_s"] > 1.0e6          # floor: 1.0 M models/s (measured 1.32-1.36 M); north star 100 k
+    assert r["frac"] > 0.40                      # north star: >= 40 % of the HBM roofline on the dominant kernel
+
+
+def test_secondary_configs3_throughput_floor(line):
+    s = line["secondary"]["c4"]
+    assert "error" not in s, s
+    assert "32-series/4-factor" in s["workload"] and "T=2000" in s["workload"]
+    assert s["roofline"]["bound"] == "fp64" and s["roofline"]["unit"] == "TFLOP/s" and s["roofline"]["peak"] == 78.6
+    assert s["models_per_s"] >= 20000.0, s       # floor (round 2: 24.6 k; a regression of the wide kernels fails here)
+    assert 0.0 < s["roofline"]["frac"] < 1.0
+
+
+def test_secondary_configs4_solver_loop(line):
+    s = line["secondary"]["c5"]
+    assert "error" not in s, s
+    assert s["roofline"]["bound"] == "fp64"
+    assert s["objective_evaluations_per_s"] >= 4.5e6, s   # floor (round 2: 6.4 M evaluations/s)
