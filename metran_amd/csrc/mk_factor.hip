@@ -364,6 +364,11 @@ __global__ void __launch_bounds__(64) fa_minres_kernel(long B, long R, int N, in
 // communality, rotated (varimax: _rotate with gamma = 1, maxiter = 20, tol = 1e-6, :146-171) and scaled back;
 // columns whose sum is negative change sign.  In place on loadings [B,N,KMAX].
 // svd(M) of the K x K step: M^T M = W diag(s^2) W^T  =>  R = u vh = M W diag(1/s) W^T, d = sum(s).
+// Where a singular value is exactly 0 the polar factor is not unique; numpy's u vh completes it with LAPACK's bases of
+// the null spaces.  Here: the identity on the null space (+ w_j w_j^T), which is what LAPACK returns in the two ways
+// an EXACT zero arises -- M = 0 (u = vh = I: a loading matrix whose only non-zero column has unit-normalised entries
+// +-1, fixture mv1 of factor_multi.npz) and zero columns of the loadings (zero rows AND columns of M: the completion
+// only ever multiplies those zero columns).
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) fa_rotate_kernel(long B, int N, int KMAX, const long long *nfact, double *loadings,
                                                        double gamma, int maxiter, double tol)
@@ -435,6 +440,7 @@ __global__ void __launch_bounds__(64) fa_rotate_kernel(long B, int N, int KMAX, 
                     double mw = 0.0;
                     for (int r = 0; r < k; ++r) mw += M[a * k + r] * W[r * k + j];
                     if (sj > 0.0) v += mw / sj * W[c * k + j];
+                    else v += W[a * k + j] * W[c * k + j]; // null direction of M: see below
                 }
                 Rm[i] = v;
             }
