@@ -46,7 +46,7 @@ EVALS_PER_STEP = 50  # c5: "50 parameter evaluations x batch=8192"
 def kernel_source_sha():
     """Identity of the kernels a PMC profile belongs to (stamped into profiles/*/pmc_hbm.json)."""
     h = hashlib.sha256()
-    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_wide.hip", "metran_amd/csrc/mk_prims.h",
+    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_wide.hip", "metran_amd/csrc/mk_split.hip", "metran_amd/csrc/mk_prims.h",
               "metran_amd/csrc/mk_sweeps.h", "metran_amd/csrc/mk_internal.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]

@@ -426,6 +426,7 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     const int rec = records_filter(p, o);
     if (rec < 0) return rec;
     mk::FilterArgs a;
+    a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER] ? 1 : 0;
     a.rs = rec ? o->record_stride : 0;
     a.sym = (rec && (o->flags & MK_OUT_PACKED_SYM)) ? 1 : 0;
     // dense sigmas/detfs are [B,T] (stride 1); inside filtered records they are RS doubles apart

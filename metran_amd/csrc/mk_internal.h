@@ -33,6 +33,7 @@ struct FilterArgs {
     long long *sigmacount;
     double *F, *Pf, *Xp, *Pp;
     unsigned *status;
+    long variant;        // bit 0: wide models keep filter_kernel<N,K,64> (one state per lane) instead of the split layout
 };
 
 // Timing experiments that skip phases of a kernel (and so produce wrong numbers) exist only in builds made with
@@ -83,6 +84,8 @@ struct SparseArgs { // objective of ONE record (all instances share it), observe
 };
 
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);
+// mk_split.hip: wide models, N series on the lanes + replicated factor block (hipErrorNotSupported: not served)
+hipError_t launch_filter_split(int N, int K, const FilterArgs &a, hipStream_t s);
 hipError_t launch_sparse(int N, int K, const SparseArgs &a, hipStream_t s);
 hipError_t launch_adjoint(int N, int K, const AdjointArgs &a, hipStream_t s);
 hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,

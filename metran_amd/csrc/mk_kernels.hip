@@ -1871,6 +1871,12 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     const unsigned grid = (unsigned)((a.B + GPB - 1) / GPB);
     const bool book = a.sigmas || a.detfs;
     const bool any = a.F || a.Pf || a.Xp || a.Pp;
+    if constexpr (n > 16 && N <= 32) { // wide models: several per wavefront in the split layout (mk_split.hip)
+        if (!(a.variant & 1)) {
+            const hipError_t e = launch_filter_split(N, K, a, s);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
     if (!any && !book)
         hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false, false>), dim3(grid), dim3(256), 0, s, a);
     else if (!any)
@@ -1965,6 +1971,7 @@ void get_shape(int i, int *N, int *K);
 #ifdef MK_SHAPE_MODULE
 } // namespace mk
 #include "mk_wide.hip" // one translation unit per run-time shape module
+#include "mk_split.hip"
 namespace mk {
 // ---------------------------------------------------------------------------------------------
 // Shape module: this same translation unit compiled at run time for ONE (N, K) that is not in the

@@ -88,7 +88,8 @@ class BatchedKalman:
             pass
 
     # ------------------------------------------------------------------ kernel variants (A/B measurements)
-    _VARIANTS = {"smoother16": (0, ("record", "blk")), "wide_smoother": (1, ("mfma", "v1"))}
+    _VARIANTS = {"smoother16": (0, ("record", "blk")), "wide_smoother": (1, ("mfma", "v1")),
+                 "wide_filter": (2, ("split", "lane_per_state"))}
 
     def set_variant(self, which, name):
         """Choose between two equivalent kernels of a shape class (``mk_set_kernel_variant``): ``"smoother16"``:

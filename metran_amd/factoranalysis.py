@@ -35,6 +35,7 @@ reference calls (one batched ``numpy.linalg.eig`` on the host) for the ORDER onl
 eigenvalues -- and ``mk_fa_minres`` builds the loadings from the device's own decomposition of those pairs.
 """
 import logging
+import os
 import queue
 import threading
 
@@ -64,12 +65,28 @@ def eig_order(corr, psi, kmax):
     out = np.tile(np.arange(kmax, dtype=np.int64), (B, 1))
     good = np.isfinite(sstar).all(axis=(1, 2))
     if good.any():
-        w = np.linalg.eig(sstar[good])[0].real
+        w = _eigvals_of_eig(sstar[good])
         pos = np.argsort(-w, axis=1, kind="stable")
         rank = np.empty_like(pos)
         np.put_along_axis(rank, pos, np.broadcast_to(np.arange(N), pos.shape), axis=1)
         out[good] = rank[:, :kmax]
     return out
+
+
+def _eigvals_of_eig(mats):
+    """``numpy.linalg.eig(mats)[0].real`` for a stack of matrices, the stack split over host threads (LAPACK releases
+    the GIL; at R = 4096 this call was 3/4 of ``FactorAnalysisBatch.solve`` on one core).  Each matrix goes through the
+    same dgeev call as in the reference, so the ORDER of the eigenvalues -- the only thing used -- is the same."""
+    B = mats.shape[0]
+    workers = min(16, os.cpu_count() or 1, max(1, B // 64))
+    if workers <= 1:
+        return np.linalg.eig(mats)[0].real
+    from concurrent.futures import ThreadPoolExecutor
+
+    bounds = np.linspace(0, B, workers + 1).astype(int)
+    with ThreadPoolExecutor(workers) as pool:
+        parts = list(pool.map(lambda i: np.linalg.eig(mats[bounds[i]:bounds[i + 1]])[0].real, range(workers)))
+    return np.concatenate(parts, axis=0)
 
 
 class FactorResult(dict):
