@@ -208,7 +208,8 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *prob, double *d_mle);
  * records into d_work (n_instances*T*mk_record_stride(n) doubles; time_major as in mk_outputs);
  * backward: the adjoint kernel re-reads them once.  d_gphi / d_gq [B,n] receive
  * d(-2 log L)/d diag(Phi) and /d diag(Q); d_mle [B], d_sigmacount [B] as in mk_filter; d_status may be
- * NULL.  N+K <= 16 (MK_ERR_SHAPE otherwise: difference mk_loglik instead). */
+ * NULL.  N+K <= 16: four models per wavefront (adjoint_kernel); 16 < N+K <= 64: one model per wavefront
+ * (adjoint_wide_kernel, mk_split.hip) -- at configs[3]'s shape one gradient instead of 37 differenced filter runs. */
 MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *prob, double *d_work, int time_major,
                           double *d_mle, int64_t *d_sigmacount, double *d_gphi, double *d_gq,
                           uint32_t *d_status);

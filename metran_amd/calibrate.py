@@ -39,7 +39,7 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     ``alpha0`` and ``pmin`` are Metran's initial value and lower bound (metran/metran.py:446-462).
     ``gradient``: "fd" = the reference's forward differences ((n+1)*R filter instances per gradient),
     "adjoint" = ``BatchedKalman.loglik_grad_alpha`` (one forward + one backward launch over R instances,
-    exact to rounding; state dimension <= 16), "auto" = adjoint where available.
+    exact to rounding), "auto" = adjoint where available (every supported shape).
     ``compact``: models converge after very different numbers of iterations (8192 synthetic models: half within 25, the
     last one after 140), and a lock-step launch costs the same whether a model still moves or not; whenever the active
     models are fewer than ``compact`` x the models in flight (and more than ``compact_min`` are in flight), the active
@@ -68,7 +68,7 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     active_all = torch.zeros(R, dtype=torch.bool, device=dev)
 
     if gradient == "auto":
-        gradient = "adjoint" if n <= 16 else "fd"
+        gradient = "adjoint" if kf.has_adjoint() else "fd"
     if gradient not in ("fd", "adjoint"):
         raise ValueError("gradient must be 'auto', 'fd' or 'adjoint'")
     grad_mode = gradient                              # may switch to "fd" for a small flight (fd_below); the request stays

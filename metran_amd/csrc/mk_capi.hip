@@ -636,9 +636,6 @@ MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *p, double *d_work, 
     if (!d_work || !d_mle || !d_sigmacount || !d_gphi || !d_gq)
         return fail(MK_ERR_INVALID, "mk_loglik_grad: d_work, d_mle, d_sigmacount, d_gphi and d_gq are required");
     const int64_t n = p->N + p->K;
-    if (n > 16)
-        return fail(MK_ERR_SHAPE, "mk_loglik_grad: the adjoint kernel covers N+K <= 16 (got %lld); use finite "
-                                        "differences over mk_loglik for wider models", (long long)n);
     // forward pass: filtered records only (+ per-step bookkeeping in the record pads), objective, step count
     mk_outputs o;
     memset(&o, 0, sizeof(o));

@@ -86,6 +86,7 @@ struct SparseArgs { // objective of ONE record (all instances share it), observe
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);
 // mk_split.hip: wide models, N series on the lanes + replicated factor block (hipErrorNotSupported: not served)
 hipError_t launch_filter_split(int N, int K, const FilterArgs &a, hipStream_t s);
+hipError_t launch_adjoint_wide(int N, int K, const AdjointArgs &a, hipStream_t s); // mk_split.hip: n > 16
 hipError_t launch_sparse(int N, int K, const SparseArgs &a, hipStream_t s);
 hipError_t launch_adjoint(int N, int K, const AdjointArgs &a, hipStream_t s);
 hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, const double *loadings, double dt,

@@ -2085,7 +2085,7 @@ static hipError_t launch_adjoint_nk(const AdjointArgs &a, hipStream_t s)
         hipLaunchKernelGGL((adjoint_kernel<N, K, 16>), dim3((unsigned)((a.B + GPB - 1) / GPB)), dim3(256), 0, s, a);
         return hipGetLastError();
     } else {
-        return hipErrorNotSupported; // wide models keep the finite-difference gradient
+        return launch_adjoint_wide(N, K, a, s); // one model per wavefront: mk_split.hip
     }
 }
 #define MK_CASE_ADJOINT(NN, KK) \

@@ -496,3 +496,362 @@ hipError_t launch_filter_split(int N, int K, const FilterArgs &a, hipStream_t s)
 }
 
 } // namespace mk
+
+namespace mk {
+
+// =====================================================================================
+// Reverse-mode (adjoint) gradient of -2 log L for WIDE models (16 < n <= 64), one model per wavefront, lane r = state r.
+//   The same backward walk as adjoint_kernel (mk_kernels.hip; formulas there and in tests/adjoint_ref.py): per step the
+//   filtered record of step t-1 is re-read, the prediction and the scalar updates of step t are recomputed keeping
+//   (d, 1/f, v) of every update -- here in a wave-private LDS table, whose rows also serve as the broadcast source of the
+//   rank-one update -- and the adjoints (xb, Pb) are pulled back through them, last observation first.  What the 16-lane
+//   kernel does with fused DPP broadcasts is done with group-uniform LDS reads (b = Pb d, Pb += z db^T / 2), two DPP tree
+//   sums per update (a = xb.d, c = d.b) and jump tables for the run-time column j (P[r][j], Pb[r][j] += db_r / 2).
+//   Registers: the rows of Pb and of P (which doubles as the prefetch buffer of the next record); the filtered row of
+//   step t-1, needed again by the prediction adjoint, waits in LDS.  The reference has no counterpart: scipy differences
+//   n + 1 filter runs (metran/solver.py:248-255) -- 37 of them at configs[3]'s shape.
+// =====================================================================================
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, result in every lane: xor-1, xor-2 inside the quads, half-row and row mirrors, then the four
+// row sums through readlanes
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_perm_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_perm_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_perm_f64<0x141>(v); // row_half_mirror
+    v += dpp_perm_f64<0x140>(v); // row_mirror
+    using G64 = Group<64>;
+    return (G64::bcast<0>(v) + G64::bcast<16>(v)) + (G64::bcast<32>(v) + G64::bcast<48>(v));
+}
+
+// p[j - BASE] += h for a wavefront-uniform j in [BASE, BASE + 16) (jump table, 12 bytes per case: v_add_f64 + s_branch)
+template <int BASE>
+__device__ __forceinline__ void add16(int j, double h, double &p0, double &p1, double &p2, double &p3, double &p4, double &p5,
+                                      double &p6, double &p7, double &p8, double &p9, double &p10, double &p11, double &p12,
+                                      double &p13, double &p14, double &p15)
+{
+    int t;
+    asm volatile("s_sub_i32 %[t], %[j], %[base]\n\t"
+                 "s_cmp_lt_u32 %[t], 16\n\t"
+                 "s_cbranch_scc0 .Ladd_end_%=\n\t"
+                 "s_mul_i32 %[t], %[t], 12\n\t"
+                 "s_add_u32 %[t], %[t], 12\n\t"
+                 "s_getpc_b64 vcc\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_setpc_b64 vcc\n\t"
+                 "v_add_f64 %[p0], %[p0], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p1], %[p1], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p2], %[p2], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p3], %[p3], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p4], %[p4], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p5], %[p5], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p6], %[p6], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p7], %[p7], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p8], %[p8], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p9], %[p9], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p10], %[p10], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p11], %[p11], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p12], %[p12], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p13], %[p13], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p14], %[p14], %[h]\n\ts_branch .Ladd_end_%=\n\t"
+                 "v_add_f64 %[p15], %[p15], %[h]\n\t"
+                 ".Ladd_end_%=:"
+                 : [t] "=&s"(t), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [p4] "+v"(p4), [p5] "+v"(p5),
+                   [p6] "+v"(p6), [p7] "+v"(p7), [p8] "+v"(p8), [p9] "+v"(p9), [p10] "+v"(p10), [p11] "+v"(p11),
+                   [p12] "+v"(p12), [p13] "+v"(p13), [p14] "+v"(p14), [p15] "+v"(p15)
+                 : [j] "s"(j), [base] "n"(BASE), [h] "v"(h)
+                 : "vcc", "scc");
+}
+template <int N, int n>
+__device__ __forceinline__ void add_column(int j, double h, double (&P)[n])
+{
+    static_assert(N <= 64 && n >= 16, "wide models");
+    double dump = 0.0; // cases beyond N - 1 are never selected (j < N)
+#define MK_AE(i) ((i) < N ? P[(i) < N ? (i) : 0] : dump)
+    sfor<0, (N + 15) / 16>(MK_LAMBDA(bb) {
+        constexpr int B0 = 16 * decltype(bb)::value;
+        add16<B0>(j, h, MK_AE(B0 + 0), MK_AE(B0 + 1), MK_AE(B0 + 2), MK_AE(B0 + 3), MK_AE(B0 + 4), MK_AE(B0 + 5), MK_AE(B0 + 6),
+                  MK_AE(B0 + 7), MK_AE(B0 + 8), MK_AE(B0 + 9), MK_AE(B0 + 10), MK_AE(B0 + 11), MK_AE(B0 + 12), MK_AE(B0 + 13),
+                  MK_AE(B0 + 14), MK_AE(B0 + 15));
+    });
+#undef MK_AE
+}
+// all lanes: dst = P[j], wavefront-uniform j < N <= 64
+template <int N, int n>
+__device__ __forceinline__ void pick_column_all(double &dst, int j, const double (&P)[n])
+{
+#define MK_PE(i) P[(i) < N ? (i) : N - 1]
+    sfor<0, (N + 15) / 16>(MK_LAMBDA(bb) {
+        constexpr int B0 = 16 * decltype(bb)::value;
+        pick16<B0, ~0ull>(dst, j, MK_PE(B0 + 0), MK_PE(B0 + 1), MK_PE(B0 + 2), MK_PE(B0 + 3), MK_PE(B0 + 4), MK_PE(B0 + 5),
+                          MK_PE(B0 + 6), MK_PE(B0 + 7), MK_PE(B0 + 8), MK_PE(B0 + 9), MK_PE(B0 + 10), MK_PE(B0 + 11),
+                          MK_PE(B0 + 12), MK_PE(B0 + 13), MK_PE(B0 + 14), MK_PE(B0 + 15));
+    });
+#undef MK_PE
+}
+
+template <int N, int K>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) adjoint_wide_kernel(AdjointArgs a)
+{
+    constexpr int n = N + K;
+    static_assert(n > 16 && n <= 64, "one model per wavefront, 16 < n <= 64");
+    using Gp = Group<64>;
+    constexpr int NP = n + (n & 1);
+    constexpr int DS = NP + 2;                  // one update: d [n] (+ pad), 1/f, v
+    constexpr int GT = (N * K + 1) & ~1;
+    constexpr int DB = 12, NBT = (n + DB - 1) / DB; // uniform LDS vectors are read in pieces of DB doubles
+    const int lane = threadIdx.x;
+    long inst = (long)blockIdx.x;
+    const bool live = inst < a.B;
+    if (!live) inst = a.B - 1;
+    const long rec = inst % a.R;
+    const int r = lane < n ? lane : n - 1;      // lanes >= n replicate lane n-1 (and contribute nothing to the sums)
+    const double lmask = lane < n ? 1.0 : 0.0;
+    const long T = a.T;
+
+    __shared__ __attribute__((aligned(16))) double lds[NP + GT + N * DS + n * NP + NP];
+    double *phim = lds;                         // diag(Phi)
+    double *gtab = phim + NP;                   // loadings [N][K]
+    double *dS = gtab + GT;                     // per-update table of the current step
+    double *PL = dS + N * DS;                   // filtered covariance of step t-1, row r at PL + r NP
+    double *dbv = PL + n * NP;                  // db of the current update
+
+    const double phi_r = a.phi[inst * n + r];
+    const double q_r = a.q[inst * n + r];
+    const int jr = lane < N ? lane : N - 1;
+    double gam[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
+    const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
+    phim[r] = phi_r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) gtab[jr * K + k] = gam[k];
+    wave_lds_sync();
+    const long sctot = a.sigmacount[inst];      // observed steps in total (written by the forward filter)
+    long rem = 0;                               // observed steps already walked (from the end)
+
+    const long RS = a.rs;
+    const double *recbase = a.F + inst * a.bs * RS;
+    const long rstep = a.ts * RS;
+    const double *obase = a.obs + rec * a.obs_bs * N + jr;
+    const long ostep = a.obs_ts * N;
+
+    // uniform LDS vector `src` in pieces, one piece ahead of its use: body(c, value)
+    auto sweep = [&](const double *src, auto body) __attribute__((always_inline)) {
+        double cur[DB], nxt[DB];
+        auto fetch = [&](auto bb, double(&dst)[DB]) __attribute__((always_inline)) {
+            constexpr int c0 = DB * decltype(bb)::value;
+#pragma unroll
+            for (int i = 0; i < DB; i += 2)
+                if (c0 + i < n) {
+                    const v2d t2 = *reinterpret_cast<const v2d *>(src + c0 + i);
+                    dst[i] = t2.x;
+                    dst[i + 1] = t2.y;
+                }
+        };
+        fetch(std::integral_constant<int, 0>{}, cur);
+        sfor<0, NBT>(MK_LAMBDA(bb) {
+            constexpr int b = decltype(bb)::value, c0 = DB * b;
+            if constexpr (b + 1 < NBT) fetch(std::integral_constant<int, b + 1>{}, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            sfor<0, DB>(MK_LAMBDA(ii) {
+                constexpr int c = c0 + decltype(ii)::value;
+                if constexpr (c < n) body(std::integral_constant<int, c>{}, cur[decltype(ii)::value]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (b + 1 < NBT) {
+#pragma unroll
+                for (int i = 0; i < DB; ++i) cur[i] = nxt[i];
+            }
+        });
+    };
+
+    double xb = 0.0, Pb[n], gphi = 0.0, gq = 0.0;
+#pragma unroll
+    for (int c = 0; c < n; ++c) Pb[c] = 0.0;
+    double xn, P[n]; // filtered moments of step t-1 (prefetched), then the running covariance row of step t
+    auto load_prev = [&](long t) __attribute__((always_inline)) {
+        if (t > 0) {
+            const double *p = recbase + (t - 1) * rstep;
+            xn = p[r];
+            load_cols<n>(p + n + r, P);
+        } else { // run_filter defaults (kalmanfilter.py:747-750) or the caller's initial state
+            xn = a.x0 ? a.x0[inst * n + r] : 0.0;
+            int rv0 = r; // opaque: the identity row is built HERE (hoisted out of the time loop it is n spilled doubles)
+            asm volatile("" : "+v"(rv0));
+#pragma unroll
+            for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == rv0 ? 1.0 : 0.0);
+        }
+    };
+    load_prev(T - 1);
+
+    for (long t = T - 1; t >= 0; --t) {
+        const double xprev = xn;
+        const double y = obase[t * ostep];
+        wave_lds_sync(); // the previous step's reads of PL are complete
+        store_row<n>(PL + r * NP, P);
+        const unsigned long long vm = __ballot(lane < N && isfinite(y));
+        if (vm != 0) {
+            const double w = (sctot - rem - 1 >= a.warmup) ? 1.0 : 0.0; // compressed index of this step (:563-564)
+            ++rem;
+            // ---- forward: prediction and scalar updates of step t, as the filter ----
+            double x = phi_r * xprev;
+            {
+                int rv = r;
+                double qv = q_r;
+                asm volatile("" : "+v"(rv), "+v"(qv));
+                sweep(phim, [&](auto cc, double ph) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    P[c] = fma(P[c] * phi_r, ph, c == rv ? qv : 0.0);
+                });
+            }
+            int cnt = 0;
+            for (unsigned long long m = vm; m; m &= m - 1) {
+                const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
+                double vl = y - x;
+                sfor<0, K>(MK_LAMBDA(k) { vl = fma(-gam[decltype(k)::value], Gp::template bcast<N + decltype(k)::value>(x), vl); });
+                const double v = readlane_f64(vl, j);
+                double dr = 0.0;
+                pick_column_all<N, n>(dr, j, P);
+                const double *gp = gtab + j * K;
+                sfor<0, K>(MK_LAMBDA(k) { dr = fma(P[N + decltype(k)::value], gp[decltype(k)::value], dr); });
+                double *drow = dS + cnt * DS;
+                drow[r] = dr;
+                double fl = rvar + dr;
+                sfor<0, K>(MK_LAMBDA(k) { fl = fma(Gp::template bcast<N + decltype(k)::value>(dr), gam[decltype(k)::value], fl); });
+                const double f = readlane_f64(fl, j);
+                const double rf = rcp_nr(f);
+                const double kr = dr * rf;
+                *reinterpret_cast<v2d *>(drow + NP) = v2d{rf, v}; // the same value from every lane
+                wave_lds_sync();
+                sweep(drow, [&](auto cc, double dcv) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    P[c] = fma(-dcv, kr, P[c]);
+                });
+                x = fma(kr, v, x);
+                ++cnt;
+            }
+            // ---- reverse: adjoints back through the updates, last observation first ----
+            unsigned long long mm = vm;
+            for (int u = cnt - 1; u >= 0; --u) {
+                const int j = __builtin_amdgcn_readfirstlane(63 - (int)__builtin_clzll(mm));
+                mm &= ~(1ull << j);
+                const double *drow = dS + u * DS;
+                const double dr = drow[r];
+                const v2d rv2 = *reinterpret_cast<const v2d *>(drow + NP);
+                const double rf = rv2.x, v = rv2.y;
+                double b0 = 0.0, b1 = 0.0;
+                sweep(drow, [&](auto cc, double dcv) __attribute__((always_inline)) { // b_r = sum_c Pb[r][c] d_c
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (c % 2 == 0) b0 = fma(Pb[c], dcv, b0);
+                    else b1 = fma(Pb[c], dcv, b1);
+                });
+                const double b = b0 + b1;
+                const double asum = wave_sum_f64(lmask * (xb * dr)); // a = xb . d
+                const double csum = wave_sum_f64(lmask * (dr * b));  // c = d . b
+                const double vrf = v * rf;
+                const double vbar = fma(2.0 * w, v, asum) * rf;
+                const double fbar = (fma(-w * v, vrf, w) - asum * vrf + csum * rf) * rf;
+                const double *gp = gtab + j * K;
+                double g[K];
+                sfor<0, K>(MK_LAMBDA(k) { g[decltype(k)::value] = gp[decltype(k)::value]; });
+                double zr = (r == j) ? 1.0 : 0.0; // element r of Z_j = e_j + sum_k loadings[j,k] e_{N+k}
+                sfor<0, K>(MK_LAMBDA(k) { zr = (r == N + decltype(k)::value) ? g[decltype(k)::value] : zr; });
+                const double dbar = fma(xb, vrf, fma(-2.0 * rf, b, fbar * zr));
+                xb = fma(-vbar, zr, xb);
+                const double hd = 0.5 * dbar, hz = 0.5 * zr;
+                dbv[r] = dbar;
+                add_column<N, n>(j, hd, Pb);                                  // Pb[r][j] += db_r / 2
+                sfor<0, K>(MK_LAMBDA(k) { Pb[N + decltype(k)::value] = fma(hd, g[decltype(k)::value], Pb[N + decltype(k)::value]); });
+                wave_lds_sync();
+                sweep(dbv, [&](auto cc, double dbc) __attribute__((always_inline)) { // Pb[r][c] += z_r db_c / 2
+                    constexpr int c = decltype(cc)::value;
+                    Pb[c] = fma(hz, dbc, Pb[c]);
+                });
+                wave_lds_sync(); // dbv is rewritten by the next update
+            }
+        }
+        // next record into the (now dead) P row: in flight during the prediction adjoint; this loop stores nothing
+        if (t > 0) load_prev(t - 1);
+        // ---- prediction adjoint (Pprev from LDS) ----
+        {
+            double diag = 0.0, ts0 = 0.0, ts1 = 0.0;
+            const double *prow = PL + r * NP;
+            int rv = r;
+            asm volatile("" : "+v"(rv));
+            // two vectors in step: diag(Phi) (uniform) and the lane's own row of Pf[t-1], both in pieces
+            double curA[DB], curB[DB], nxtA[DB], nxtB[DB];
+            auto fetch2 = [&](auto bb, double(&da)[DB], double(&db)[DB]) __attribute__((always_inline)) {
+                constexpr int c0 = DB * decltype(bb)::value;
+#pragma unroll
+                for (int i = 0; i < DB; i += 2)
+                    if (c0 + i < n) {
+                        const v2d ta = *reinterpret_cast<const v2d *>(phim + c0 + i);
+                        const v2d tb = *reinterpret_cast<const v2d *>(prow + c0 + i);
+                        da[i] = ta.x;
+                        da[i + 1] = ta.y;
+                        db[i] = tb.x;
+                        db[i + 1] = tb.y;
+                    }
+            };
+            fetch2(std::integral_constant<int, 0>{}, curA, curB);
+            sfor<0, NBT>(MK_LAMBDA(bb) {
+                constexpr int b = decltype(bb)::value, c0 = DB * b;
+                if constexpr (b + 1 < NBT) fetch2(std::integral_constant<int, b + 1>{}, nxtA, nxtB);
+                __builtin_amdgcn_sched_barrier(0);
+                sfor<0, DB>(MK_LAMBDA(ii) {
+                    constexpr int i = decltype(ii)::value, c = c0 + i;
+                    if constexpr (c < n) {
+                        diag = (c == rv) ? Pb[c] : diag;
+                        const double t1 = Pb[c] * curA[i];      // Pb[r][c] phi_c
+                        if constexpr (c % 2 == 0) ts0 = fma(t1, curB[i], ts0);
+                        else ts1 = fma(t1, curB[i], ts1);
+                        Pb[c] = t1 * phi_r;
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (b + 1 < NBT) {
+#pragma unroll
+                    for (int i = 0; i < DB; ++i) {
+                        curA[i] = nxtA[i];
+                        curB[i] = nxtB[i];
+                    }
+                }
+            });
+            gq += diag;
+            gphi = fma(xb, xprev, fma(2.0, ts0 + ts1, gphi));
+            xb *= phi_r;
+        }
+    }
+    if (live && lane < n) {
+        if (a.gphi) a.gphi[inst * n + lane] = gphi;
+        if (a.gq) a.gq[inst * n + lane] = gq;
+    }
+}
+
+template <int N, int K>
+static hipError_t launch_adjoint_wide_nk(const AdjointArgs &a, hipStream_t s)
+{
+    if constexpr (N + K > 16) {
+        hipLaunchKernelGGL((adjoint_wide_kernel<N, K>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+#define MK_CASE_ADJW(NN, KK) \
+    if (N == NN && K == KK) return launch_adjoint_wide_nk<NN, KK>(a, s);
+hipError_t launch_adjoint_wide(int N, int K, const AdjointArgs &a, hipStream_t s)
+{
+    MK_SHAPES(MK_CASE_ADJW)
+    return hipErrorNotSupported;
+}
+
+} // namespace mk

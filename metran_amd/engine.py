@@ -333,7 +333,7 @@ class BatchedKalman:
         ``gphi = d(-2 log L)/d phi``, ``gq = d(-2 log L)/d q`` in two launches (forward filter writing the
         filtered records into a workspace that is kept between calls, then the backward adjoint kernel).
         The reference has no gradient (metran/solver.py:248-255 leaves scipy to difference P+1 runs).
-        State dimension n <= 16; wider models raise (difference ``loglik`` instead)."""
+        Any supported shape: four models per wavefront for n <= 16, one per wavefront for 16 < n <= 64."""
         torch = _torch()
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         need = B * self.T * self.record_stride()
@@ -350,8 +350,9 @@ class BatchedKalman:
         return mle, gphi, gq
 
     def has_adjoint(self):
-        """Whether ``loglik_grad`` (``mk_loglik_grad``, the adjoint kernel) serves this engine's shape."""
-        return self.N is not None and self.n <= 16
+        """Whether ``loglik_grad`` (``mk_loglik_grad``) serves this engine's shape: ``adjoint_kernel`` for n <= 16 (four
+        models per wavefront), ``adjoint_wide_kernel`` for 16 < n <= 64 (one model per wavefront)."""
+        return self.N is not None and self.n <= 64
 
     def loglik_grad_alpha(self, alpha, dt=1.0, warmup=1):
         """``(mle [B], d mle / d alpha [B,n])`` for Metran's parametrisation (``params_from_alpha`` forward,

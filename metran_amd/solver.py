@@ -104,7 +104,7 @@ class HipSolve:
 
     def __init__(self, mt, gradient="fd", **kwargs):
         """``gradient="fd"`` (default) follows the reference's finite-difference path; ``"adjoint"`` hands
-        scipy the exact gradient from ``mk_loglik_grad`` (state dimension <= 16): the same optimum in ~6x
+        scipy the exact gradient from ``mk_loglik_grad``: the same optimum in ~6x
         fewer filter runs, but not the reference's iteration path."""
         if gradient not in ("fd", "adjoint"):
             raise ValueError("gradient must be 'fd' or 'adjoint'")

@@ -23,6 +23,11 @@ ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--batch", type=int, default=8192, help="models per GPU")
 ap.add_argument("--T", type=int, default=1000)
 ap.add_argument("--maxiter", type=int, default=200)
+ap.add_argument("--series", type=int, default=8)
+ap.add_argument("--factors", type=int, default=2)
+ap.add_argument("--missing", type=float, default=0.0)
+ap.add_argument("--gradient", default="auto", choices=["auto", "adjoint", "fd"],
+                help="fd = one launch of (n+1) x models differenced filter instances per gradient (what wide models had before round 3)")
 ap.add_argument("--fd-below", type=int, default=4096,
                 help="switch from the adjoint gradient to batched forward differences once (n+1) x active models <= this (0: never)")
 a = ap.parse_args()
@@ -45,18 +50,18 @@ from metran_amd.synthetic import make_dfm_batch_torch  # noqa: E402
 rank, world, local_rank = init_from_env()
 torch.cuda.set_device(local_rank)
 dev = torch.device("cuda", local_rank)
-N, K = 8, 2
+N, K = a.series, a.factors
 total = a.batch * world
 lo, hi = shard_range(total, rank, world)
-d = make_dfm_batch_torch(hi - lo, N, K, a.T, seed=5000 + rank, device=dev)
+d = make_dfm_batch_torch(hi - lo, N, K, a.T, seed=5000 + rank, device=dev, missing=a.missing)
 kf = BatchedKalman(local_rank, layout="time_major")
 kf.set_observations(d["obs"]).set_loadings(d["loadings"])
-calibrate_batch(kf, maxiter=2)  # warm-up (kernel load, allocator)
+calibrate_batch(kf, maxiter=2, gradient=a.gradient)  # warm-up (kernel load, allocator)
 torch.cuda.synchronize()
 if world > 1:
     torch.distributed.barrier()
 t0 = time.perf_counter()
-res = calibrate_sharded(total, lambda lo_, hi_: kf, maxiter=a.maxiter, fd_below=a.fd_below)  # this rank's engine holds exactly [lo, hi)
+res = calibrate_sharded(total, lambda lo_, hi_: kf, maxiter=a.maxiter, fd_below=a.fd_below, gradient=a.gradient)  # this rank's engine holds exactly [lo, hi)
 torch.cuda.synchronize()
 if world > 1:
     torch.distributed.barrier()
@@ -69,9 +74,11 @@ dt = float(dt.item())
 true_obj = kf.loglik(d["phi"], d["q"])
 ok_local = (res.obj[lo:hi] <= true_obj + 1e-6).double().mean()
 if rank == 0:
-    print(json.dumps({"workload": "calibrate_sharded: %d x (8 series, 2 factors) per GPU on %d GPU(s), T=%d, fp64" % (a.batch, world, a.T),
+    print(json.dumps({"workload": "calibrate_sharded: %d x (%d series, %d factors) per GPU on %d GPU(s), T=%d, %d %% missing, fp64" % (
+                          a.batch, N, K, world, a.T, round(100 * a.missing)),
                       "n_gpus": world, "models": int(res.alpha.shape[0]), "seconds": dt, "models_per_s": total / dt,
-                      "gradient": "adjoint" + (", forward differences once (n+1) x active models <= %d" % a.fd_below if a.fd_below else ""),
+                      "gradient": ("batched forward differences" if a.gradient == "fd" else
+                                   "adjoint" + (", forward differences once (n+1) x active models <= %d" % a.fd_below if a.fd_below else "")),
                       "iterations_rank0": int(res.nit), "nfev_all_ranks": int(nfev.item()), "evals_per_s": float(nfev.item()) / dt,
                       "converged_frac": float(res.converged.double().mean()),
                       "rank0_frac_at_or_below_true_parameter_objective": float(ok_local),
