@@ -40,10 +40,17 @@ def cache_dir():
     return d
 
 
+def _extra_flags():
+    """Extra hipcc flags for the shape modules (``METRAN_HIP_JIT_FLAGS``, build-time A/B measurements such as
+    ``-DMK_NO_TILED_SWEEPS``); part of the cache key."""
+    return os.environ.get("METRAN_HIP_JIT_FLAGS", "").split()
+
+
 def _source_hash():
     h = hashlib.sha256()
     for f in _SOURCES:
         h.update(open(f, "rb").read())
+    h.update(" ".join(_extra_flags()).encode())
     return h.hexdigest()[:16]
 
 
@@ -67,8 +74,8 @@ def build_shape_module(N, K):
         obj = os.path.join(tmp, "mod.o")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-DMK_SHAPE_MODULE",
-               "-DMK_SHAPES(X)=X(%d,%d)" % (N, K), "-save-temps=obj", "-Wno-unused-command-line-argument", "-c",
-               _SOURCES[0], "-o", obj]
+               "-DMK_SHAPES(X)=X(%d,%d)" % (N, K), "-save-temps=obj", "-Wno-unused-command-line-argument"] + _extra_flags() + [
+               "-c", _SOURCES[0], "-o", obj]
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         if r.returncode != 0:
             raise MetranHipError("hipcc failed for shape (%d,%d):\n%s" % (N, K, r.stderr[-2000:]))
