@@ -1,19 +1,20 @@
 #!/bin/bash
 # Box-side: the round's profiles.  For every bench configuration: rocprofv3 kernel-trace stats, HBM traffic from two
 # separate PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains), the bench line of the same
-# command; SQ counters for c2 and c4.  Everything lands in gpurun_out/prof_r02/ -- copy into profiles/r02/.
-#   bash scripts/collect_profiles.sh [configs...]        (default: c2 c2sym c3 c3sym c4 c5)
+# command; SQ counters for c2 and c4.  Everything lands in gpurun_out/prof_${ROUND}/ -- copy into profiles/${ROUND}/.
+#   ROUND=r03 bash scripts/collect_profiles.sh [configs...]        (default: c2 c3 c4 c5; c2sym / c3sym: packed-symmetric records)
 set -u
+ROUND=${ROUND:-r03}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02; mkdir -p $OUT
-CFGS="${@:-c2 c2sym c3 c3sym c4 c5}"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${ROUND}; mkdir -p $OUT
+CFGS="${@:-c2 c3 c4 c5}"
 for tag in $CFGS; do
   cfg=${tag%sym}; symflag=""; sym=0
   if [ "$tag" != "$cfg" ]; then symflag="--packed-sym"; sym=1; fi
   # the default bench.py run of each configuration (c2/c3: 50 timed + 10 warm-up steps -- the GPU needs ~10 launches after
   # idling to reach its steady clocks, scripts/probe_ramp.py; the kernel-trace averages include those warm-up launches)
   steps=50; warm=10; [ $cfg = c4 ] && steps=3 && warm=1; [ $cfg = c5 ] && steps=3 && warm=1
-  CMD="python $GRAFT_REPO_ROOT/bench.py --config $cfg $symflag --steps $steps --warmup $warm --no-cpu-baseline"
+  CMD="python $GRAFT_REPO_ROOT/bench.py --config $cfg $symflag --steps $steps --warmup $warm --no-cpu-baseline --no-secondary --no-live-traffic"
   cd /tmp
   rm -rf /tmp/kt /tmp/pf /tmp/pw
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $CMD > $OUT/${tag}_bench_under_rocprof.json 2> $OUT/${tag}_kt.err
@@ -34,8 +35,16 @@ for tag in $CFGS; do
     python scripts/pmc_extract.py /tmp/ps2 $OUT/pmc_sq_${tag}_b.json > /dev/null
   fi
   # the bench line of the plain command (with the CPU baselines for the headline configuration), reading the traffic just taken
-  mkdir -p profiles/r02; cp $OUT/pmc_hbm_${tag}.json profiles/r02/
+  mkdir -p profiles/${ROUND}; cp $OUT/pmc_hbm_${tag}.json profiles/${ROUND}/
   extra="--no-cpu-baseline"; [ $tag = c2 ] && extra=""
-  python bench.py --config $cfg $symflag $extra > $OUT/bench_${tag}.json 2> $OUT/bench_${tag}.err
+  python bench.py --config $cfg $symflag $extra --no-secondary > $OUT/bench_${tag}.json 2> $OUT/bench_${tag}.err
   echo "== $tag"; cat $OUT/${tag}_kernel_stats.csv | cut -c1-150; tail -c 400 $OUT/bench_${tag}.json | head -c 400; echo
 done
+# the default command as the driver runs it (headline + the secondary configurations), under kernel-trace and plain
+cd /tmp; rm -rf /tmp/ktd
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -- python $GRAFT_REPO_ROOT/bench.py --no-live-traffic > $OUT/default_bench_under_rocprof.json 2> $OUT/default_kt.err
+f=$(ls /tmp/ktd/*/*kernel_stats.csv 2>/dev/null | head -1)
+if [ -n "$f" ]; then head -1 $f > $OUT/default_kernel_stats.csv; grep "mk::" $f >> $OUT/default_kernel_stats.csv; fi
+cd $GRAFT_REPO_ROOT
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "== default"; cat $OUT/default_kernel_stats.csv | cut -c1-160

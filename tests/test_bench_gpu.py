@@ -32,6 +32,11 @@ def test_headline_is_configs1_with_roofline(line):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert line["models_per_s"] > 1.0e6          # floor: 1.0 M models/s (measured 1.32-1.36 M); north star 100 k
     assert r["frac"] > 0.40                      # north star: >= 40 % of the HBM roofline on the dominant kernel
+    # HBM traffic of the dominant kernel: measured in this very run (rocprofv3 PMC child passes), within the record
+    # pad of the algorithmic bytes
+    dom = r["kernels"][r["kernel"]]
+    assert dom["traffic_source"].startswith("measured in this run"), dom
+    assert 0.98 < r["traffic"] / r["algorithmic_bytes"] < 1.10
 
 
 def test_secondary_configs3_throughput_floor(line):
