@@ -236,6 +236,16 @@ smoother_wave_kernel(SmootherArgs a)
 // =====================================================================================
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// rows of L^T packed for the back substitution: row c holds L(k, c) for k = lt_kb(c) .. n-1 (lt_kb(c) = (c+1) & ~1: the
+// first pair starts at an even k, so rows are 16-byte aligned pairs), padded to an even count
+constexpr int lt_kb(int c) { return (c + 1) & ~1; }
+constexpr int lt_off(int n, int c)
+{
+    int s = 0;
+    for (int i = 0; i < c; ++i) s += (n - lt_kb(i) + 1) & ~1;
+    return s;
+}
+
 // EPI / SYM as in smoother_record_kernel: 0 records, 1 + projection, 2 + state means and variances; SYM: the
 // filtered (and smoothed) records are packed-symmetric
 template <int N, int K, int EPI, bool SYM>
@@ -252,8 +262,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // sweeps, then a 16-row staging buffer for J.  A full second n x LD matrix made the wavefront's share 22.4 KB:
     // 7 wavefronts per CU instead of the 8 its registers allow, and 4096 models = 2.3 rounds of 1792 instead of 2
     // of 2048 (measured at T = 500: 35.9 ms for 4096 models against 2 x 13.9 ms for 2 x 1792).
-    constexpr int USZ = tri_off(n), JSZ = 16 * LD, RSZ = USZ > JSZ ? USZ : JSZ;
-    using Gp = Group<G>;
+    constexpr int USZ = tri_off(n), JSZ = 16 * LD, LTSZ = lt_off(n, n - 1) + 2;
+    constexpr int RSZ = (USZ > JSZ ? USZ : JSZ) > LTSZ ? (USZ > JSZ ? USZ : JSZ) : LTSZ;
     const int lane = threadIdx.x;
     long inst = (long)blockIdx.x;
     const bool live = inst < a.B;
@@ -434,18 +444,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             z[c] = (s0 + s1) * ij;  // z~_c
         });
         wave_lds_sync();
-        // backward: x_c = z~_c - sum_{k>c} L(k,c) x_k, axpy form over the rows k = n-1 .. 1 of L.  Row k of L is
-        // what lane k still holds in A[] after the forward sweep: its elements reach every lane as readlane
-        // pairs (scalar operands of the multiply-add) -- no LDS traffic, which is what bounds this kernel
-        if (!MK_TUNE_SKIP(a, 2))
-        sfor_down<1, n>(MK_LAMBDA(kc) {
-            constexpr int k = decltype(kc)::value + 1; // n-1 .. 1
-            const double zk = z[k];
-            // batches of readlane pairs ahead of their multiply-adds (Group<64>::axpy_lane): one pair straight before its
-            // FMA costs an `s_nop 1` each (630 a step at n = 36; 113 -> 109 ms at configs[3]).  Rows of L written back to
-            // LDS and read at wavefront-uniform addresses instead (1 260 readlanes -> 190 LDS operations) measured the same.
-            Gp::template axpy_lane<k, 0, k, true, n>(z, A, zk);
-        });
+        // backward: x_c = z~_c - sum_{k>c} L(k,c) x_k.
+        // Round 3: DOT form over the columns c = n-2 .. 0 with L^T read back from LDS at wavefront-uniform addresses -- the
+        // lanes park their rows of L (A[c] = L(r,c), c < r) transposed in the region the forward sweep's U table has just
+        // left (row c of L^T: L(k,c) for k = kb(c) .. n-1, kb(c) = (c+1) & ~1 so that every 16-byte pair is aligned; 35
+        // exec-masked 8-byte stores), then every lane runs the same n(n-1)/2 multiply-adds on its own row of Z~ with
+        // operands that need no cross-lane instruction at all.  The axpy form it replaces broadcast every L(k,c) with a
+        // readlane pair: 1 260 VALU instructions a step next to the 630 multiply-adds.  All reads are independent of the
+        // results, so they run ahead of the multiply-adds in batches.
+        if (!MK_TUNE_SKIP(a, 2)) {
+            double *Lt = Um + lane; // element r of a row of L^T (lanes >= n: one past the row's last entry, never read)
+            sfor<0, n - 1>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;
+                lds_store_masked<(~0ull << (c + 1)) & (n < 64 ? (1ull << n) - 1 : ~0ull), 8 * (lt_off(n, c) - lt_kb(c))>(Lt, A[c]);
+            });
+            wave_lds_sync();
+            sfor_down<0, n - 1>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;           // n-2 .. 0
+                constexpr int kb = lt_kb(c), NPR = (n - kb + 1) / 2; // pairs (kb + 2p, kb + 2p + 1)
+                constexpr int PB = 6;
+                const double *row = Um + lt_off(n, c);
+                double b0 = z[c], b1 = 0.0;
+                sfor<0, (NPR + PB - 1) / PB>(MK_LAMBDA(bb) {
+                    constexpr int p0 = PB * decltype(bb)::value, p1 = p0 + PB < NPR ? p0 + PB : NPR;
+                    v2d buf[PB];
+#pragma unroll
+                    for (int p = p0; p < p1; ++p) buf[p - p0] = *reinterpret_cast<const v2d *>(row + 2 * p);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = p0; p < p1; ++p) {
+                        if (kb + 2 * p > c) b0 = fma(-buf[p - p0].x, z[kb + 2 * p], b0);
+                        if (kb + 2 * p + 1 > c && kb + 2 * p + 1 < n) b1 = fma(-buf[p - p0].y, z[kb + 2 * p + 1], b1);
+                    }
+                });
+                z[c] = b0 + b1;
+            });
+            wave_lds_sync(); // the reads of L^T are complete: the region becomes the J staging buffer
+        }
         // z = J[r, :]
         // smoothed mean (:461-464): xs[t] = F[t] + J delta, delta from LDS (uniform reads)
         {
