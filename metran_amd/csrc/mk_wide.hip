@@ -254,7 +254,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int n = N + K, G = 64;
     constexpr bool PROJ = (EPI == 1), VAR = (EPI == 2);
     static_assert(n > 16 && n <= G, "one model per wavefront, 16 < n <= 64");
-    constexpr int NB = (n + 15) / 16; // 16-wide tile rows / columns
+    // STR (round 3): the state is [N series | K factors]; when N is a multiple of 16 and K <= 4 the two products run their
+    // 16x16x4 tiles on the N x N series block only (K runs over all n: the factor rows are the last k-step) and the K-wide
+    // factor border on the vector pipe -- at n = 36 the tiles of the padded 48 x 48 problem spend 44 % of their multiply-adds
+    // on padding (135 tiles a step; 63 here)
+    constexpr bool STR = (N % 16 == 0) && (K <= 4) && !SYM;
+    constexpr int NB = STR ? N / 16 : (n + 15) / 16; // 16-wide tile rows / columns
     constexpr int KS = (n + 3) / 4;   // k-steps
     constexpr int LD = (n + 3) & ~1;  // LDS row stride: even (16-byte rows), n + 2 or n + 3
     constexpr int PADC = (n + 1) & ~1; // first of the (at least two) padding columns of a row of Dm: (phi_c, q_c)
@@ -377,9 +382,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         recU -= recUstep;
         const double xfc = *iF.vec;
         double A[n], z[n];
+        double pfb[STR ? K : 1]; // STR: Pf[r][N + k], the seeds of the border columns of Ps
         {
             double Pfc[n];
             load_pf_rows(Pfc);
+            if constexpr (STR) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) pfb[k] = Pfc[N + k];
+            }
             wave_lds_sync(); // previous iteration's reads of Dm / the J buffer are complete
             sfor<0, n / 2 + n % 2>(MK_LAMBDA(pp) { // two columns at a time; phi_c is a wavefront-uniform LDS read
                 constexpr int c0 = 2 * decltype(pp)::value;
@@ -413,24 +423,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (!MK_TUNE_SKIP(a, 4))
         sfor<0, n>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
-            constexpr int NPR = (c + 1) / 2; // pairs covering elements 0 .. c-1 (the last may reach the diagonal slot)
-            constexpr int PB = 4;            // pairs per batch of reads
+            constexpr int NR = (c + 15) / 16; // registers of 16 operands: lane 16 q + j holds U(c, 16 m + j) for every q
             const double *Uc = Um + tri_off(c);
+            double uc[NR > 0 ? NR : 1];
+            sfor<0, NR>(MK_LAMBDA(mm) {
+                constexpr int m = decltype(mm)::value;
+                if constexpr (16 * m + 15 < c) {
+                    uc[m] = Uc[16 * m + l15];
+                } else { // the row's last register: lanes beyond the diagonal re-read element c-1 (never broadcast)
+                    const int k = 16 * m + l15;
+                    uc[m] = Uc[k < c ? k : c - 1];
+                }
+            });
             double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
-            sfor<0, (NPR + PB - 1) / PB>(MK_LAMBDA(bb) {
-                constexpr int p0 = PB * decltype(bb)::value, p1 = p0 + PB < NPR ? p0 + PB : NPR;
-                v2d buf[PB];
-#pragma unroll
-                for (int p = p0; p < p1; ++p) buf[p - p0] = *reinterpret_cast<const v2d *>(Uc + 2 * p);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = p0; p < p1; ++p) {
-                    a0 = fma(-buf[p - p0].x, A[2 * p], a0);
-                    s0 = fma(-buf[p - p0].x, z[2 * p], s0);
-                    if (2 * p + 1 < c) {
-                        a1 = fma(-buf[p - p0].y, A[2 * p + 1], a1);
-                        s1 = fma(-buf[p - p0].y, z[2 * p + 1], s1);
-                    }
+            sfor<0, c>(MK_LAMBDA(kk) {
+                constexpr int k = decltype(kk)::value;
+                if constexpr (k % 2 == 0) {
+                    Group<16>::fmac<k % 16, true>(a0, uc[k / 16], A[k]);
+                    Group<16>::fmac<k % 16, true>(s0, uc[k / 16], z[k]);
+                } else {
+                    Group<16>::fmac<k % 16, true>(a1, uc[k / 16], A[k]);
+                    Group<16>::fmac<k % 16, true>(s1, uc[k / 16], z[k]);
                 }
             });
             const double u = a0 + a1;
@@ -461,21 +474,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             wave_lds_sync();
             sfor_down<0, n - 1>(MK_LAMBDA(cc) {
                 constexpr int c = decltype(cc)::value;           // n-2 .. 0
-                constexpr int kb = lt_kb(c), NPR = (n - kb + 1) / 2; // pairs (kb + 2p, kb + 2p + 1)
-                constexpr int PB = 6;
-                const double *row = Um + lt_off(n, c);
-                double b0 = z[c], b1 = 0.0;
-                sfor<0, (NPR + PB - 1) / PB>(MK_LAMBDA(bb) {
-                    constexpr int p0 = PB * decltype(bb)::value, p1 = p0 + PB < NPR ? p0 + PB : NPR;
-                    v2d buf[PB];
-#pragma unroll
-                    for (int p = p0; p < p1; ++p) buf[p - p0] = *reinterpret_cast<const v2d *>(row + 2 * p);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int p = p0; p < p1; ++p) {
-                        if (kb + 2 * p > c) b0 = fma(-buf[p - p0].x, z[kb + 2 * p], b0);
-                        if (kb + 2 * p + 1 > c && kb + 2 * p + 1 < n) b1 = fma(-buf[p - p0].y, z[kb + 2 * p + 1], b1);
+                constexpr int kb = lt_kb(c), M0 = (c + 1) / 16, M1 = (n + 15) / 16; // registers M0 .. M1-1 cover k = c+1 .. n-1
+                const double *row = Um + lt_off(n, c) - kb; // element k of the row sits at row[k], k = kb .. n-1
+                double lc[M1 - M0];
+                sfor<M0, M1>(MK_LAMBDA(mm) {
+                    constexpr int m = decltype(mm)::value;
+                    if constexpr (16 * m >= kb && 16 * m + 15 < n) {
+                        lc[m - M0] = row[16 * m + l15];
+                    } else { // lanes outside the row re-read its first / last element (never broadcast)
+                        int k = 16 * m + l15;
+                        k = k < kb ? kb : k;
+                        k = k > n - 1 ? n - 1 : k;
+                        lc[m - M0] = row[k];
                     }
+                });
+                double b0 = z[c], b1 = 0.0;
+                sfor<c + 1, n>(MK_LAMBDA(kk) { // k = n-1 .. c+1: z[c+1], the freshest operand, last
+                    constexpr int k = n + c - decltype(kk)::value;
+                    if constexpr (k % 2 == 0)
+                        Group<16>::fmac<k % 16, true>(b0, lc[k / 16 - M0], z[k]);
+                    else
+                        Group<16>::fmac<k % 16, true>(b1, lc[k / 16 - M0], z[k]);
                 });
                 z[c] = b0 + b1;
             });
@@ -485,26 +504,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // smoothed mean (:461-464): xs[t] = F[t] + J delta, delta from LDS (uniform reads)
         {
             double a0 = xfc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            constexpr int PB = 6; // pairs per batch (left alone, hipcc reads all n/2 pairs first and spills half of them)
-            sfor<0, (n / 2 + PB - 1) / PB>(MK_LAMBDA(bb) {
-                constexpr int p0 = PB * decltype(bb)::value, p1 = p0 + PB < n / 2 ? p0 + PB : n / 2;
-                v2d v[PB];
+            constexpr int M1 = (n + 15) / 16;
+            double dreg[M1]; // lane 16 q + j: delta[16 m + j] (dl has 64 entries; those >= n are finite replicas, never broadcast)
 #pragma unroll
-                for (int p = p0; p < p1; ++p) v[p - p0] = *reinterpret_cast<const v2d *>(dl + 2 * p);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = p0; p < p1; ++p) {
-                    if (p % 2 == 0) {
-                        a0 = fma(v[p - p0].x, z[2 * p], a0);
-                        a1 = fma(v[p - p0].y, z[2 * p + 1], a1);
-                    } else {
-                        a2 = fma(v[p - p0].x, z[2 * p], a2);
-                        a3 = fma(v[p - p0].y, z[2 * p + 1], a3);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < M1; ++m) dreg[m] = dl[16 * m + l15];
+            sfor<0, n>(MK_LAMBDA(mm) {
+                constexpr int m = decltype(mm)::value;
+                if constexpr (m % 4 == 0) Group<16>::fmac<m % 16, false>(a0, dreg[m / 16], z[m]);
+                else if constexpr (m % 4 == 1) Group<16>::fmac<m % 16, false>(a1, dreg[m / 16], z[m]);
+                else if constexpr (m % 4 == 2) Group<16>::fmac<m % 16, false>(a2, dreg[m / 16], z[m]);
+                else Group<16>::fmac<m % 16, false>(a3, dreg[m / 16], z[m]);
             });
-            if constexpr (n % 2 == 1) a0 = fma(dl[n - 1], z[n - 1], a0);
             xs = (a0 + a1) + (a2 + a3);
             asm volatile("" : "+v"(xs)); // finished HERE: deferred behind the products, its delta operands were spilled
         }
@@ -543,6 +553,93 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 });
             });
         }
+        // ---- STR: the factor border on the vector pipe ----
+        //   vb[k]  = V^T[N+k][j]  = sum_m D[N+k][m] J[j][m]          lane j < N: the last k-step of product 2's B operand
+        //   Vf[m][k] = (D J_f^T)[m][k] = sum_c D[m][c] J[N+k][c]     lane m: its own row of D, the factor rows of J uniform
+        //   pb[k]  = Ps[r][N+k]   = Pf[r][N+k] + sum_m J[r][m] Vf[m][k]   lane r: every row, i.e. the border columns AND the
+        //                                                               K x K block (rows r >= N)
+        // Done BEFORE the J^T fragments occupy their registers; the staging region is free (L^T has been consumed):
+        // [ J_f rows: K x LD | vb: 4 x N | Vf^T: 4 x VLD ].  Every wavefront-uniform operand u[m] arrives as ONE per-lane
+        // 8-byte read per 16 values (lane 16 q + j reads u[16 m' + j]) and is broadcast inside the multiply-add
+        // (v_fmac_f64_dpp row_newbcast, as in the sweeps above).
+        double pb[STR ? 4 : 1];
+        double Bv[STR ? NB : 1];
+        if constexpr (STR) {
+            constexpr int M1 = (n + 15) / 16, VLD = 16 * M1;
+            double *jf = Um, *vbuf = Um + 4 * LD, *vf = vbuf + 4 * N;
+            static_assert(4 * LD + 4 * N + 4 * VLD <= RSZ + 64, "border buffers exceed the staging region");
+            wave_lds_sync(); // the reads of L^T are complete
+            {
+                constexpr unsigned long long frows = ((n < 64 ? (1ull << n) : 0ull) - 1ull) & ~((1ull << N) - 1ull); // lanes N .. n-1
+                double *dst = jf + (r - N) * LD;
+                sfor<0, n / 2>(MK_LAMBDA(pp) {
+                    constexpr int c0 = 2 * decltype(pp)::value;
+                    lds_store_masked<frows, 8 * c0>(dst, v2d{z[c0], z[c0 + 1]});
+                });
+                if constexpr (n % 2 == 1) lds_store_masked<frows, 8 * (n - 1)>(dst, z[n - 1]);
+            }
+            wave_lds_sync();
+            // operand index of this lane in register m' (clamped: indices >= n are never broadcast)
+            int oi[M1];
+#pragma unroll
+            for (int m = 0; m < M1; ++m) oi[m] = 16 * m + l15 < n ? 16 * m + l15 : n - 1;
+            double vb[4] = {0.0, 0.0, 0.0, 0.0}, vfa[4] = {0.0, 0.0, 0.0, 0.0};
+            double du[K][M1], ju[K][M1];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int m = 0; m < M1; ++m) {
+                    du[k][m] = Dm[(N + k) * LD + oi[m]];
+                    ju[k][m] = jf[k * LD + oi[m]];
+                }
+            constexpr int DBP = 3; // pairs of the lane's own row of D per batch
+            sfor<0, (n / 2 + DBP - 1) / DBP>(MK_LAMBDA(bb) {
+                constexpr int p0 = DBP * decltype(bb)::value, p1 = p0 + DBP < n / 2 ? p0 + DBP : n / 2;
+                v2d dr[DBP];
+#pragma unroll
+                for (int p = p0; p < p1; ++p) dr[p - p0] = *reinterpret_cast<const v2d *>(Dr + 2 * p);
+                sfor<2 * p0, 2 * p1>(MK_LAMBDA(cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const double dc = c % 2 ? dr[c / 2 - p0].y : dr[c / 2 - p0].x;
+                    sfor<0, K>(MK_LAMBDA(kk) {
+                        constexpr int k = decltype(kk)::value;
+                        Group<16>::fmac<c % 16, false>(vb[k], du[k][c / 16], z[c]);
+                        Group<16>::fmac<c % 16, false>(vfa[k], ju[k][c / 16], dc);
+                    });
+                });
+            });
+            if constexpr (n % 2 == 1) {
+                const double dc = Dr[n - 1];
+                sfor<0, K>(MK_LAMBDA(kk) {
+                    constexpr int k = decltype(kk)::value;
+                    Group<16>::fmac<(n - 1) % 16, false>(vb[k], du[k][(n - 1) / 16], z[n - 1]);
+                    Group<16>::fmac<(n - 1) % 16, false>(vfa[k], ju[k][(n - 1) / 16], dc);
+                });
+            }
+            {   // vb[k] of lane j -> vbuf[k][j] (lanes j < N); Vf[m][k] of lane m -> vf[k][m] (lanes >= n rewrite entry n-1)
+                constexpr unsigned long long srows = (1ull << N) - 1ull; // N <= 48 here (N % 16 == 0, n <= 64)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_store_masked<srows, 0>(vbuf + k * N + lane, vb[k]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) vf[k * VLD + r] = vfa[k];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pb[k] = k < K ? pfb[k < K ? k : 0] : 0.0;
+            sfor<0, K>(MK_LAMBDA(kk) { // pb[k] += J[r][m] Vf[m][k]
+                constexpr int k = decltype(kk)::value;
+                double vu[M1];
+#pragma unroll
+                for (int m = 0; m < M1; ++m) vu[m] = vf[k * VLD + oi[m]];
+                sfor<0, n>(MK_LAMBDA(mm) {
+                    constexpr int m = decltype(mm)::value;
+                    Group<16>::fmac<m % 16, false>(pb[k], vu[m / 16], z[m]);
+                });
+            });
+            // B operand of the factor k-step: B[k = l4][col = 16 Jb + l15] = vb[k] of lane 16 Jb + l15
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) Bv[jb] = vbuf[l4 * N + 16 * jb + l15];
+        }
         // J^T in C-layout: JT[Ib][ks] = J[16 Ib + l15][4 ks + l4] (k >= n only when n % 4 != 0: zero).  The rows of J
         // go from the lanes' registers through the staging buffer 16 at a time (LDS operations of one wavefront
         // execute in order: the fences are compiler fences)
@@ -560,7 +657,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if constexpr (n % 2 == 1) lds_store_masked<rows, 8 * (n - 1)>(dst, z[n - 1]);
             }
             wave_lds_sync();
-            const int jrow = Ib == NB - 1 ? jt_last : jt_row;
+            const int jrow = (!STR && Ib == NB - 1) ? jt_last : jt_row;
             sfor<0, KS>(MK_LAMBDA(ks) {
                 constexpr int kb = 4 * decltype(ks)::value;
                 if constexpr (kb + 3 < n) {
@@ -616,7 +713,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 });
             });
         });
+        if constexpr (STR) { // the factor rows of V^T: the last k-step of product 2
+            sfor<0, NB>(MK_LAMBDA(ib) {
+                constexpr int Ib = decltype(ib)::value;
+                sfor<Ib, NB>(MK_LAMBDA(jb) {
+                    constexpr int Jb = decltype(jb)::value;
+                    constexpr int ti = Ib * NB - Ib * (Ib - 1) / 2 + (Jb - Ib);
+                    Pt[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(JT[Ib][KS - 1], Bv[Jb], Pt[ti], 0, 0, 0);
+                });
+            });
+        }
         wave_lds_sync(); // all reads of D are done: Dm is free for Ps[t]
+        if constexpr (STR) { // border columns N .. n-1 of every row, mirrored into rows N .. n-1 by the series lanes
+            double *dst = Dr + N;
+            if constexpr (K == 4 && N % 2 == 0) {
+                *reinterpret_cast<v2d *>(dst) = v2d{pb[0], pb[1]};
+                *reinterpret_cast<v2d *>(dst + 2) = v2d{pb[2], pb[3]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) dst[k] = pb[k];
+            }
+            constexpr unsigned long long srows = (1ull << N) - 1ull;
+#pragma unroll
+            for (int k = 0; k < K; ++k) lds_store_masked<srows, 0>(Dm + (N + k) * LD + lane, pb[k]);
+        }
         sfor<0, NB>(MK_LAMBDA(ib) {
             constexpr int Ib = decltype(ib)::value;
             sfor<Ib, NB>(MK_LAMBDA(jb) {

@@ -271,7 +271,9 @@ def test_full_size_c4_projection(kf):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("N,K", [(7, 2), (11, 3), (14, 2), (20, 2)])  # n = 9; 14 and 16 (tiled sweeps); 22 (split filter)
+@pytest.mark.parametrize("N,K", [(7, 2), (11, 3), (14, 2), (20, 2), (16, 2), (32, 1), (48, 3)])
+# n = 9; 14 and 16 (tiled sweeps); 22 (split filter); the last three: the smoother's structured products (series tiles + factor
+# border) with 1, 2 and 3 tile rows and fewer than four factors
 def test_runtime_specialised_shapes(kf, N, K, tmp_path_factory, monkeypatch):
     """Shapes outside the ahead-of-time list get kernels built at run time (metran_amd/jit.py:
     hipcc + DPP hazard check + mk_register_shape_module); same parity bar."""
