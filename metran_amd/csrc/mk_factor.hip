@@ -7,7 +7,7 @@
 //   fa_minres_kernel    _minresfun (:315-347), _minresgrad (:349-373), _get_loadings (:375-401)
 //   fa_rotate_kernel    communality normalisation, _rotate (varimax, :121-171), sign convention (:84-108)
 // One model per wavefront; every N x N matrix lives in a wave-private LDS block (N <= 64).  The reference
-// calls LAPACK (eig / eigh / svd / inv) on N x N matrices; here ONE device routine, a cyclic Jacobi
+// calls LAPACK (eig / eigh / svd / inv) on N x N matrices; here ONE device routine, a parallel-ordering Jacobi
 // eigen-decomposition of a symmetric matrix, serves all of them: the correlation matrix is symmetric (eig),
 // svd(M) of the K x K varimax step comes from eigh(M^T M) (R = u vh is the orthogonal polar factor of M),
 // and diag(inv(S)) = sum_k V_ik^2 / w_k.  This is not the hot path: no MFMA, no tuning beyond keeping the
@@ -27,15 +27,27 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-// Cyclic Jacobi on a symmetric n x n matrix A (LDS, row-major, destroyed: the eigenvalues end up on its
-// diagonal) accumulating the eigenvectors in the COLUMNS of V.  The (p,q) rotations of a sweep run one after
-// the other; within a rotation lane k updates row/column k.  Converges quadratically; 12 sweeps is far more
-// than an N <= 64 correlation matrix needs (the loop stops when the off-diagonal mass is at rounding level).
+// Jacobi eigen-decomposition of a symmetric n x n matrix A (LDS, row-major, destroyed: the eigenvalues end up on its
+// diagonal) accumulating the eigenvectors in the COLUMNS of V, in the PARALLEL (round-robin) ordering: a sweep is
+// m - 1 rounds (m = n rounded up to even) of m / 2 rotations on disjoint index pairs -- the circle method: in round r
+// index m-1 meets r, and (r + i) mod (m-1) meets (r - i) mod (m-1), i = 1 .. m/2 - 1 -- so that every pair (p, q) is
+// met exactly once per sweep, as in the cyclic ordering round 2 shipped (one rotation at a time, three fences each:
+// 496 dependent rotations a sweep at n = 32; 31 rounds here).  Within a round
+//   1. lane i < m/2 forms (c, s) of its pair from the CURRENT A(p,p), A(q,q), A(p,q)  (Rutishauser's formulas);
+//   2. all lanes apply the rotations to the columns of A and of V (element (k, pair i): lanes of one row k take
+//      different pairs: no two lanes touch the same element, consecutive lanes read different columns of one row);
+//   3. after a fence, to the rows of A (element (pair i, k): consecutive lanes take consecutive columns k).
+// The rotations of a round commute (disjoint planes): the result is J^T A J for their product J.  Converges
+// quadratically like the cyclic ordering; the loop stops when the off-diagonal mass is at rounding level.
 __device__ void jacobi_eigh(double *A, double *V, int n, int lane)
 {
+    __shared__ double rot_c[32], rot_s[32];
+    __shared__ int rot_p[32], rot_q[32];
     for (int i = lane; i < n * n; i += 64) V[i] = (i / n == i % n) ? 1.0 : 0.0;
     wsync();
-    for (int sweep = 0; sweep < 12; ++sweep) {
+    if (n < 2) return;
+    const int m = n + (n & 1), hp = m / 2;
+    for (int sweep = 0; sweep < 16; ++sweep) {
         double off = 0.0, dia = 0.0;
         for (int i = lane; i < n * n; i += 64) {
             const double v = A[i];
@@ -47,33 +59,68 @@ __device__ void jacobi_eigh(double *A, double *V, int n, int lane)
             dia += __shfl_xor(dia, s);
         }
         if (off <= 1e-30 * dia || off == 0.0) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue; // uniform: every lane reads the same element
-                const double app = A[p * n + p], aqq = A[q * n + q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                wsync();
-                // columns p and q of A and V (lane k: row k)
-                for (int k = lane; k < n; k += 64) {
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
+        for (int r = 0; r < m - 1; ++r) {
+            if (lane < hp) {
+                int p, q;
+                if (lane == 0) {
+                    p = m - 1;
+                    q = r;
+                } else {
+                    p = (r + lane) % (m - 1);
+                    q = (r - lane + (m - 1)) % (m - 1);
                 }
-                wsync();
-                // rows p and q of A (lane k: column k)
-                for (int k = lane; k < n; k += 64) {
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
                 }
-                wsync();
+                double c = 1.0, sn = 0.0;
+                if (q < n) { // (an odd n has one idle index per round)
+                    const double apq = A[p * n + q];
+                    if (apq != 0.0) {
+                        const double app = A[p * n + p], aqq = A[q * n + q];
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        sn = t * c;
+                    }
+                } else {
+                    q = p; // identity on the idle index: c = 1, s = 0 and both "columns" are the same one
+                }
+                rot_p[lane] = p;
+                rot_q[lane] = q;
+                rot_c[lane] = c;
+                rot_s[lane] = sn;
             }
+            wsync();
+            // columns of A and V
+            for (int idx = lane; idx < n * hp; idx += 64) {
+                const int i = idx % hp, k = idx / hp;
+                const int p = rot_p[i], q = rot_q[i];
+                const double c = rot_c[i], sn = rot_s[i];
+                if (sn != 0.0) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - sn * akq;
+                    A[k * n + q] = sn * akp + c * akq;
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
+            wsync();
+            // rows of A
+            for (int idx = lane; idx < n * hp; idx += 64) {
+                const int k = idx % n, i = idx / n;
+                const int p = rot_p[i], q = rot_q[i];
+                const double c = rot_c[i], sn = rot_s[i];
+                if (sn != 0.0) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + c * aqk;
+                }
+            }
+            wsync();
+        }
     }
     wsync();
 }
@@ -179,9 +226,15 @@ __global__ void __launch_bounds__(64) fa_analyse_kernel(long B, int N, long maxf
     }
     wsync();
     // diag(inv(S))_i = sum_k V_ik^2 / w_k with the UNCLIPPED eigenvalues
-    double wmin = 1.0;
-    for (int k = 0; k < n; ++k) wmin = fmin(wmin, A[k * n + k]);
-    if (!(wmin > 0.0)) bad = true; // numpy.linalg.inv raises on a singular matrix -> _minres returns None (:199-200)
+    double wmin = 1.0, wmax = 0.0;
+    for (int k = 0; k < n; ++k) {
+        wmin = fmin(wmin, A[k * n + k]);
+        wmax = fmax(wmax, A[k * n + k]);
+    }
+    // numpy.linalg.inv raises on a singular matrix -> _minres returns None (:199-200).  LAPACK meets an exactly zero pivot
+    // when two series are collinear; the Jacobi eigenvalue of that direction is zero only up to rounding (either sign),
+    // so "singular" is a smallest eigenvalue below 1e-14 of the largest
+    if (!(wmin > 1e-14 * wmax)) bad = true;
     for (int i = lane; i < n; i += 64) {
         double d = 0.0;
         for (int k = 0; k < n; ++k) d += V[i * n + k] * V[i * n + k] / A[k * n + k];

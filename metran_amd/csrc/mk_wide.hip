@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // 16x16x4 tiles on the N x N series block only (K runs over all n: the factor rows are the last k-step) and the K-wide
     // factor border on the vector pipe -- at n = 36 the tiles of the padded 48 x 48 problem spend 44 % of their multiply-adds
     // on padding (135 tiles a step; 63 here)
-    constexpr bool STR = (N % 16 == 0) && (K <= 4) && !SYM;
+    constexpr bool STR = (N % 16 == 0) && (K <= 4);
     constexpr int NB = STR ? N / 16 : (n + 15) / 16; // 16-wide tile rows / columns
     constexpr int KS = (n + 3) / 4;   // k-steps
     constexpr int LD = (n + 3) & ~1;  // LDS row stride: even (16-byte rows), n + 2 or n + 3
