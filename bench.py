@@ -441,6 +441,68 @@ def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=3, warmu
     return out
 
 
+def secondary_factor_analysis(dev, R=4096, T=1000, N=8, K=2, reps=3):
+    """SURVEY section 8 row f4 in the driver's record: ``FactorAnalysisBatch.solve`` on R synthetic block-structure models
+    (observations generated on the device, 10 % missing): correlations -> eigenvalues / MAP test -> minres -> loadings ->
+    varimax, best of ``reps`` calls after one warm-up call."""
+    import torch
+
+    from metran_amd.factoranalysis import FactorAnalysisBatch
+
+    g = torch.Generator(device=dev).manual_seed(100 + N)
+    load = torch.zeros(R, N, K, dtype=torch.float64, device=dev)
+    cols = (torch.arange(N, device=dev) * K) // N
+    load[:, torch.arange(N, device=dev), cols] = 0.6 + 0.3 * torch.rand(R, N, dtype=torch.float64, device=dev, generator=g)
+    f = torch.randn(R, T, K, dtype=torch.float64, device=dev, generator=g)
+    y = torch.einsum("rtk,rnk->rtn", f, load)
+    y += torch.randn(R, T, N, dtype=torch.float64, device=dev, generator=g) * torch.sqrt(1.0 - (load ** 2).sum(2))[:, None, :]
+    y[torch.rand(R, T, N, device=dev, generator=g) < 0.1] = float("nan")
+    del f
+    fb = FactorAnalysisBatch()
+    fb.solve(obs=y)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fb.solve(obs=y)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    hist = torch.bincount(r.nfactors.to(torch.int64).clamp(min=0)).tolist()
+    return {"workload": "FactorAnalysisBatch.solve: %d x (%d series, %d true factors), T=%d, 10 %% missing, fp64" % (R, N, K, T),
+            "seconds": best, "models_per_s": R / best, "models_moved_by_lbfgsb": int((~r.stalled).sum().item()),
+            "nfactors_histogram": {str(i): c for i, c in enumerate(hist) if c}}
+
+
+def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200):
+    """Row f1 in the driver's record: ``calibrate_batch`` (lock-step L-BFGS-B on the adjoint gradient) of B independent
+    models from the default start to convergence."""
+    import torch
+
+    from metran_amd.calibrate import calibrate_batch
+    from metran_amd.engine import BatchedKalman
+    from metran_amd.synthetic import make_dfm_batch_torch
+
+    d = make_dfm_batch_torch(B, N, K, T, seed=5000, device=dev, missing=0.0)
+    kf = BatchedKalman(local_rank, layout="time_major")
+    try:
+        kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+        calibrate_batch(kf, maxiter=2)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = calibrate_batch(kf, maxiter=maxiter)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        true_obj = kf.loglik(d["phi"], d["q"])
+        return {"workload": "calibrate_batch: %d x (%d series, %d factors), T=%d, fp64, adjoint gradient" % (B, N, K, T),
+                "seconds": dt, "models_per_s": B / dt, "iterations": int(res.nit), "objective_evaluations": int(res.nfev),
+                "converged_frac": float(res.converged.double().mean()),
+                "frac_at_or_below_true_parameter_objective": float((res.obj <= true_obj + 1e-6).double().mean())}
+    finally:
+        kf.close()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -596,6 +658,12 @@ def main():
             try:
                 res["secondary"][name] = secondary_workload(name, local_rank, rank, dev, args.layout, sync)
             except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure here
+                res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        for name, fn in (("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
+                         ("f1_calibration", lambda: secondary_calibration(local_rank, dev))):
+            try:
+                res["secondary"][name] = fn()
+            except Exception as e:  # noqa: BLE001
                 res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(res))

@@ -44,7 +44,7 @@ def test_secondary_configs3_throughput_floor(line):
     assert "error" not in s, s
     assert "32-series/4-factor" in s["workload"] and "T=2000" in s["workload"]
     assert s["roofline"]["bound"] == "fp64" and s["roofline"]["unit"] == "TFLOP/s" and s["roofline"]["peak"] == 78.6
-    assert s["models_per_s"] >= 20000.0, s       # floor (round 2: 24.6 k; a regression of the wide kernels fails here)
+    assert s["models_per_s"] >= 21000.0, s       # floor (round 2: 24.6 k, round 3: 28.4-28.7 k, 23.4 k on a slow lease; a regression of the wide kernels fails here)
     assert 0.0 < s["roofline"]["frac"] < 1.0
 
 
@@ -53,3 +53,16 @@ def test_secondary_configs4_solver_loop(line):
     assert "error" not in s, s
     assert s["roofline"]["bound"] == "fp64"
     assert s["objective_evaluations_per_s"] >= 4.5e6, s   # floor (round 2: 6.4 M evaluations/s)
+
+
+def test_secondary_factor_analysis_and_calibration(line):
+    """Rows f4 and f1 in the driver-run line: throughput floors well under the round-3 measurements (400 k models/s for the
+    factor analysis of 8-series models, 8 k models/s for the calibration of 8192 8/2 models)."""
+    f4 = line["secondary"]["f4_factor_analysis"]
+    assert "error" not in f4, f4
+    assert f4["models_per_s"] >= 50000.0, f4
+    assert sum(f4["nfactors_histogram"].values()) == 4096 and "0" not in f4["nfactors_histogram"]
+    f1 = line["secondary"]["f1_calibration"]
+    assert "error" not in f1, f1
+    assert f1["converged_frac"] > 0.95 and f1["frac_at_or_below_true_parameter_objective"] > 0.95, f1
+    assert f1["models_per_s"] >= 4000.0, f1
