@@ -82,6 +82,18 @@ struct Group<16> {
         else
             asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
     }
+    // two broadcast-multiply-adds in ONE asm statement (hipcc pads every asm statement that follows another with an
+    // `s_nop 0`; neither instruction reads what the other writes)
+    template <int J0, int J1, bool NEG = false>
+    static __device__ __forceinline__ void fmac2(double &acc0, double src0, double mul0, double &acc1, double src1, double mul1)
+    {
+        if constexpr (NEG)
+            asm volatile("v_fmac_f64_dpp %0, %2, -%3 row_newbcast:%6" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, -%5 row_newbcast:%7" MK_DPPMASK
+                         : "+v"(acc0), "+v"(acc1) : "v"(src0), "v"(mul0), "v"(src1), "v"(mul1), "n"(J0), "n"(J1));
+        else
+            asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%6" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, %5 row_newbcast:%7" MK_DPPMASK
+                         : "+v"(acc0), "+v"(acc1) : "v"(src0), "v"(mul0), "v"(src1), "v"(mul1), "n"(J0), "n"(J1));
+    }
     template <int J, int C0, int C1, bool NEG, int n>
     static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
     {

@@ -235,6 +235,7 @@ smoother_wave_kernel(SmootherArgs a)
 //     computed and mirrored into the LDS matrix the lanes then read their rows from.
 // =====================================================================================
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double global_double;
 
 // rows of L^T packed for the back substitution: row c holds L(k, c) for k = lt_kb(c) .. n-1 (lt_kb(c) = (c+1) & ~1: the
 // first pair starts at an even k, so rows are 16-byte aligned pairs), padded to an even count
@@ -312,15 +313,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         sM = a.state_means + blkT * n + r;
         sV = a.state_vars + blkT * n + r;
     }
+    // packed-symmetric records: element (r, c) of the upper triangle stored by rows sits at K(c) + r for c <= r and at
+    // offr + c for c > r.  The record base is the same in every lane (one model per wavefront): made a scalar, the
+    // accesses are (scalar base) + (32-bit lane offset) and the offsets are n 32-bit registers, not n 64-bit pointers
+    // (which the loop kept live and spilled: 145-167 scratch registers)
+    const int offr = r * n - r * (r - 1) / 2 - r;
+    auto uniform_ptr = [](double *p) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<global_double *>(((unsigned long long)hi << 32) | lo); // (global, not flat: scalar-base addressing)
+    };
+    auto at = [](auto *base, int idx) __attribute__((always_inline)) { // base + zero-extended 32-bit BYTE offset
+        typedef __attribute__((address_space(1))) char global_char;
+        return reinterpret_cast<decltype(base)>(reinterpret_cast<global_char *>(const_cast<global_double *>(base)) + 8u * (unsigned)idx);
+    };
     auto load_pf_rows = [&](double(&row)[n]) __attribute__((always_inline)) {
-        if constexpr (SYM) load_cols_sym<n>(iF.mat - r, row, r);
-        else load_cols<n>(iF.mat, row);
+        if constexpr (SYM) {
+            const global_double *ub = uniform_ptr(iF.mat - r);
+            int rv = r, ov = offr; // opaque copies: the n offsets are formed here, every time (hoisted, they are kept as 64-bit pairs)
+            asm volatile("" : "+v"(rv), "+v"(ov));
+#pragma unroll
+            for (int c = 0; c < n; ++c) row[c] = *at(ub, rv >= c ? sym_row_offset(n, c) - c + rv : ov + c);
+        } else {
+            load_cols<n>(iF.mat, row);
+        }
     };
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
         if (oS.vec) *oS.vec = xv;
         if (oS.mat) {
-            if constexpr (SYM) store_cols_sym<n>(oS.mat - r, row, r);
-            else store_cols<n>(oS.mat, row);
+            if constexpr (SYM) {
+                global_double *ub = uniform_ptr(oS.mat - r);
+                int rv = r;
+                asm volatile("" : "+v"(rv));
+#pragma unroll
+                for (int c = 0; c < n; ++c)
+                    if (rv >= c) *at(ub, sym_row_offset(n, c) - c + rv) = row[c];
+            } else {
+                store_cols<n>(oS.mat, row);
+            }
         }
         oS.advance(-1);
         if (padS) {
@@ -438,13 +468,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
             sfor<0, c>(MK_LAMBDA(kk) {
                 constexpr int k = decltype(kk)::value;
-                if constexpr (k % 2 == 0) {
-                    Group<16>::fmac<k % 16, true>(a0, uc[k / 16], A[k]);
-                    Group<16>::fmac<k % 16, true>(s0, uc[k / 16], z[k]);
-                } else {
-                    Group<16>::fmac<k % 16, true>(a1, uc[k / 16], A[k]);
-                    Group<16>::fmac<k % 16, true>(s1, uc[k / 16], z[k]);
-                }
+                if constexpr (k % 2 == 0) Group<16>::fmac2<k % 16, k % 16, true>(a0, uc[k / 16], A[k], s0, uc[k / 16], z[k]);
+                else Group<16>::fmac2<k % 16, k % 16, true>(a1, uc[k / 16], A[k], s1, uc[k / 16], z[k]);
             });
             const double u = a0 + a1;
             if constexpr (c + 1 < n) // U(r, c), lanes r > c only: the rows are packed (replica lanes >= n rewrite row n-1)
@@ -489,13 +514,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 });
                 double b0 = z[c], b1 = 0.0;
-                sfor<c + 1, n>(MK_LAMBDA(kk) { // k = n-1 .. c+1: z[c+1], the freshest operand, last
-                    constexpr int k = n + c - decltype(kk)::value;
+                // k = n-1 .. c+1 (z[c+1], the freshest operand, last), two per statement
+                sfor<0, (n - 1 - c) / 2>(MK_LAMBDA(pp) {
+                    constexpr int k = n - 1 - 2 * decltype(pp)::value; // pair (k, k-1), both > c
                     if constexpr (k % 2 == 0)
-                        Group<16>::fmac<k % 16, true>(b0, lc[k / 16 - M0], z[k]);
+                        Group<16>::fmac2<k % 16, (k - 1) % 16, true>(b0, lc[k / 16 - M0], z[k], b1, lc[(k - 1) / 16 - M0], z[k - 1]);
                     else
-                        Group<16>::fmac<k % 16, true>(b1, lc[k / 16 - M0], z[k]);
+                        Group<16>::fmac2<k % 16, (k - 1) % 16, true>(b1, lc[k / 16 - M0], z[k], b0, lc[(k - 1) / 16 - M0], z[k - 1]);
                 });
+                if constexpr ((n - 1 - c) % 2 == 1) {
+                    constexpr int k = c + 1;
+                    if constexpr (k % 2 == 0) Group<16>::fmac<k % 16, true>(b0, lc[k / 16 - M0], z[k]);
+                    else Group<16>::fmac<k % 16, true>(b1, lc[k / 16 - M0], z[k]);
+                }
                 z[c] = b0 + b1;
             });
             wave_lds_sync(); // the reads of L^T are complete: the region becomes the J staging buffer
@@ -603,8 +634,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const double dc = c % 2 ? dr[c / 2 - p0].y : dr[c / 2 - p0].x;
                     sfor<0, K>(MK_LAMBDA(kk) {
                         constexpr int k = decltype(kk)::value;
-                        Group<16>::fmac<c % 16, false>(vb[k], du[k][c / 16], z[c]);
-                        Group<16>::fmac<c % 16, false>(vfa[k], ju[k][c / 16], dc);
+                        Group<16>::fmac2<c % 16, c % 16, false>(vb[k], du[k][c / 16], z[c], vfa[k], ju[k][c / 16], dc);
                     });
                 });
             });
