@@ -276,7 +276,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (!live) inst = a.B - 1;
     const int r = lane < n ? lane : n - 1;
     const long T = a.T;
-    __shared__ __attribute__((aligned(16))) double lds_m[n * LD + RSZ + 64];
+    // (projection variant: the lane's K loadings, scale and offset wait in LDS between the steps -- 12 registers the loop
+    // otherwise spilled, 9 scratch loads a step whose traffic reached HBM: 130 GB a launch against 114)
+    constexpr int PCS = PROJ ? ((K + 3) & ~1) : 0;
+    __shared__ __attribute__((aligned(16))) double lds_m[n * LD + RSZ + 64 + 64 * PCS];
     double *Dm = lds_m;           // D = Ps[t+1] - Pp[t+1] row-major; after product 2: Ps[t]
     double *Um = Dm + n * LD;     // U packed; then 16 rows of J at a time
     double *dl = Um + RSZ;        // delta = xs[t+1] - Xp[t+1]
@@ -297,13 +300,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     const long rec_id = inst % a.R;
     const int jr = lane < N ? lane : N - 1;
-    double gam[K], pscale = 1.0, poffset = 0.0;
     double *pM = nullptr, *pV = nullptr;
+    double *pcl = dl + 64 + lane * PCS; // this lane's projection constants [gam_0 .. gam_{K-1}, scale, offset]
     if constexpr (PROJ) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec_id * N + jr) * K + k];
-        if (a.scale) pscale = a.scale[rec_id * N + jr];
-        if (a.offset) poffset = a.offset[rec_id * N + jr];
+        for (int k = 0; k < K; ++k) pcl[k] = a.loadings[(rec_id * N + jr) * K + k];
+        pcl[K] = a.scale ? a.scale[rec_id * N + jr] : 1.0;
+        pcl[K + 1] = a.offset ? a.offset[rec_id * N + jr] : 0.0;
         const long pidx = blkT * N + jr;
         pM = a.sim_means ? a.sim_means + pidx : nullptr;
         pV = a.sim_vars ? a.sim_vars + pidx : nullptr;
@@ -358,8 +361,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             padS -= a.ts * RS;
         }
         if constexpr (PROJ) {
-            double mean, var;
-            project<N, K, G>(xv, row, gam, pscale, poffset, lane, mean, var);
+            double mean, var, gam[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) gam[k] = pcl[k];
+            project<N, K, G>(xv, row, gam, pcl[K], pcl[K + 1], lane, mean, var);
             if (lane < N && live) {
                 if (pM) *pM = mean;
                 if (pV) *pV = var;
