@@ -7,7 +7,7 @@ P+1 sequential filter runs (2-point finite differences, no analytic jac).  Here 
 lock-step: one kernel launch evaluates the objective of every model at its current point AND at its P
 forward-difference points ((P+1)*R filter instances sharing the R uploaded records), a bound-projected
 L-BFGS update is computed for all models with batched tensor algebra on the device, and the Armijo
-back-tracking line search evaluates one trial point per still-searching model per launch.
+back-tracking line search (steps from a quadratic interpolation) evaluates one trial point per still-searching model per launch.
 
 The iteration is not scipy's L-BFGS-B code path (that is ``metran_amd.solver.HipSolve``, which keeps
 scipy on the host and reproduces the reference's trajectory for ONE model); it minimises the same
@@ -146,13 +146,19 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         for _ in range(max_backtracks):
             xt = torch.maximum(x + step[:, None] * d, lo)
             ft = value(torch.where(searching[:, None], xt, x))
-            ok = searching & (ft <= f + 1e-4 * (pg * (xt - x)).sum(1)) & torch.isfinite(ft)
+            gd = (pg * (xt - x)).sum(1)                 # directional derivative along the trial displacement (< 0)
+            ok = searching & (ft <= f + 1e-4 * gd) & torch.isfinite(ft)
             x_new = torch.where(ok[:, None], xt, x_new)
             f_new = torch.where(ok, ft, f_new)
             searching &= ~ok
             if not bool(searching.any()):
                 break
-            step = torch.where(searching, step * 0.5, step)
+            # next trial: the minimiser of the parabola through f, its slope and the rejected value, kept inside
+            # [0.1, 0.5] of the rejected step (plain halving needs log2 of the ratio in launches, and every launch costs
+            # the whole flight: with thousands of models in lock-step some model needs 1/64 in most iterations)
+            curv = ft - f - gd                          # > 0 wherever the Armijo test failed with a finite value
+            theta = torch.where(torch.isfinite(ft) & (curv > 0), -gd / (2.0 * curv), torch.full_like(ft, 0.1))
+            step = torch.where(searching, step * theta.clamp(0.1, 0.5), step)
         active &= ~searching  # no acceptable step: this model is done (at numerical precision)
         f_prev = f
         g_prev = g
