@@ -1,12 +1,12 @@
 #!/bin/bash
 # Box-side: same-box A/B of two builds of libmetran_hip.so on one bench configuration, interleaved (leases differ by up to
 # 25 % on compute-bound kernels, DESIGN.md section 6: only a comparison on one box means anything).
-#   gpurun -- 'bash scripts/ab_bench.sh c4 build/libmetran_hip_base.so [pytest files...]'
-# BASE: a library built from the commit to compare against (make -C metran_amd/csrc BUILD=/tmp/x OUT=$PWD/build/libmetran_hip_base.so
+#   gpurun -- 'bash scripts/ab_bench.sh c4 ab/libmetran_hip_base.so [pytest files...]'
+# BASE: a library built from the commit to compare against (make -C metran_amd/csrc BUILD=/tmp/x OUT=$PWD/ab/libmetran_hip_base.so
 # in a stash / worktree of that commit); the working tree's library is the other side.  Optional parity tests afterwards.
 set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-CFG=${1:-c4}; BASE=${2:-build/libmetran_hip_base.so}; shift 2 || true
+CFG=${1:-c4}; BASE=${2:-ab/libmetran_hip_base.so}; shift 2 || true
 run() {
   timeout 300 python bench.py --config $CFG --no-cpu-baseline --no-live-traffic --no-secondary --steps 3 --warmup 1 2>/dev/null | python -c "
 import json,sys
