@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define MK_API __attribute__((visibility("default")))
-#define MK_ABI_VERSION 3
+#define MK_ABI_VERSION 4
 
 typedef enum mk_status {
     MK_OK = 0,
@@ -213,6 +213,15 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *prob, double *d_mle);
 MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *prob, double *d_work, int time_major,
                           double *d_mle, int64_t *d_sigmacount, double *d_gphi, double *d_gq,
                           uint32_t *d_status);
+/* The two launches of mk_loglik_grad separately.  A line search evaluates the objective at several trial points and
+ * needs the gradient at the accepted one only: with MK_GRAD_FORWARD every trial is the recording forward pass (d_mle,
+ * d_sigmacount, d_status, the records in d_work; d_gphi / d_gq may be NULL), and MK_GRAD_BACKWARD then walks the records
+ * the LAST forward pass left in d_work -- same prob (parameters included), same d_work, same d_sigmacount -- instead of
+ * filtering the accepted point once more.  phases = MK_GRAD_FORWARD | MK_GRAD_BACKWARD is mk_loglik_grad. */
+enum { MK_GRAD_FORWARD = 1, MK_GRAD_BACKWARD = 2 };
+MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *prob, double *d_work, int time_major,
+                                 double *d_mle, int64_t *d_sigmacount, double *d_gphi, double *d_gq,
+                                 uint32_t *d_status, int phases);
 /* Chain rule of mk_params_from_alpha: d/dalpha = (gphi - 2 phi c gq) phi dt / alpha^2, c = 1 - sum_k
  * loadings^2 for the series, 1 for the factors (metran/metran.py:246-322). */
 MK_API int mk_alpha_grad(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K,

@@ -102,6 +102,8 @@ API = {
                              c_void_p]),
     "mk_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mk_loglik_grad": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mk_loglik_grad_phases": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int]),
     "mk_alpha_grad": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double, c_void_p,
                               c_void_p, c_void_p]),
     "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -121,7 +123,7 @@ API = {
     "mk_kernel_ms_totals": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
 }
 
-ABI_VERSION = 3  # MK_ABI_VERSION of include/metran_hip.h
+ABI_VERSION = 4  # MK_ABI_VERSION of include/metran_hip.h
 _lib = None
 
 

@@ -90,10 +90,14 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         return f[0].clone(), ((f[1:] - f[0:1]) / eps).transpose(0, 1).contiguous()
 
     def value(xc):
+        """Objective at a trial point.  With the adjoint gradient it is the RECORDING forward pass: the gradient of the
+        accepted point is then the backward walk over the records of the last trial, not a second filter run."""
         nonlocal nfev, launches
-        phi, q = kf.params_from_alpha(xc, dt=dt)
         nfev += R
         launches += 1
+        if grad_mode == "adjoint":
+            return kf.loglik_forward_alpha(xc, dt=dt, warmup=warmup)
+        phi, q = kf.params_from_alpha(xc, dt=dt)
         return kf.loglik(phi, q, warmup=warmup).clone()
 
     def proj_grad(xc, g):  # gradient with the components pushing into an active bound removed
@@ -145,7 +149,7 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         x_new, f_new = x.clone(), f.clone()
         for _ in range(max_backtracks):
             xt = torch.maximum(x + step[:, None] * d, lo)
-            ft = value(torch.where(searching[:, None], xt, x))
+            ft = value(torch.where(searching[:, None], xt, x_new))   # settled models: at the point they settled on
             gd = (pg * (xt - x)).sum(1)                 # directional derivative along the trial displacement (< 0)
             ok = searching & (ft <= f + 1e-4 * gd) & torch.isfinite(ft)
             x_new = torch.where(ok[:, None], xt, x_new)
@@ -162,7 +166,14 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         active &= ~searching  # no acceptable step: this model is done (at numerical precision)
         f_prev = f
         g_prev = g
-        f_tmp, g_new = value_and_grad(x_new)
+        if grad_mode == "adjoint":
+            # the last trial launch evaluated every model AT x_new (a model that found no step: at a rejected point --
+            # it keeps its old gradient, and stops)
+            launches += 1
+            g_new = torch.where(searching[:, None], g, kf.loglik_backward_alpha())
+            f_tmp = f_new
+        else:
+            f_tmp, g_new = value_and_grad(x_new)
         s_ = x_new - x
         y_ = g_new - g_prev
         sy = (s_ * y_).sum(1)

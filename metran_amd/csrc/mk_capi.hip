@@ -631,10 +631,19 @@ MK_API int mk_sum(mk_context *ctx, int64_t count, const double *v, double *out)
 MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *p, double *d_work, int time_major, double *d_mle,
                           int64_t *d_sigmacount, double *d_gphi, double *d_gq, uint32_t *d_status)
 {
+    return mk_loglik_grad_phases(ctx, p, d_work, time_major, d_mle, d_sigmacount, d_gphi, d_gq, d_status,
+                                 MK_GRAD_FORWARD | MK_GRAD_BACKWARD);
+}
+
+MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *p, double *d_work, int time_major, double *d_mle,
+                                 int64_t *d_sigmacount, double *d_gphi, double *d_gq, uint32_t *d_status, int phases)
+{
     MK_CTX(ctx);
     if (int rc = check_problem(p)) return rc;
-    if (!d_work || !d_mle || !d_sigmacount || !d_gphi || !d_gq)
-        return fail(MK_ERR_INVALID, "mk_loglik_grad: d_work, d_mle, d_sigmacount, d_gphi and d_gq are required");
+    if (!(phases & (MK_GRAD_FORWARD | MK_GRAD_BACKWARD)) || (phases & ~(MK_GRAD_FORWARD | MK_GRAD_BACKWARD)))
+        return fail(MK_ERR_INVALID, "mk_loglik_grad_phases: phases must be MK_GRAD_FORWARD, MK_GRAD_BACKWARD or both");
+    if (!d_work || !d_sigmacount || ((phases & MK_GRAD_FORWARD) && !d_mle) || ((phases & MK_GRAD_BACKWARD) && (!d_gphi || !d_gq)))
+        return fail(MK_ERR_INVALID, "mk_loglik_grad: d_work and d_sigmacount are required; d_mle by the forward pass, d_gphi and d_gq by the backward pass");
     const int64_t n = p->N + p->K;
     // forward pass: filtered records only (+ per-step bookkeeping in the record pads), objective, step count
     mk_outputs o;
@@ -648,7 +657,9 @@ MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *p, double *d_work, 
     o.d_detfs = o.d_sigmas + 1;
     o.time_major = time_major;
     o.record_stride = mk::record_stride((int)n);
-    if (int rc = do_filter(ctx, p, &o)) return rc;
+    if (phases & MK_GRAD_FORWARD)
+        if (int rc = do_filter(ctx, p, &o)) return rc;
+    if (!(phases & MK_GRAD_BACKWARD)) return MK_OK;
     mk::AdjointArgs a;
     a.B = p->n_instances;
     a.R = p->n_records;

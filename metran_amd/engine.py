@@ -349,6 +349,58 @@ class BatchedKalman:
                                      self._p(mle), self._p(sc), self._p(gphi), self._p(gq), None))
         return mle, gphi, gq
 
+    def loglik_forward(self, phi, q, warmup=1, x0=None, P0=None):
+        """The forward half of ``loglik_grad`` alone (``mk_loglik_grad_phases``, MK_GRAD_FORWARD): ``mle [B]``, with the
+        filtered records left in the workspace.  ``loglik_backward()`` then returns the gradient AT THESE parameters
+        without filtering them again -- a line search evaluates several trial points and wants the gradient of the last
+        one only."""
+        torch = _torch()
+        prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        need = B * self.T * self.record_stride()
+        work = getattr(self, "_grad_work", None)
+        if work is None or work.numel() < need:
+            self._grad_work = work = torch.empty(need, dtype=torch.float64, device=self.device)
+        mle = torch.empty(B, dtype=torch.float64, device=self.device)
+        sc = torch.empty(B, dtype=torch.int64, device=self.device)
+        self._bind_stream()
+        check(self._L.mk_loglik_grad_phases(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
+                                            self._p(mle), self._p(sc), None, None, None, 1))
+        self._grad_pending = (prob, keep, B, sc, work)
+        return mle
+
+    def loglik_backward(self):
+        """``(gphi [B,n], gq [B,n])`` at the parameters of the last ``loglik_forward`` (MK_GRAD_BACKWARD)."""
+        torch = _torch()
+        pending = getattr(self, "_grad_pending", None)
+        if pending is None:
+            raise MetranHipError("loglik_backward without a preceding loglik_forward")
+        prob, keep, B, sc, work = pending
+        gphi = torch.empty((B, self.n), dtype=torch.float64, device=self.device)
+        gq = torch.empty_like(gphi)
+        self._bind_stream()
+        check(self._L.mk_loglik_grad_phases(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
+                                            None, self._p(sc), self._p(gphi), self._p(gq), None, 2))
+        return gphi, gq
+
+    def loglik_forward_alpha(self, alpha, dt=1.0, warmup=1):
+        """``loglik_forward`` in Metran's parametrisation; ``loglik_backward_alpha()`` completes it."""
+        alpha = self._dev(alpha)
+        if alpha.ndim == 1:
+            alpha = alpha[None]
+        phi, q = self.params_from_alpha(alpha, dt=dt)
+        self._grad_alpha = (alpha, float(dt))
+        return self.loglik_forward(phi, q, warmup=warmup)
+
+    def loglik_backward_alpha(self):
+        """``d mle / d alpha [B,n]`` at the point of the last ``loglik_forward_alpha``."""
+        torch = _torch()
+        gphi, gq = self.loglik_backward()
+        alpha, dt = self._grad_alpha
+        galpha = torch.empty_like(gphi)
+        check(self._L.mk_alpha_grad(self._ctx, int(alpha.shape[0]), self.R, self.N, self.K, self._p(alpha),
+                                    self._p(self.loadings), dt, self._p(gphi), self._p(gq), self._p(galpha)))
+        return galpha
+
     def has_adjoint(self):
         """Whether ``loglik_grad`` (``mk_loglik_grad``) serves this engine's shape: ``adjoint_kernel`` for n <= 16 (four
         models per wavefront), ``adjoint_wide_kernel`` for 16 < n <= 64 (one model per wavefront)."""

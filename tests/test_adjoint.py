@@ -169,3 +169,31 @@ def test_adjoint_on_a_runtime_specialised_shape(tmp_path_factory, monkeypatch):
         assert abs(mle[b] - m) <= 1e-11 * abs(m)
         np.testing.assert_allclose(gphi[b], rp, rtol=1e-9, atol=1e-9 * np.abs(rp).max())
         np.testing.assert_allclose(gq[b], rq, rtol=1e-9, atol=1e-9 * np.abs(rq).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(8, 2), (32, 4)])
+def test_forward_and_backward_phases_separately(N, K):
+    """``mk_loglik_grad_phases``: several recording forward passes at different points, then ONE backward walk = the
+    gradient of the LAST point, bit for bit what ``mk_loglik_grad`` returns there (the line search of calibrate_batch)."""
+    import torch
+
+    from metran_amd.engine import BatchedKalman
+
+    B, T = 11, 60
+    d = make_dfm_batch(B, N, K, T, seed=900 + N, missing=0.2, first_step="random")
+    kf = BatchedKalman(0, layout="time_major")
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    alpha = torch.from_numpy(d["alpha"]).cuda()
+    ref_mle, ref_g = kf.loglik_grad_alpha(alpha)
+    other_mle, _ = kf.loglik_grad_alpha(alpha * 1.7)
+    m1 = kf.loglik_forward_alpha(alpha * 1.7)          # a rejected trial point ...
+    m2 = kf.loglik_forward_alpha(alpha)                # ... then the accepted one
+    g = kf.loglik_backward_alpha()
+    assert torch.equal(m1, other_mle) and torch.equal(m2, ref_mle)
+    assert torch.equal(g, ref_g)
+    kf2 = BatchedKalman(0, layout="time_major")
+    kf2.set_observations(d["obs"]).set_loadings(d["loadings"])
+    with pytest.raises(Exception):
+        kf2.loglik_backward()                          # no forward pass yet
+    kf.close(), kf2.close()
