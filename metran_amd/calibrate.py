@@ -147,13 +147,24 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         step = torch.ones(R, **f64)
         searching = active.clone()
         x_new, f_new = x.clone(), f.clone()
+        # differenced gradients on a flight that fits one round of wavefronts: the n difference points of every TRIAL ride
+        # in its launch (a launch is latency-bound there: T sequential steps whatever the number of instances), so an
+        # accepted trial needs no second launch for its gradient
+        speculate = grad_mode == "fd" and (n + 1) * R <= 4096
+        g_acc = g
         for _ in range(max_backtracks):
             xt = torch.maximum(x + step[:, None] * d, lo)
-            ft = value(torch.where(searching[:, None], xt, x_new))   # settled models: at the point they settled on
+            xe = torch.where(searching[:, None], xt, x_new)          # settled models: at the point they settled on
+            if speculate:
+                ft, gt = value_and_grad(xe)
+            else:
+                ft = value(xe)
             gd = (pg * (xt - x)).sum(1)                 # directional derivative along the trial displacement (< 0)
             ok = searching & (ft <= f + 1e-4 * gd) & torch.isfinite(ft)
             x_new = torch.where(ok[:, None], xt, x_new)
             f_new = torch.where(ok, ft, f_new)
+            if speculate:
+                g_acc = torch.where(ok[:, None], gt, g_acc)
             searching &= ~ok
             if not bool(searching.any()):
                 break
@@ -172,6 +183,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
             launches += 1
             g_new = torch.where(searching[:, None], g, kf.loglik_backward_alpha())
             f_tmp = f_new
+        elif speculate:
+            f_tmp, g_new = f_new, g_acc
         else:
             f_tmp, g_new = value_and_grad(x_new)
         s_ = x_new - x
