@@ -87,6 +87,16 @@ def test_no_gpu_calls_fail_loudly_not_silently(lib):
     assert lib.mk_shape_supported(7, 7) == 0
 
 
+def test_graft_entry_build_passes():
+    """The driver's build check: ``__graft_entry__.build()`` (make is a no-op on a built tree) ends with the ABI and
+    shape assertions -- an ABI bump that forgets the entry point shows here, not in the driver's record."""
+    import __graft_entry__ as g
+
+    g.build()
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert not re.search(r"mk_abi_version\(\)\s*==\s*\d", src), "hard-coded ABI number in build()"
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: no module of the package may reference it."""
     pkg = os.path.join(ROOT, "metran_amd")
