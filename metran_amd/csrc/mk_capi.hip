@@ -261,7 +261,8 @@ MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
 {
     MK_CTX(ctx);
     if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
-    if (value < 0 || value > 1) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1");
+    if (value < 0 || value > (which == MK_VARIANT_WIDE_SMOOTHER ? 2 : 1))
+        return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for MK_VARIANT_WIDE_SMOOTHER)");
     ctx->variant[which] = value;
     return MK_OK;
 }
@@ -466,7 +467,8 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (!o->d_F || !o->d_Pf)
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
     mk::SmootherArgs a;
-    a.variant = (ctx->variant[MK_VARIANT_SMOOTHER16] ? 1 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] ? 2 : 0);
+    a.variant = (ctx->variant[MK_VARIANT_SMOOTHER16] ? 1 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 1 ? 2 : 0) |
+                (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 2 ? 4 : 0);
     a.rs = 0;
     a.sym = 0;
     a.state_means = a.state_vars = nullptr;

@@ -249,10 +249,24 @@ constexpr int lt_off(int n, int c)
 
 // EPI / SYM as in smoother_record_kernel: 0 records, 1 + projection, 2 + state means and variances; SYM: the
 // filtered (and smoothed) records are packed-symmetric
-template <int N, int K, int EPI, bool SYM>
+// FOLD (round 3, last step): the fused factorisation / forward sweep carried TWO rows per lane -- row r of A = Pp (which
+// becomes L) and row r of W (which becomes Z~) -- through the same recursion x_c -= U(c,k) x_k with the same uniform
+// operands: 2 x n(n-1)/2 broadcast multiply-adds a step on n of the 64 lanes.  With n <= 36 the rows of A fit the lanes the
+// model does not use: row r >= H of A rides in lane r + OFF (OFF = 64 - n, H = max(0, 2n - 64): lanes n .. 63 at n = 36
+// carry rows 8 .. 35), so ONE multiply-add per (c, k) serves both recursions; the H head rows (they need columns c < H
+// only: H(H-1)/2 = 28 multiply-adds at n = 36) stay in lanes 0 .. H-1 as a second, short array.  Per lane the arithmetic is
+// the same sequence as before: the results are bit-identical to the unfolded kernel (FOLDP = false, kept behind
+// mk_set_kernel_variant(ctx, MK_VARIANT_WIDE_SMOOTHER, 2) and tested for exactly that).  The A-lanes are no longer
+// replicas of lane n-1: their own-row LDS writes go to a dummy row, the smoothed mean is re-broadcast from lane n-1, and
+// every global store still sees replicas.
+template <int N, int K, int EPI, bool SYM, bool FOLDP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_mfma_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, G = 64;
+    constexpr bool FOLD = FOLDP && n <= 36;
+    constexpr int H = FOLD && 2 * n > 64 ? 2 * n - 64 : 0; // head rows of A kept in lanes 0 .. H-1 (second array)
+    constexpr int OFF = 64 - n;                            // row r >= H of A lives in lane r + OFF
+    constexpr int AL0 = OFF + H;                           // first A-lane (= max(n, 64 - n))
     constexpr bool PROJ = (EPI == 1), VAR = (EPI == 2);
     static_assert(n > 16 && n <= G, "one model per wavefront, 16 < n <= 64");
     // STR (round 3): the state is [N series | K factors]; when N is a multiple of 16 and K <= 4 the two products run their
@@ -284,10 +298,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *Um = Dm + n * LD;     // U packed; then 16 rows of J at a time
     double *dl = Um + RSZ;        // delta = xs[t+1] - Xp[t+1]
     double *Dr = Dm + r * LD;
-    double *Ur = Um + ((r & 1) ? 2 * (r >> 1) * ((r >> 1) + 1) : 2 * (r >> 1) * (r >> 1)); // = Um + tri_off(r)
+    // FOLD: the row of A / L this lane carries (z-lanes: their own), and where the lane's own-row WRITES go (A-lanes: a dummy row)
+    const bool isA = FOLD && lane >= AL0;
+    const int rowA = isA ? lane - OFF : r;
+    // (the dummy row is the delta buffer: LD <= 64 doubles, rewritten AFTER the top loop's D update and dead again when the
+    // border columns are written)
+    static_assert(!FOLD || LD <= 64, "dummy row does not fit the delta buffer");
+    double *Dw = isA ? dl : Dr;
+    double *Ur = Um + ((rowA & 1) ? 2 * (rowA >> 1) * ((rowA >> 1) + 1) : 2 * (rowA >> 1) * (rowA >> 1)); // = Um + tri_off(rowA)
 
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
+    const double phi_x = isA ? a.phi[inst * n + rowA] : 1.0; // FOLD: A-lanes scale W's row to A's (z-lanes: exact no-op)
     Dr[PADC] = phi_r; // diag(Phi), diag(Q) as wavefront-uniform LDS operands (the padding columns are never overwritten)
     Dr[PADC + 1] = q_r;
 
@@ -330,15 +352,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         typedef __attribute__((address_space(1))) char global_char;
         return reinterpret_cast<decltype(base)>(reinterpret_cast<global_char *>(const_cast<global_double *>(base)) + 8u * (unsigned)idx);
     };
-    auto load_pf_rows = [&](double(&row)[n]) __attribute__((always_inline)) {
+    const int offrA = rowA * n - rowA * (rowA - 1) / 2 - rowA;
+    auto load_pf_rows = [&](double(&row)[n], bool fold = false) __attribute__((always_inline)) { // fold: row rowA instead of row r
         if constexpr (SYM) {
             const global_double *ub = uniform_ptr(iF.mat - r);
-            int rv = r, ov = offr; // opaque copies: the n offsets are formed here, every time (hoisted, they are kept as 64-bit pairs)
+            int rv = fold ? rowA : r, ov = fold ? offrA : offr; // opaque copies: the n offsets are formed here, every time (hoisted, they are kept as 64-bit pairs)
             asm volatile("" : "+v"(rv), "+v"(ov));
 #pragma unroll
             for (int c = 0; c < n; ++c) row[c] = *at(ub, rv >= c ? sym_row_offset(n, c) - c + rv : ov + c);
         } else {
-            load_cols<n>(iF.mat, row);
+            load_cols<n>(fold ? iF.mat + (rowA - r) : iF.mat, row);
         }
     };
     auto store = [&](double xv, const double(&row)[n]) __attribute__((always_inline)) {
@@ -416,11 +439,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         iF.advance_nn(-1);
         recU -= recUstep;
         const double xfc = *iF.vec;
-        double A[n], z[n];
+        // FOLD: z = the lane's row through the fused sweep (z-lanes: W -> Z~; A-lanes: A -> L), A = the H head rows of A
+        double A[FOLD ? (H > 0 ? H : 1) : n], z[n];
         double pfb[STR ? K : 1]; // STR: Pf[r][N + k], the seeds of the border columns of Ps
         {
             double Pfc[n];
-            load_pf_rows(Pfc);
+            load_pf_rows(Pfc, FOLD);
             if constexpr (STR) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) pfb[k] = Pfc[N + k];
@@ -429,21 +453,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             sfor<0, n / 2 + n % 2>(MK_LAMBDA(pp) { // two columns at a time; phi_c is a wavefront-uniform LDS read
                 constexpr int c0 = 2 * decltype(pp)::value;
                 const double ph0 = Dm[c0 * LD + PADC];
-                z[c0] = Pfc[c0] * ph0;         // W = Pf Phi
-                A[c0] = phi_r * z[c0];         // row of Phi Pf Phi: Pp[t+1] WITHOUT q on the diagonal (added to the pivots)
+                double a0, a1 = 0.0; // row of Phi Pf Phi: Pp[t+1] WITHOUT q on the diagonal (added to the pivots)
+                if constexpr (FOLD) {
+                    const double w0 = Pfc[c0] * ph0; // W = Pf Phi
+                    a0 = phi_r * w0;
+                    z[c0] = w0 * phi_x;
+                    if constexpr (c0 < H) A[c0] = a0;
+                } else {
+                    z[c0] = Pfc[c0] * ph0;
+                    a0 = A[c0] = phi_r * z[c0];
+                }
                 if constexpr (c0 + 1 < n) {
                     const double ph1 = Dm[(c0 + 1) * LD + PADC];
-                    z[c0 + 1] = Pfc[c0 + 1] * ph1;
-                    A[c0 + 1] = phi_r * z[c0 + 1];
-                    const v2d ps = *reinterpret_cast<const v2d *>(Dr + c0); // D = Ps[t+1] - Pp[t+1], in place
-                    *reinterpret_cast<v2d *>(Dr + c0) = v2d{ps.x - A[c0], ps.y - A[c0 + 1]};
+                    if constexpr (FOLD) {
+                        const double w1 = Pfc[c0 + 1] * ph1;
+                        a1 = phi_r * w1;
+                        z[c0 + 1] = w1 * phi_x;
+                        if constexpr (c0 + 1 < H) A[c0 + 1] = a1;
+                    } else {
+                        z[c0 + 1] = Pfc[c0 + 1] * ph1;
+                        a1 = A[c0 + 1] = phi_r * z[c0 + 1];
+                    }
+                    const v2d ps = *reinterpret_cast<const v2d *>(Dw + c0); // D = Ps[t+1] - Pp[t+1], in place
+                    *reinterpret_cast<v2d *>(Dw + c0) = v2d{ps.x - a0, ps.y - a1};
                 } else {
-                    Dr[c0] = Dr[c0] - A[c0];
+                    Dw[c0] = Dw[c0] - a0;
                 }
                 if constexpr (c0 % 8 == 6) __builtin_amdgcn_sched_barrier(0);
             });
         }
-        Dr[r] -= q_r; // the diagonal of Q (replica lanes >= n rewrite row n-1 with the same value)
+        Dw[r] -= q_r; // the diagonal of Q (replica lanes >= n rewrite row n-1 with the same value; A-lanes: the dummy row)
         dl[lane] = xs - phi_r * xfc; // delta (lanes >= n: replicas of lane n-1, never read)
         __builtin_amdgcn_sched_barrier(0);
         // ---- A = L D L^T and the forward substitution of W, ONE sweep over the columns (dot form) ----
@@ -470,21 +509,50 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     uc[m] = Uc[k < c ? k : c - 1];
                 }
             });
-            double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
-            sfor<0, c>(MK_LAMBDA(kk) {
-                constexpr int k = decltype(kk)::value;
-                if constexpr (k % 2 == 0) Group<16>::fmac2<k % 16, k % 16, true>(a0, uc[k / 16], A[k], s0, uc[k / 16], z[k]);
-                else Group<16>::fmac2<k % 16, k % 16, true>(a1, uc[k / 16], A[k], s1, uc[k / 16], z[k]);
-            });
-            const double u = a0 + a1;
-            if constexpr (c + 1 < n) // U(r, c), lanes r > c only: the rows are packed (replica lanes >= n rewrite row n-1)
-                lds_store_masked<~0ull << (c + 1), 8 * c>(Ur, u);
-            wave_lds_sync();
-            const double piv = readlane_f64(u, c) + Dm[c * LD + PADC + 1]; // d_c = u_c(lane c) + q_c
-            pivmin = min_f64(pivmin, piv);
-            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
-            A[c] = u * ij;          // L(r, c)
-            z[c] = (s0 + s1) * ij;  // z~_c
+            if constexpr (FOLD) {
+                // one recursion for both roles: even k into x0, odd k into x1 (the unfolded kernel's a0/a1 and s0/s1)
+                double x0 = z[c], x1 = 0.0, h0 = 0.0, h1 = 0.0;
+                sfor<0, c / 2>(MK_LAMBDA(pp) {
+                    constexpr int k = 2 * decltype(pp)::value;
+                    Group<16>::fmac2<k % 16, (k + 1) % 16, true>(x0, uc[k / 16], z[k], x1, uc[(k + 1) / 16], z[k + 1]);
+                });
+                if constexpr (c % 2 == 1) Group<16>::fmac<(c - 1) % 16, true>(x0, uc[(c - 1) / 16], z[c - 1]);
+                if constexpr (c < H) { // head rows (lanes 0 .. H-1; c < H <= 16: one operand register)
+                    h0 = A[c];
+                    sfor<0, c>(MK_LAMBDA(kk) {
+                        constexpr int k = decltype(kk)::value;
+                        if constexpr (k % 2 == 0) Group<16>::fmac<k % 16, true>(h0, uc[0], A[k]);
+                        else Group<16>::fmac<k % 16, true>(h1, uc[0], A[k]);
+                    });
+                }
+                const double u = x0 + x1, hs = h0 + h1;
+                // U(r, c) for the rows r > c: rows >= H from the A-lanes r + OFF, head rows from lanes c+1 .. H-1
+                constexpr int r0 = (c + 1 > H ? c + 1 : H) + OFF;
+                if constexpr (r0 < 64) lds_store_masked<~0ull << r0, 8 * c>(Ur, u);
+                if constexpr (c + 1 < H) lds_store_masked<((1ull << H) - 1ull) & (~0ull << (c + 1)), 8 * c>(Ur, hs);
+                wave_lds_sync();
+                const double piv = (c < H ? readlane_f64(hs, c) : readlane_f64(u, c + OFF)) + Dm[c * LD + PADC + 1]; // d_c = u_c(row c) + q_c
+                pivmin = min_f64(pivmin, piv);
+                const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
+                z[c] = u * ij;                          // A-lanes: L(r, c); z-lanes: z~_c
+                if constexpr (c < H) A[c] = hs * ij;    // L(r, c), r < H
+            } else {
+                double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
+                sfor<0, c>(MK_LAMBDA(kk) {
+                    constexpr int k = decltype(kk)::value;
+                    if constexpr (k % 2 == 0) Group<16>::fmac2<k % 16, k % 16, true>(a0, uc[k / 16], A[k], s0, uc[k / 16], z[k]);
+                    else Group<16>::fmac2<k % 16, k % 16, true>(a1, uc[k / 16], A[k], s1, uc[k / 16], z[k]);
+                });
+                const double u = a0 + a1;
+                if constexpr (c + 1 < n) // U(r, c), lanes r > c only: the rows are packed (replica lanes >= n rewrite row n-1)
+                    lds_store_masked<~0ull << (c + 1), 8 * c>(Ur, u);
+                wave_lds_sync();
+                const double piv = readlane_f64(u, c) + Dm[c * LD + PADC + 1]; // d_c = u_c(lane c) + q_c
+                pivmin = min_f64(pivmin, piv);
+                const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
+                A[c] = u * ij;          // L(r, c)
+                z[c] = (s0 + s1) * ij;  // z~_c
+            }
         });
         wave_lds_sync();
         // backward: x_c = z~_c - sum_{k>c} L(k,c) x_k.
@@ -496,10 +564,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // readlane pair: 1 260 VALU instructions a step next to the 630 multiply-adds.  All reads are independent of the
         // results, so they run ahead of the multiply-adds in batches.
         if (!MK_TUNE_SKIP(a, 2)) {
-            double *Lt = Um + lane; // element r of a row of L^T (lanes >= n: one past the row's last entry, never read)
+            double *Lt = Um + (FOLD ? rowA : lane); // element r of a row of L^T (unfolded, lanes >= n: one past the row's last entry, never read)
             sfor<0, n - 1>(MK_LAMBDA(cc) {
                 constexpr int c = decltype(cc)::value;
-                lds_store_masked<(~0ull << (c + 1)) & (n < 64 ? (1ull << n) - 1 : ~0ull), 8 * (lt_off(n, c) - lt_kb(c))>(Lt, A[c]);
+                if constexpr (FOLD) { // L(k, c), k > c: rows k >= H sit in the A-lanes k + OFF, head rows in lanes c+1 .. H-1
+                    constexpr int r0 = (c + 1 > H ? c + 1 : H) + OFF;
+                    lds_store_masked<~0ull << r0, 8 * (lt_off(n, c) - lt_kb(c))>(Lt, z[c]);
+                    if constexpr (c + 1 < H)
+                        lds_store_masked<((1ull << H) - 1ull) & (~0ull << (c + 1)), 8 * (lt_off(n, c) - lt_kb(c))>(Lt, A[c]);
+                } else {
+                    lds_store_masked<(~0ull << (c + 1)) & (n < 64 ? (1ull << n) - 1 : ~0ull), 8 * (lt_off(n, c) - lt_kb(c))>(Lt, A[c]);
+                }
             });
             wave_lds_sync();
             sfor_down<0, n - 1>(MK_LAMBDA(cc) {
@@ -552,6 +627,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 else Group<16>::fmac<m % 16, false>(a3, dreg[m / 16], z[m]);
             });
             xs = (a0 + a1) + (a2 + a3);
+            if constexpr (FOLD) { // the A-lanes carried rows of L, not of J: they become replicas of lane n-1 again
+                const double xl = readlane_f64(xs, n - 1);
+                xs = isA ? xl : xs;
+            }
             asm volatile("" : "+v"(xs)); // finished HERE: deferred behind the products, its delta operands were spilled
         }
         wave_lds_sync(); // Dm (D) visible to the whole wavefront
@@ -760,7 +839,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         wave_lds_sync(); // all reads of D are done: Dm is free for Ps[t]
         if constexpr (STR) { // border columns N .. n-1 of every row, mirrored into rows N .. n-1 by the series lanes
-            double *dst = Dr + N;
+            double *dst = Dw + N; // (A-lanes: the dummy row -- their pb is not a row of Ps)
             if constexpr (K == 4 && N % 2 == 0) {
                 *reinterpret_cast<v2d *>(dst) = v2d{pb[0], pb[1]};
                 *reinterpret_cast<v2d *>(dst + 2) = v2d{pb[2], pb[3]};
@@ -802,7 +881,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // which smoother serves the shapes with n > 16: the MFMA kernel, or (mk_set_kernel_variant(ctx, MK_VARIANT_WIDE_SMOOTHER,
-// 1), for A/B measurements) the round-1 kernel -- both tested against the oracle
+// 1 / 2), for A/B measurements) the round-1 kernel / the MFMA kernel without the lane fold -- all tested against the oracle
 template <int N, int K>
 static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
 {
@@ -815,7 +894,11 @@ static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
             if (proj) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
         } else {
-#define MK_LAUNCH_WIDE(E, S) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S>), dim3(grid), dim3(64), 0, s, a)
+#define MK_LAUNCH_WIDE(E, S)                                                                                      \
+    do {                                                                                                          \
+        if (a.variant & 4) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, false>), dim3(grid), dim3(64), 0, s, a); \
+        else hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, true>), dim3(grid), dim3(64), 0, s, a);          \
+    } while (0)
             if (a.sym) {
                 if (epi == 1) MK_LAUNCH_WIDE(1, true);
                 else if (epi == 2) MK_LAUNCH_WIDE(2, true);

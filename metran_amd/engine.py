@@ -88,12 +88,12 @@ class BatchedKalman:
             pass
 
     # ------------------------------------------------------------------ kernel variants (A/B measurements)
-    _VARIANTS = {"smoother16": (0, ("record", "blk")), "wide_smoother": (1, ("mfma", "v1")),
+    _VARIANTS = {"smoother16": (0, ("record", "blk")), "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded")),
                  "wide_filter": (2, ("split", "lane_per_state"))}
 
     def set_variant(self, which, name):
         """Choose between two equivalent kernels of a shape class (``mk_set_kernel_variant``): ``"smoother16"``:
-        ``"record"`` (default) | ``"blk"``; ``"wide_smoother"``: ``"mfma"`` (default) | ``"v1"``.  Both members of a pair
+        ``"record"`` (default) | ``"blk"``; ``"wide_smoother"``: ``"mfma"`` (default) | ``"v1"`` | ``"mfma_unfolded"``.  Both members of a pair
         are tested against the oracle; there is no environment switch."""
         sel, names = self._VARIANTS[which]
         check(self._L.mk_set_kernel_variant(self._ctx, sel, names.index(name)))
