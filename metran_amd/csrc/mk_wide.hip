@@ -494,6 +494,99 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // cross-lane traffic at all (the right-looking form it replaces moved row j to every lane with 2(n-j)
         // readlanes per column, 1332 VALU instructions a step at n = 36, on a kernel that is VALU-issue bound).
         // u_c goes to LDS BEFORE the reciprocal: the write -> read round trip of row c+1 overlaps the pivot chain.
+        if constexpr (FOLD) {
+            // SOFTWARE-PIPELINED over the columns.  The plain loop is a chain of n stages, each: last multiply-add ->
+            // sum -> LDS store of U(., c) -> pivot (readlane + q_c) -> reciprocal (5 dependent instructions) -> scale ->
+            // LDS read of row c+1 of U (which waits for the store) -> its c+1 multiply-adds: ~330 cycles a stage of which the
+            // wavefront issues for ~130.  Here stage c (i) fetches row c+1 of U for k <= c-1 BEFORE its own store (those
+            // elements are old), (ii) finishes column c with the one missing term, k = c-1, whose operand U(c, c-1) came
+            // out of stage c-1 as a readlane of the lane that holds row c (no LDS round trip on the critical path),
+            // (iii) issues the reciprocal and runs the multiply-adds of column c+1 over k <= c-1 -- all operands final --
+            // BETWEEN the dependent instructions of its refinement.  Every accumulator sees the same terms in the same
+            // order as in the plain loop (even k / odd k chains, the k = c-1 term last in its chain): bit-identical.
+            double px0 = z[0], px1 = 0.0, ph0 = H > 0 ? A[0] : 0.0, ph1 = 0.0; // column being finished: even-k / odd-k chains
+            double sU = 0.0;                                                    // U(c, c-1), wavefront-uniform
+            constexpr int M1u = (n + 15) / 16;
+            double ucp[M1u], qc = Dm[PADC + 1];
+#pragma unroll
+            for (int m = 0; m < M1u; ++m) ucp[m] = 0.0;
+            if (!MK_TUNE_SKIP(a, 4))
+            sfor<0, n>(MK_LAMBDA(cc) {
+                constexpr int c = decltype(cc)::value;
+                // (i) ucp: the operands of column c+1 for k <= c-1 (lane 16 q + j holds U(c+1, 16 m + j) for every q) and qc = q_c
+                // were fetched during stage c-1, right behind ITS store of U(., c-1) (LDS operations of a wavefront
+                // complete in order): a whole stage of multiply-adds ago
+                // (ii) the missing term of column c
+                if constexpr (c >= 1) {
+                    if constexpr ((c - 1) % 2 == 0) px0 = fma(-sU, z[c - 1], px0);
+                    else px1 = fma(-sU, z[c - 1], px1);
+                    if constexpr (c < H) {
+                        if constexpr ((c - 1) % 2 == 0) ph0 = fma(-sU, A[c - 1], ph0);
+                        else ph1 = fma(-sU, A[c - 1], ph1);
+                    }
+                }
+                const double u = px0 + px1, hs = ph0 + ph1;
+                // U(r, c) for the rows r > c: rows >= H from the A-lanes r + OFF, head rows from lanes c+1 .. H-1
+                constexpr int r0 = (c + 1 > H ? c + 1 : H) + OFF;
+                if constexpr (r0 < 64) lds_store_masked<~0ull << r0, 8 * c>(Ur, u);
+                if constexpr (c + 1 < H) lds_store_masked<((1ull << H) - 1ull) & (~0ull << (c + 1)), 8 * c>(Ur, hs);
+                // operands of the NEXT stage's multiply-adds (column c+2, k <= c) and its q: issued here, consumed a stage later
+                constexpr int NRq = c + 2 < n ? (c + 16) / 16 : 0;
+                double ucq[NRq > 0 ? NRq : 1], qn = 0.0;
+                if constexpr (NRq > 0) {
+                    const double *Un = Um + tri_off(c + 2);
+                    sfor<0, NRq>(MK_LAMBDA(mm) {
+                        constexpr int m = decltype(mm)::value;
+                        if constexpr (16 * m + 15 < c + 1) {
+                            ucq[m] = Un[16 * m + l15];
+                        } else { // the last register: lanes at k > c re-read element c (never broadcast)
+                            const int k = 16 * m + l15;
+                            ucq[m] = Un[k < c + 1 ? k : c];
+                        }
+                    });
+                }
+                if constexpr (c + 1 < n) qn = Dm[(c + 1) * LD + PADC + 1];
+                const double piv = (c < H ? readlane_f64(hs, c) : readlane_f64(u, c + OFF)) + qc; // d_c = u_c(row c) + q_c
+                if constexpr (c + 1 < n) sU = c + 1 < H ? readlane_f64(hs, c + 1) : readlane_f64(u, c + 1 + OFF); // U(c+1, c)
+                pivmin = min_f64(pivmin, piv);
+                // (iii) 1/d_c (rcp_nr, spelled out) with the multiply-adds of column c+1 between its dependent instructions
+                double nx0 = 0.0, nx1 = 0.0, nh0 = 0.0, nh1 = 0.0;
+                if constexpr (c + 1 < n) nx0 = z[c + 1];
+                if constexpr (c + 1 < H) nh0 = A[c + 1];
+                constexpr int NP = (c + 1 < n) ? c / 2 : 0;           // pairs (k, k+1), k = 0, 2, .. < c-1
+                constexpr int P1 = NP / 3, P2 = 2 * NP / 3;
+                auto pairs = [&](auto lo, auto hi) __attribute__((always_inline)) {
+                    sfor<decltype(lo)::value, decltype(hi)::value>(MK_LAMBDA(pp) {
+                        constexpr int k = 2 * decltype(pp)::value;
+                        Group<16>::fmac2<k % 16, (k + 1) % 16, true>(nx0, ucp[k / 16], z[k], nx1, ucp[(k + 1) / 16], z[k + 1]);
+                    });
+                };
+                double r0v = __builtin_amdgcn_rcp(piv);
+                asm volatile("" : "+v"(r0v));
+                pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, P1>{});
+                double e = fma(-piv, r0v, 1.0); // relative error of r0
+                asm volatile("" : "+v"(e));
+                pairs(std::integral_constant<int, P1>{}, std::integral_constant<int, P2>{});
+                double pe = fma(e, e, e);       // e + e^2
+                asm volatile("" : "+v"(pe));
+                pairs(std::integral_constant<int, P2>{}, std::integral_constant<int, NP>{});
+                if constexpr (c + 1 < n && c % 2 == 1) Group<16>::fmac<(c - 1) % 16, true>(nx0, ucp[(c - 1) / 16], z[c - 1]);
+                if constexpr (c + 1 < H) { // head rows of column c+1, k <= c-1 (c + 1 < H <= 16: one operand register)
+                    sfor<0, c>(MK_LAMBDA(kk) {
+                        constexpr int k = decltype(kk)::value;
+                        if constexpr (k % 2 == 0) Group<16>::fmac<k % 16, true>(nh0, ucp[0], A[k]);
+                        else Group<16>::fmac<k % 16, true>(nh1, ucp[0], A[k]);
+                    });
+                }
+                const double ij0 = fma(r0v, pe, r0v); // r0 (1 + e + e^2): error e^3
+                const double ij = piv > 0.0 ? ij0 : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
+                z[c] = u * ij;                          // A-lanes: L(r, c); z-lanes: z~_c
+                if constexpr (c < H) A[c] = hs * ij;    // L(r, c), r < H
+                px0 = nx0, px1 = nx1, ph0 = nh0, ph1 = nh1;
+                qc = qn;
+                sfor<0, NRq>(MK_LAMBDA(mm) { ucp[decltype(mm)::value] = ucq[decltype(mm)::value]; });
+            });
+        } else {
         if (!MK_TUNE_SKIP(a, 4))
         sfor<0, n>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
@@ -509,51 +602,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     uc[m] = Uc[k < c ? k : c - 1];
                 }
             });
-            if constexpr (FOLD) {
-                // one recursion for both roles: even k into x0, odd k into x1 (the unfolded kernel's a0/a1 and s0/s1)
-                double x0 = z[c], x1 = 0.0, h0 = 0.0, h1 = 0.0;
-                sfor<0, c / 2>(MK_LAMBDA(pp) {
-                    constexpr int k = 2 * decltype(pp)::value;
-                    Group<16>::fmac2<k % 16, (k + 1) % 16, true>(x0, uc[k / 16], z[k], x1, uc[(k + 1) / 16], z[k + 1]);
-                });
-                if constexpr (c % 2 == 1) Group<16>::fmac<(c - 1) % 16, true>(x0, uc[(c - 1) / 16], z[c - 1]);
-                if constexpr (c < H) { // head rows (lanes 0 .. H-1; c < H <= 16: one operand register)
-                    h0 = A[c];
-                    sfor<0, c>(MK_LAMBDA(kk) {
-                        constexpr int k = decltype(kk)::value;
-                        if constexpr (k % 2 == 0) Group<16>::fmac<k % 16, true>(h0, uc[0], A[k]);
-                        else Group<16>::fmac<k % 16, true>(h1, uc[0], A[k]);
-                    });
-                }
-                const double u = x0 + x1, hs = h0 + h1;
-                // U(r, c) for the rows r > c: rows >= H from the A-lanes r + OFF, head rows from lanes c+1 .. H-1
-                constexpr int r0 = (c + 1 > H ? c + 1 : H) + OFF;
-                if constexpr (r0 < 64) lds_store_masked<~0ull << r0, 8 * c>(Ur, u);
-                if constexpr (c + 1 < H) lds_store_masked<((1ull << H) - 1ull) & (~0ull << (c + 1)), 8 * c>(Ur, hs);
-                wave_lds_sync();
-                const double piv = (c < H ? readlane_f64(hs, c) : readlane_f64(u, c + OFF)) + Dm[c * LD + PADC + 1]; // d_c = u_c(row c) + q_c
-                pivmin = min_f64(pivmin, piv);
-                const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
-                z[c] = u * ij;                          // A-lanes: L(r, c); z-lanes: z~_c
-                if constexpr (c < H) A[c] = hs * ij;    // L(r, c), r < H
-            } else {
-                double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
-                sfor<0, c>(MK_LAMBDA(kk) {
-                    constexpr int k = decltype(kk)::value;
-                    if constexpr (k % 2 == 0) Group<16>::fmac2<k % 16, k % 16, true>(a0, uc[k / 16], A[k], s0, uc[k / 16], z[k]);
-                    else Group<16>::fmac2<k % 16, k % 16, true>(a1, uc[k / 16], A[k], s1, uc[k / 16], z[k]);
-                });
-                const double u = a0 + a1;
-                if constexpr (c + 1 < n) // U(r, c), lanes r > c only: the rows are packed (replica lanes >= n rewrite row n-1)
-                    lds_store_masked<~0ull << (c + 1), 8 * c>(Ur, u);
-                wave_lds_sync();
-                const double piv = readlane_f64(u, c) + Dm[c * LD + PADC + 1]; // d_c = u_c(lane c) + q_c
-                pivmin = min_f64(pivmin, piv);
-                const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
-                A[c] = u * ij;          // L(r, c)
-                z[c] = (s0 + s1) * ij;  // z~_c
-            }
+            double a0 = A[c], a1 = 0.0, s0 = z[c], s1 = 0.0;
+            sfor<0, c>(MK_LAMBDA(kk) {
+                constexpr int k = decltype(kk)::value;
+                if constexpr (k % 2 == 0) Group<16>::fmac2<k % 16, k % 16, true>(a0, uc[k / 16], A[k], s0, uc[k / 16], z[k]);
+                else Group<16>::fmac2<k % 16, k % 16, true>(a1, uc[k / 16], A[k], s1, uc[k / 16], z[k]);
+            });
+            const double u = a0 + a1;
+            if constexpr (c + 1 < n) // U(r, c), lanes r > c only: the rows are packed (replica lanes >= n rewrite row n-1)
+                lds_store_masked<~0ull << (c + 1), 8 * c>(Ur, u);
+            wave_lds_sync();
+            const double piv = readlane_f64(u, c) + Dm[c * LD + PADC + 1]; // d_c = u_c(lane c) + q_c
+            pivmin = min_f64(pivmin, piv);
+            const double ij = piv > 0.0 ? rcp_nr(piv) : 0.0; // d_c <= 0: null direction dropped (see ldlt_factor)
+            A[c] = u * ij;          // L(r, c)
+            z[c] = (s0 + s1) * ij;  // z~_c
         });
+        }
         wave_lds_sync();
         // backward: x_c = z~_c - sum_{k>c} L(k,c) x_k.
         // Round 3: DOT form over the columns c = n-2 .. 0 with L^T read back from LDS at wavefront-uniform addresses -- the
