@@ -94,6 +94,32 @@ struct Group<16> {
             asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%6" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, %5 row_newbcast:%7" MK_DPPMASK
                          : "+v"(acc0), "+v"(acc1) : "v"(src0), "v"(mul0), "v"(src1), "v"(mul1), "n"(J0), "n"(J1));
     }
+    // four in one statement, two accumulators alternating (acc0, acc1, acc0, acc1): the dot-form sweeps of the wide smoother
+    template <int J0, int J1, int J2, int J3, bool NEG = false>
+    static __device__ __forceinline__ void fmac4(double &acc0, double &acc1, double s0, double m0, double s1, double m1, double s2,
+                                                 double m2, double s3, double m3)
+    {
+        if constexpr (NEG)
+            asm volatile("v_fmac_f64_dpp %0, %2, -%3 row_newbcast:%10" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, -%5 row_newbcast:%11" MK_DPPMASK
+                         "\n\tv_fmac_f64_dpp %0, %6, -%7 row_newbcast:%12" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %8, -%9 row_newbcast:%13" MK_DPPMASK
+                         : "+v"(acc0), "+v"(acc1)
+                         : "v"(s0), "v"(m0), "v"(s1), "v"(m1), "v"(s2), "v"(m2), "v"(s3), "v"(m3), "n"(J0), "n"(J1), "n"(J2), "n"(J3));
+        else
+            asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%10" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, %5 row_newbcast:%11" MK_DPPMASK
+                         "\n\tv_fmac_f64_dpp %0, %6, %7 row_newbcast:%12" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %8, %9 row_newbcast:%13" MK_DPPMASK
+                         : "+v"(acc0), "+v"(acc1)
+                         : "v"(s0), "v"(m0), "v"(s1), "v"(m1), "v"(s2), "v"(m2), "v"(s3), "v"(m3), "n"(J0), "n"(J1), "n"(J2), "n"(J3));
+    }
+    // four independent accumulators, one broadcast lane, one multiplier: acc_i += bcast<J>(s_i) * mul
+    template <int J>
+    static __device__ __forceinline__ void fmac4x(double &a0, double &a1, double &a2, double &a3, double s0, double s1, double s2,
+                                                  double s3, double mul)
+    {
+        asm volatile("v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %5, %8 row_newbcast:%9" MK_DPPMASK
+                     "\n\tv_fmac_f64_dpp %2, %6, %8 row_newbcast:%9" MK_DPPMASK "\n\tv_fmac_f64_dpp %3, %7, %8 row_newbcast:%9" MK_DPPMASK
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                     : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(mul), "n"(J));
+    }
     template <int J, int C0, int C1, bool NEG, int n>
     static __device__ __forceinline__ void axpy_lane(double (&acc)[n], const double (&src)[n], double mul)
     {

@@ -384,10 +384,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             padS -= a.ts * RS;
         }
         if constexpr (PROJ) {
+            // project<N, K, 64> picks the lane's diagonal element out of its row with N compare-selects and the K x K factor block
+            // with readlanes (~140 vector instructions a step on a kernel bound by their issue); Ps[t] is IN the LDS matrix at
+            // this point: the diagonal is one per-lane read, the factor block K wavefront-uniform rows.  Same arithmetic.
             double mean, var, gam[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) gam[k] = pcl[k];
-            project<N, K, G>(xv, row, gam, pcl[K], pcl[K + 1], lane, mean, var);
+            double m = xv, tt = 0.0;
+            const double diag = Dm[r * LD + (lane < N ? lane : 0)];
+            double pfk[K][K];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int l = 0; l < K; ++l) pfk[k][l] = Dm[(N + (k < l ? k : l)) * LD + N + (k < l ? l : k)]; // [kk][ll] = [ll][kk] = element (kk, ll), kk <= ll
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                m = fma(gam[kk], Group<G>::template bcast<N + kk>(xv), m);
+            });
+            sfor<0, K>(MK_LAMBDA(k) {
+                constexpr int kk = decltype(k)::value;
+                double u = 2.0 * row[N + kk];
+                sfor<0, K>(MK_LAMBDA(l) { u = fma(gam[decltype(l)::value], pfk[kk][decltype(l)::value], u); });
+                tt = fma(gam[kk], u, tt);
+            });
+            mean = fma(pcl[K], m, pcl[K + 1]);
+            const double v = pcl[K] * pcl[K] * (diag + tt);
+            var = v < 0.0 ? 0.0 : v; // kalmanfilter.py:601-602 (np.maximum keeps a NaN)
             if (lane < N && live) {
                 if (pM) *pM = mean;
                 if (pV) *pV = var;
@@ -430,8 +452,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     {
         double Psn[n];
         load_pf_rows(Psn);
-        store(xs, Psn);
         store_row<n>(Dr, Psn);
+        wave_lds_sync(); // (the projection epilogue reads the diagonal and the factor block from the LDS matrix)
+        store(xs, Psn);
     }
     double pivmin = 1.0;
 
@@ -659,18 +682,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 });
                 double b0 = z[c], b1 = 0.0;
-                // k = n-1 .. c+1 (z[c+1], the freshest operand, last), two per statement
-                sfor<0, (n - 1 - c) / 2>(MK_LAMBDA(pp) {
-                    constexpr int k = n - 1 - 2 * decltype(pp)::value; // pair (k, k-1), both > c
-                    if constexpr (k % 2 == 0)
-                        Group<16>::fmac2<k % 16, (k - 1) % 16, true>(b0, lc[k / 16 - M0], z[k], b1, lc[(k - 1) / 16 - M0], z[k - 1]);
-                    else
-                        Group<16>::fmac2<k % 16, (k - 1) % 16, true>(b1, lc[k / 16 - M0], z[k], b0, lc[(k - 1) / 16 - M0], z[k - 1]);
+                // k = n-1 .. c+1 (z[c+1], the freshest operand, last), four per statement (hipcc pads every asm statement that
+                // follows another with an s_nop), then a pair and a single; even k into b0, odd k into b1
+                constexpr int CNT = n - 1 - c, Q4 = CNT / 4, R2 = (CNT % 4) / 2;
+                auto acc_of = [&](auto kk) -> double & { if constexpr (decltype(kk)::value % 2 == 0) return b0; else return b1; };
+                sfor<0, Q4>(MK_LAMBDA(qq) {
+                    constexpr int k = n - 1 - 4 * decltype(qq)::value; // (k, k-1, k-2, k-3), all > c
+                    Group<16>::fmac4<k % 16, (k - 1) % 16, (k - 2) % 16, (k - 3) % 16, true>(
+                        acc_of(std::integral_constant<int, k>{}), acc_of(std::integral_constant<int, k - 1>{}), lc[k / 16 - M0], z[k],
+                        lc[(k - 1) / 16 - M0], z[k - 1], lc[(k - 2) / 16 - M0], z[k - 2], lc[(k - 3) / 16 - M0], z[k - 3]);
                 });
-                if constexpr ((n - 1 - c) % 2 == 1) {
+                if constexpr (R2 == 1) {
+                    constexpr int k = n - 1 - 4 * Q4; // pair (k, k-1)
+                    Group<16>::fmac2<k % 16, (k - 1) % 16, true>(acc_of(std::integral_constant<int, k>{}), lc[k / 16 - M0], z[k],
+                                                                 acc_of(std::integral_constant<int, k - 1>{}), lc[(k - 1) / 16 - M0], z[k - 1]);
+                }
+                if constexpr (CNT % 2 == 1) {
                     constexpr int k = c + 1;
-                    if constexpr (k % 2 == 0) Group<16>::fmac<k % 16, true>(b0, lc[k / 16 - M0], z[k]);
-                    else Group<16>::fmac<k % 16, true>(b1, lc[k / 16 - M0], z[k]);
+                    Group<16>::fmac<k % 16, true>(acc_of(std::integral_constant<int, k>{}), lc[k / 16 - M0], z[k]);
                 }
                 z[c] = b0 + b1;
             });
@@ -686,10 +715,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int m = 0; m < M1; ++m) dreg[m] = dl[16 * m + l15];
             sfor<0, n>(MK_LAMBDA(mm) {
                 constexpr int m = decltype(mm)::value;
-                if constexpr (m % 4 == 0) Group<16>::fmac<m % 16, false>(a0, dreg[m / 16], z[m]);
-                else if constexpr (m % 4 == 1) Group<16>::fmac<m % 16, false>(a1, dreg[m / 16], z[m]);
-                else if constexpr (m % 4 == 2) Group<16>::fmac<m % 16, false>(a2, dreg[m / 16], z[m]);
-                else Group<16>::fmac<m % 16, false>(a3, dreg[m / 16], z[m]);
+                if constexpr (m % 4 == 0 && m + 3 < n) {
+                    asm volatile("v_fmac_f64_dpp %0, %4, %6 row_newbcast:%10" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, %7 row_newbcast:%11" MK_DPPMASK
+                                 "\n\tv_fmac_f64_dpp %2, %5, %8 row_newbcast:%12" MK_DPPMASK "\n\tv_fmac_f64_dpp %3, %5, %9 row_newbcast:%13" MK_DPPMASK
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                                 : "v"(dreg[m / 16]), "v"(dreg[(m + 3) / 16]), "v"(z[m]), "v"(z[m + 1]), "v"(z[m + 2]), "v"(z[m + 3]),
+                                   "n"(m % 16), "n"((m + 1) % 16), "n"((m + 2) % 16), "n"((m + 3) % 16));
+                    static_assert(m / 16 == (m + 1) / 16 && (m + 2) / 16 == (m + 3) / 16, "operand registers of a quad");
+                } else if constexpr (m + 3 >= n || m % 4 != 0) {
+                    if constexpr (m >= n - n % 4) { // the tail n % 4 terms
+                        if constexpr (m % 4 == 0) Group<16>::fmac<m % 16, false>(a0, dreg[m / 16], z[m]);
+                        else if constexpr (m % 4 == 1) Group<16>::fmac<m % 16, false>(a1, dreg[m / 16], z[m]);
+                        else if constexpr (m % 4 == 2) Group<16>::fmac<m % 16, false>(a2, dreg[m / 16], z[m]);
+                        else Group<16>::fmac<m % 16, false>(a3, dreg[m / 16], z[m]);
+                    }
+                }
             });
             xs = (a0 + a1) + (a2 + a3);
             if constexpr (FOLD) { // the A-lanes carried rows of L, not of J: they become replicas of lane n-1 again
@@ -781,10 +821,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 sfor<2 * p0, 2 * p1>(MK_LAMBDA(cc) {
                     constexpr int c = decltype(cc)::value;
                     const double dc = c % 2 ? dr[c / 2 - p0].y : dr[c / 2 - p0].x;
-                    sfor<0, K>(MK_LAMBDA(kk) {
-                        constexpr int k = decltype(kk)::value;
-                        Group<16>::fmac2<c % 16, c % 16, false>(vb[k], du[k][c / 16], z[c], vfa[k], ju[k][c / 16], dc);
-                    });
+                    if constexpr (K == 4) { // all eight multiply-adds of a column in ONE statement (no s_nop between them)
+                        Group<16>::fmac4x<c % 16>(vb[0], vb[1], vb[2], vb[3], du[0][c / 16], du[1][c / 16], du[2][c / 16], du[3][c / 16], z[c]);
+                        Group<16>::fmac4x<c % 16>(vfa[0], vfa[1], vfa[2], vfa[3], ju[0][c / 16], ju[1][c / 16], ju[2][c / 16], ju[3][c / 16], dc);
+                    } else {
+                        sfor<0, K>(MK_LAMBDA(kk) {
+                            constexpr int k = decltype(kk)::value;
+                            Group<16>::fmac2<c % 16, c % 16, false>(vb[k], du[k][c / 16], z[c], vfa[k], ju[k][c / 16], dc);
+                        });
+                    }
                 });
             });
             if constexpr (n % 2 == 1) {
@@ -805,16 +850,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             wave_lds_sync();
 #pragma unroll
             for (int k = 0; k < 4; ++k) pb[k] = k < K ? pfb[k < K ? k : 0] : 0.0;
-            sfor<0, K>(MK_LAMBDA(kk) { // pb[k] += J[r][m] Vf[m][k]
-                constexpr int k = decltype(kk)::value;
-                double vu[M1];
+            if constexpr (K == 4) { // pb[k] += J[r][m] Vf[m][k]: the four columns side by side (four independent chains a statement)
+                double vu[4][M1];
 #pragma unroll
-                for (int m = 0; m < M1; ++m) vu[m] = vf[k * VLD + oi[m]];
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int m = 0; m < M1; ++m) vu[k][m] = vf[k * VLD + oi[m]];
                 sfor<0, n>(MK_LAMBDA(mm) {
                     constexpr int m = decltype(mm)::value;
-                    Group<16>::fmac<m % 16, false>(pb[k], vu[m / 16], z[m]);
+                    Group<16>::fmac4x<m % 16>(pb[0], pb[1], pb[2], pb[3], vu[0][m / 16], vu[1][m / 16], vu[2][m / 16], vu[3][m / 16], z[m]);
                 });
-            });
+            } else {
+                sfor<0, K>(MK_LAMBDA(kk) { // pb[k] += J[r][m] Vf[m][k]
+                    constexpr int k = decltype(kk)::value;
+                    double vu[M1];
+#pragma unroll
+                    for (int m = 0; m < M1; ++m) vu[m] = vf[k * VLD + oi[m]];
+                    sfor<0, n>(MK_LAMBDA(mm) {
+                        constexpr int m = decltype(mm)::value;
+                        Group<16>::fmac<m % 16, false>(pb[k], vu[m / 16], z[m]);
+                    });
+                });
+            }
             // B operand of the factor k-step: B[k = l4][col = 16 Jb + l15] = vb[k] of lane 16 Jb + l15
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) Bv[jb] = vbuf[l4 * N + 16 * jb + l15];
