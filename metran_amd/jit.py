@@ -1,7 +1,8 @@
 """Run-time shape specialisation: kernels for an (N series, K factors) pair that is not in the
 ahead-of-time list are compiled on demand from the SAME source (``csrc/mk_kernels.hip``) by hipcc,
-statically checked for DPP hazards (``scripts/check_dpp_hazards.py``; the fused ``v_fmac_f64_dpp`` is
-inline asm that hipcc does not pad) and registered with the library (``mk_register_shape_module``).
+statically checked for the hazards hipcc does not pad around inline asm (``scripts/check_dpp_hazards.py``: the fused
+``v_fmac_f64_dpp``; ``scripts/check_asm_hazards.py``: MFMA results, MFMA operands, lane selects and transcendental
+results with one side inside an asm block) and registered with the library (``mk_register_shape_module``).
 Built modules are cached by a hash of the sources under ``$METRAN_HIP_CACHE`` (default
 ``~/.cache/metran_amd``).  Set ``METRAN_HIP_JIT=0`` to forbid compilation (unsupported shapes raise).
 """
@@ -80,11 +81,12 @@ def build_shape_module(N, K):
         if r.returncode != 0:
             raise MetranHipError("hipcc failed for shape (%d,%d):\n%s" % (N, K, r.stderr[-2000:]))
         asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
-        checker = os.path.join(_ROOT, "scripts", "check_dpp_hazards.py")
-        if asm and os.path.exists(checker):
-            c = subprocess.run([sys.executable, checker, os.path.join(tmp, asm[0])], capture_output=True, text=True)
-            if c.returncode != 0:
-                raise MetranHipError("DPP hazard check failed for shape (%d,%d):\n%s" % (N, K, c.stdout[-2000:]))
+        for script, what in (("check_dpp_hazards.py", "DPP"), ("check_asm_hazards.py", "inline-asm")):
+            checker = os.path.join(_ROOT, "scripts", script)
+            if asm and os.path.exists(checker):
+                c = subprocess.run([sys.executable, checker, os.path.join(tmp, asm[0])], capture_output=True, text=True)
+                if c.returncode != 0:
+                    raise MetranHipError("%s hazard check failed for shape (%d,%d):\n%s" % (what, N, K, c.stdout[-2000:]))
         so = os.path.join(tmp, "mod.so")
         r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj],
                            capture_output=True, text=True)
