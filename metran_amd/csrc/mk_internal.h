@@ -58,7 +58,7 @@ struct SmootherArgs {
     const double *F, *Pf;
     double *S, *Ps;
     unsigned *status;
-    long variant;        // bit 0: n <= 15 records -> smoother_blk_kernel; bit 1: n > 16 -> smoother_wave_kernel (round 1); bit 2: n > 16 -> the MFMA kernel without the lane fold;
+    long variant;        // bit 0: n <= 15 records -> smoother_blk_kernel; bit 1: n > 16 -> smoother_wave_kernel (round 1); bit 2: n > 16 -> the MFMA kernel without the lane fold; bits 3 / 4: (-DMK_EXPERIMENTAL_BLK4 builds only) n > 16, n % 4 == 0 -> the 4x4x4 MFMA block path with / without the lane fold;
                          // set by the C ABI from mk_set_kernel_variant.  Every variant is a tested, equivalent kernel.
 };
 

@@ -1,5 +1,6 @@
 """Same-box A/B of the wide-smoother variants at configs[3] size (4096 x (32,4), 30 % missing, projection path), interleaved.
-  gpurun -- 'python scripts/experiments/ab_wide_variants.py [T]'"""
+  gpurun -- 'python scripts/experiments/ab_wide_variants.py [T [variant ...]]'      (default: mfma mfma_unfolded;
+  mfma_blk4 / mfma_blk4_unfolded need METRAN_HIP_LIBRARY=ab/libmetran_hip_blk4.so, scripts/experiments/build_blk4.sh)"""
 import sys
 
 import torch
@@ -10,10 +11,11 @@ from metran_amd.synthetic import make_dfm_batch_torch  # noqa: E402
 
 B, N, K = 4096, 32, 4
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+VARIANTS = tuple(sys.argv[2:]) or ("mfma", "mfma_unfolded")
 d = make_dfm_batch_torch(B, N, K, T, seed=4000, device=torch.device("cuda", 0), missing=0.3)
 res = {}
 for rnd in range(2):
-    for variant in ("mfma", "mfma_unfolded"):
+    for variant in VARIANTS:
         kf = BatchedKalman(layout="time_major").set_variant("wide_smoother", variant)
         kf.set_observations(d["obs"]).set_loadings(d["loadings"])
         bufs = kf.alloc_projection(B)
@@ -28,5 +30,9 @@ for rnd in range(2):
         res.setdefault(variant, []).append((bufs["sim_means"].clone(), bufs["sim_vars"].clone()))
         kf.close()
         del bufs
-a, b = res["mfma"][0], res["mfma_unfolded"][0]
-print("bit-identical projection outputs:", torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))
+a = res[VARIANTS[0]][0]
+for v in VARIANTS[1:]:
+    b = res[v][0]
+    print("%s vs %s: bit-identical projection outputs: %s; max |d mean| %.2e, max |d var| %.2e"
+          % (v, VARIANTS[0], torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), float((a[0] - b[0]).abs().max()),
+             float((a[1] - b[1]).abs().max())))
