@@ -127,3 +127,21 @@ def test_no_environment_variable_changes_a_result():
     env = dict(os.environ, MK_WIDE_TUNE="7", MK_WIDE_SMOOTHER="v1", MK_SMOOTHER16="blk", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", ENV_SCRIPT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "env ignored ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_product_library_has_no_experimental_variant():
+    """The 4x4x4 MFMA block path of the wide smoother (values 3 / 4 of MK_VARIANT_WIDE_SMOOTHER) exists only in a library built
+    with -DMK_EXPERIMENTAL_BLK4 (scripts/experiments/build_blk4.sh): the product library refuses the selector and keeps its
+    default, so that no switch of the shipped ABI reaches a kernel the GPU tier does not test."""
+    from metran_amd.engine import BatchedKalman
+
+    if os.environ.get("METRAN_HIP_LIBRARY"):
+        pytest.skip("a non-default library is loaded")
+    kf = BatchedKalman()
+    try:
+        for name in ("mfma_blk4", "mfma_blk4_unfolded"):
+            with pytest.raises(Exception):
+                kf.set_variant("wide_smoother", name)
+        assert kf.get_variant("wide_smoother") == "mfma"
+    finally:
+        kf.close()
