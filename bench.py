@@ -441,6 +441,54 @@ def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=3, warmu
     return out
 
 
+def measure_transfers(dev, B, T, N, K, ms_per_step):
+    """Opt-in (``--transfers``): what a caller that starts and ends on the HOST pays on top of the HBM-resident pass
+    (never ``value``): the observation upload and the download of the results over the host link,
+    pinned buffers, best of 3.  The full state set is sized, not allocated on the host: the download rate is measured
+    on a 1 GiB piece."""
+    import torch
+
+    n = N + K
+    out = {}
+    obs_bytes = B * T * N * 8
+    h = torch.empty(obs_bytes // 8, dtype=torch.float64).pin_memory()
+    d = torch.empty(obs_bytes // 8, dtype=torch.float64, device=dev)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    out["obs_upload"] = {"bytes": obs_bytes, "seconds": best, "GBps": obs_bytes / best / 1e9}
+    del h, d
+    piece = 1 << 30
+    h = torch.empty(piece // 8, dtype=torch.float64).pin_memory()
+    d = torch.zeros(piece // 8, dtype=torch.float64, device=dev)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h.copy_(d, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    d2h = piece / best / 1e9
+    out["download_GBps"] = d2h
+    full = B * T * (3 * (n + n * n) + 2) * 8        # predicted, filtered, smoothed moments + sigma, detf
+    proj = B * T * 2 * N * 8                        # projection epilogue: simulated means + variances
+    t_pass = ms_per_step / 1e3
+    t_up = out["obs_upload"]["seconds"]
+    out["host_to_host_models_per_s"] = {
+        "all_state_outputs": B / (t_up + t_pass + full / (d2h * 1e9)),
+        "projection_outputs_only": B / (t_up + t_pass + proj / (d2h * 1e9)),
+        "note": "upload + one resident pass (the headline's ms_per_step) + download, serial, one GPU; the projection line "
+                "prices the download only (its pass is the configs[1] pass with the fused epilogue)",
+        "bytes": {"all_state_outputs": full, "projection_outputs_only": proj}}
+    return out
+
+
 def secondary_factor_analysis(dev, R=4096, T=1000, N=8, K=2, reps=3):
     """SURVEY section 8 row f4 in the driver's record: ``FactorAnalysisBatch.solve`` on R synthetic block-structure models
     (observations generated on the device, 10 % missing): correlations -> eigenvalues / MAP test -> minres -> loadings ->
@@ -516,6 +564,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 PMC child runs after the timed region (one GPU only)")
+    ap.add_argument("--transfers", action="store_true",
+                    help="one GPU: also time the host-link transfers a host-to-host caller pays (reported under 'pcie', never in value)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[3] / configs[4] lines that the default one-GPU run appends after the headline")
     ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"])
@@ -665,6 +715,11 @@ def main():
                 res["secondary"][name] = fn()
             except Exception as e:  # noqa: BLE001
                 res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and args.transfers and not args.dry_run:
+        try:
+            res["pcie"] = measure_transfers(dev, B, T, N, K, res["ms_per_step"])
+        except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure here
+            res["pcie"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
