@@ -46,5 +46,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -- python $GRAF
 f=$(ls /tmp/ktd/*/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then head -1 $f > $OUT/default_kernel_stats.csv; grep "mk::" $f >> $OUT/default_kernel_stats.csv; fi
 cd $GRAFT_REPO_ROOT
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --transfers > $OUT/bench_default.json 2> $OUT/bench_default.err   # (--transfers: adds the pcie object)
 echo "== default"; cat $OUT/default_kernel_stats.csv | cut -c1-160
