@@ -154,8 +154,6 @@ MK_API int mk_sync(mk_context *ctx);
  *   MK_VARIANT_SMOOTHER16     n <= 15, packed records: 0 smoother_record_kernel (DPP), 1 smoother_blk_kernel (4x4x4 MFMA)
  *   MK_VARIANT_WIDE_SMOOTHER  n > 16: 0 the blocked MFMA smoother (n <= 36: rows of A folded into the idle lanes),
  *                             1 smoother_wave_kernel (round 1, row per lane), 2 the MFMA smoother without the fold
- *                             (3 / 4: the 4x4x4 MFMA block path with / without the fold exist only in a library built with
- *                             -DMK_EXPERIMENTAL_BLK4, scripts/experiments/; the product library answers MK_ERR_INVALID)
  *   MK_VARIANT_WIDE_FILTER    n > 16, N <= 32: 0 filter_split_kernel (series on the lanes, factor block replicated:
  *                             2 or 4 models per wavefront), 1 filter_kernel<N,K,64> (one state per lane) */
 enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_COUNT = 3 };

@@ -261,11 +261,7 @@ MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
 {
     MK_CTX(ctx);
     if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
-#ifdef MK_EXPERIMENTAL_BLK4
-    constexpr int wide_max = 4; // 3 / 4: the 4x4x4 MFMA block path with / without the lane fold (experimental build only, scripts/experiments/build_blk4.sh)
-#else
     constexpr int wide_max = 2;
-#endif
     if (value < 0 || value > (which == MK_VARIANT_WIDE_SMOOTHER ? wide_max : 1))
         return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for MK_VARIANT_WIDE_SMOOTHER)");
     ctx->variant[which] = value;
@@ -473,8 +469,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
     mk::SmootherArgs a;
     a.variant = (ctx->variant[MK_VARIANT_SMOOTHER16] ? 1 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 1 ? 2 : 0) |
-                (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 2 ? 4 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 3 ? 8 : 0) |
-                (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 4 ? 16 : 0);
+                (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 2 ? 4 : 0);
     a.rs = 0;
     a.sym = 0;
     a.state_means = a.state_vars = nullptr;

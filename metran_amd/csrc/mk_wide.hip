@@ -247,19 +247,6 @@ constexpr int lt_off(int n, int c)
     return s;
 }
 
-#ifdef MK_EXPERIMENTAL_BLK4
-// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products, D_b = A_b^T-as-stored B_b + C_b (see smoother_blk_kernel)
-__device__ __forceinline__ double mfma4(double a, double b, double c, int, int, int)
-{
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-// An MFMA result that an INLINE-ASM instruction consumes (lds_store_masked: exec-masked ds_write) gets no wait states from
-// hipcc -- the statement is opaque to its hazard recogniser -- and "DGEMM 4x4x4 writes a VGPR -> LDS reads it as store data"
-// needs 9 (scripts/check_asm_hazards.py, rule M2).  This was the block path's round-3 irreproducibility: the write-back
-// stored accumulators 3-8 wait states behind their last MFMA; alone on its SIMD a wavefront got away with it, with a
-// partner wavefront holding the MFMA pipe the store read the register before the result had landed.
-__device__ __forceinline__ void mfma_settle(double &x) { asm volatile("s_nop 7\n\ts_nop 0" : "+v"(x)); }
-#endif
 
 // EPI / SYM as in smoother_record_kernel: 0 records, 1 + projection, 2 + state means and variances; SYM: the
 // filtered (and smoothed) records are packed-symmetric
@@ -273,36 +260,14 @@ __device__ __forceinline__ void mfma_settle(double &x) { asm volatile("s_nop 7\n
 // mk_set_kernel_variant(ctx, MK_VARIANT_WIDE_SMOOTHER, 2) and tested for exactly that).  The A-lanes are no longer
 // replicas of lane n-1: their own-row LDS writes go to a dummy row, the smoothed mean is re-broadcast from lane n-1, and
 // every global store still sees replicas.
-// BLK4 (round 3; n a multiple of 4, full-square records): everything after the fused factorisation / forward sweep runs on
-// 4x4 blocks of v_mfma_f64_4x4x4_4b_f64 -- four independent 4x4x4 products per instruction, which at n = 36 = 9 x 4 wastes
-// nothing on padding (the 16x16x4 tiles above pad 36 to 48: 44 % of their multiply-adds) and, unlike the row-per-lane
-// substitution, uses all 64 lanes:
-//   * L (negated, lower blocks only) goes to LDS in block-packed form; the back substitution  J^T = L^-T Z~^T  runs block
-//     row by block row: acc = Z~^T(k, :) (4 columns of Z~ through a small LDS buffer, read transposed),
-//     acc -= L(i,k)^T J^T(i, :) for i > k (the block L(i,k) read replicated into the four block slots of an operand
-//     register), then  J^T(k, :) = L_kk^-T acc  with the inverse of the unit-triangular 4x4 diagonal block (six entries,
-//     computed by every lane from wavefront-uniform reads) as the replicated operand;
-//   * a register holds four column blocks of one block row (lane x0 + 4b + 16x2 = element (x2, x0) of block b; as an A
-//     operand a block acts as its transpose -- the layout of smoother_blk_kernel), so J^T stays in 27 registers from the
-//     substitution through both products: X(k,:) = sum_i D(k,i) J^T(i,:), Ps(i,:) += J(i,k) X(k,:) block row by block row
-//     of X (one row of X live), upper block triangle only;
-//   * the smoothed mean rides along as column n: delta is injected into the spare block slot of X, F[t] seeds the same
-//     slot of the accumulator.
-// 567 MFMA instructions of 16 cycles per step (9.1 k cycles of the f64 pipe) replace 135 16x16x4 tiles (8.6 k), the
-// row-per-lane back substitution (630 multiply-adds + 1 260 readlanes, measured 25 % of the kernel) and the J staging.
-// Built only with -DMK_EXPERIMENTAL_BLK4 (scripts/experiments/build_blk4.sh): measured in round 3 at -6 % against the tile
-// kernel of that time, withheld for results that were not reproducible at full occupancy; the cause (mfma_settle above) was
-// found by static analysis after the round's GPU time had ended -- NOT yet re-validated on hardware, hence not in the product.
+// (BLK4P: the 4x4x4 MFMA block path of rounds 3-4 -- measured 127 ms against 81 ms in round 4, removed from this file;
+// source and record in scripts/experiments/.  The template parameter and the `BLK4 = false` branches are what is left.)
 template <int N, int K, int EPI, bool SYM, bool FOLDP, bool BLK4P = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_mfma_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, G = 64;
-#ifdef MK_EXPERIMENTAL_BLK4
-    constexpr bool BLK4 = BLK4P;
-#else
     constexpr bool BLK4 = false;
-    static_assert(!BLK4P, "the block path is an experimental build (-DMK_EXPERIMENTAL_BLK4)");
-#endif
+    static_assert(!BLK4P, "the block path was removed (scripts/experiments/README.md)");
     static_assert(!BLK4 || (n % 4 == 0 && !SYM), "block path: n a multiple of 4, full-square records");
     constexpr int NBK = (n + 3) / 4;                 // BLK4: 4-wide blocks per dimension
     constexpr int NGR = (NBK + 1 + 3) / 4;           // registers per block row: NBK column blocks + the mean column
@@ -1044,210 +1009,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             });
         });
         } else {
-#ifdef MK_EXPERIMENTAL_BLK4
-        // =========================== BLK4: 4x4x4 block path (see the kernel's header) ===========================
-        // lane = x0 + 4 b + 16 x2: element (x2, x0) of block slot b
-        const int x0 = lane & 3, bs = (lane >> 2) & 3, x2 = lane >> 4;
-        const int e16 = 4 * x2 + x0; // offset of the lane's element inside a 16-double block
-        // ---- -L to LDS, block-packed lower triangle: block (i, kb) at 16 (i (i+1)/2 + kb), row-major inside ----
-        if constexpr (FOLD) {
-            // rows >= H of L sit in the A-lanes (lane = row + OFF, array z), the H head rows in lanes 0 .. H-1 (array A, columns < H)
-            static_assert(H % 4 == 0, "n a multiple of 4: whole head blocks");
-            const int ib = rowA >> 2;
-            double *dst = Um + 16 * (ib * (ib + 1) / 2) + 4 * (rowA & 3);
-            sfor<0, NBK>(MK_LAMBDA(kk) {
-                constexpr int kb = decltype(kk)::value;
-                constexpr int r0 = (4 * kb > H ? 4 * kb : H) + OFF; // first A-lane whose row is >= 4 kb
-                if constexpr (r0 < 64) {
-                    lds_store_masked<~0ull << r0, 8 * (16 * kb)>(dst, v2d{-z[4 * kb], -z[4 * kb + 1]});
-                    lds_store_masked<~0ull << r0, 8 * (16 * kb + 2)>(dst, v2d{-z[4 * kb + 2], -z[4 * kb + 3]});
-                }
-                if constexpr (4 * kb < H) {
-                    constexpr unsigned long long head = ((1ull << H) - 1ull) & (~0ull << (4 * kb));
-                    lds_store_masked<head, 8 * (16 * kb)>(dst, v2d{-A[4 * kb], -A[4 * kb + 1]});
-                    lds_store_masked<head, 8 * (16 * kb + 2)>(dst, v2d{-A[4 * kb + 2], -A[4 * kb + 3]});
-                }
-            });
-        } else {
-            const int ib = r >> 2;
-            double *dst = Um + 16 * (ib * (ib + 1) / 2) + 4 * (r & 3);
-            sfor<0, NBK>(MK_LAMBDA(kk) {
-                constexpr int kb = decltype(kk)::value;
-                constexpr unsigned long long rows = ~0ull << (4 * kb); // lanes r >= 4 kb (replica lanes rewrite row n-1)
-                lds_store_masked<rows, 8 * (16 * kb)>(dst, v2d{-A[4 * kb], -A[4 * kb + 1]});
-                lds_store_masked<rows, 8 * (16 * kb + 2)>(dst, v2d{-A[4 * kb + 2], -A[4 * kb + 3]});
-            });
-        }
-        // ---- back substitution on blocks: J^T(k, :) = L_kk^-T ( Z~^T(k, :) - sum_{i>k} L(i,k)^T J^T(i, :) ) ----
-        double JT[NBK][NGR];
-        int zoff[NGR];
-#pragma unroll
-        for (int g = 0; g < NGR; ++g) { // Z~[c][4k + x2], c = 16 g + 4 b + x0 (slots beyond the matrix: row n-1 again --
-            const int c = 16 * g + 4 * bs + x0; // they only reach block slots that are never used: the four slots of an
-            zoff[g] = 4 * (c < n ? c : n - 1) + x2; // MFMA are independent products)
-        }
-        auto put_zcols = [&](auto kk) __attribute__((always_inline)) { // columns 4k .. 4k+3 of Z~ -> buffer k & 1, row r
-            constexpr int k = decltype(kk)::value;
-            double *dst = zb + (k & 1) * ZSZ + 4 * r;
-            if constexpr (FOLD) { // the A-lanes hold rows of L, not replicas of row n-1 of Z~
-                constexpr unsigned long long zl = (1ull << n) - 1ull;
-                lds_store_masked<zl, 0>(dst, v2d{z[4 * k], z[4 * k + 1]});
-                lds_store_masked<zl, 16>(dst, v2d{z[4 * k + 2], z[4 * k + 3]});
-            } else {
-                *reinterpret_cast<v2d *>(dst) = v2d{z[4 * k], z[4 * k + 1]};
-                *reinterpret_cast<v2d *>(dst + 2) = v2d{z[4 * k + 2], z[4 * k + 3]};
-            }
-        };
-        put_zcols(std::integral_constant<int, NBK - 1>{});
-        wave_lds_sync(); // -L and the first columns are in LDS
-        // M_k = L_kk^-1 (unit lower 4x4) for every diagonal block, as the replicated operand X with X^T = L_kk^-T: the
-        // lane's element M[x2][x0].  From the stored s = -l:  m10 = s10, m21 = s21, m32 = s32, m20 = s20 + m21 s10,
-        // m31 = s31 + m32 s21, m30 = s30 + m31 s10 + m32 s20 (wavefront-uniform reads; all blocks up front: the reads
-        // and the short dependency chains of the nine blocks overlap)
-        double Xd[NBK];
-        sfor<0, NBK>(MK_LAMBDA(kk) {
-            constexpr int k = decltype(kk)::value;
-            const double *dk = Um + 16 * (k * (k + 1) / 2 + k);
-            const double s10 = dk[4];
-            const v2d r2 = *reinterpret_cast<const v2d *>(dk + 8);
-            const v2d r3a = *reinterpret_cast<const v2d *>(dk + 12);
-            const double s32 = dk[14];
-            const double m20 = fma(r2.y, s10, r2.x);
-            const double m31 = fma(s32, r2.y, r3a.y);
-            const double m30 = fma(m31, s10, fma(s32, r2.x, r3a.x));
-            double v = (x2 == x0) ? 1.0 : 0.0;
-            v = (x2 == 1 && x0 == 0) ? s10 : v;
-            v = (x2 == 2 && x0 == 0) ? m20 : v;
-            v = (x2 == 2 && x0 == 1) ? r2.y : v;
-            v = (x2 == 3 && x0 == 0) ? m30 : v;
-            v = (x2 == 3 && x0 == 1) ? m31 : v;
-            v = (x2 == 3 && x0 == 2) ? s32 : v;
-            Xd[k] = v;
-        });
-        if (!MK_TUNE_SKIP(a, 2))
-        sfor_down<0, NBK>(MK_LAMBDA(kk) {
-            constexpr int k = decltype(kk)::value;
-            double acc[NGR];
-#pragma unroll
-            for (int g = 0; g < NGR; ++g) acc[g] = zb[(k & 1) * ZSZ + zoff[g]]; // written one block row ago
-            if constexpr (k > 0) put_zcols(std::integral_constant<int, k - 1>{});
-            sfor<k + 1, NBK>(MK_LAMBDA(ii) {
-                constexpr int i = decltype(ii)::value;
-                const double X = Um[16 * (i * (i + 1) / 2 + k) + e16]; // -L(i,k), the same block in all four slots
-#pragma unroll
-                for (int g = 0; g < NGR; ++g) acc[g] = mfma4(X, JT[i][g], acc[g], 0, 0, 0);
-            });
-#pragma unroll
-            for (int g = 0; g < NGR; ++g) JT[k][g] = mfma4(Xd[k], acc[g], 0.0, 0, 0, 0);
-            wave_lds_sync(); // the next block row reads what this one wrote
-        });
-        // ---- Pf[t] (and F[t] in the mean slot) as the accumulators of product 2: upper block triangle ----
-        // column of the lane in register g: 16 g + 4 b + x0; block column 4 g + b; the mean rides in block column NBK
-        constexpr int MG = NBK / 4, MB = NBK % 4; // register / slot of the mean column
-        double Pacc[NBK][NGR];
-        {
-            const double *pf = (a.rs > 0 ? recU : iF.mat - r - n) + n; // element (0, 0) of this step's covariance block
-            const double *xf = iF.vec - r;                             // element 0 of the filtered mean
-            sfor<0, NBK>(MK_LAMBDA(ii) {
-                constexpr int i = decltype(ii)::value;
-                sfor<i / 4, NGR>(MK_LAMBDA(gg) {
-                    constexpr int g = decltype(gg)::value;
-                    int col = 16 * g + 4 * bs + x0;
-                    col = col < n ? col : n - 1; // slots beyond the matrix: clamped duplicates, never written back
-                    double v = pf[(4 * i + x2) * n + col];
-                    if constexpr (g == MG) {
-                        const double m = xf[4 * i + x2];
-                        v = (bs == MB) ? (x0 == 0 ? m : 0.0) : v;
-                    }
-                    Pacc[i][g] = v;
-                });
-            });
-        }
-        // ---- products.  X = D J^T first, ALL of it (27 registers): the loop runs over the operand block D(i,k) outermost,
-        // so that two MFMAs on the same accumulator are 3 NBK instructions apart.
-        // D is read from the LDS matrix in operand form; J^T(k,i) is replicated into the four slots by a bit-mode
-        // ds_swizzle of the register that holds it (lane = x0 + 4 b + 16 x2: keep x0 and the row bit, force b = i % 4).
-        double Xm[NBK][NGR];
-        if (!MK_TUNE_SKIP(a, 1)) {
-        sfor<0, NBK>(MK_LAMBDA(ii) {
-            constexpr int i = decltype(ii)::value;
-            __builtin_amdgcn_sched_barrier(0); // one operand row at a time (bounds the hoisting of the LDS reads)
-            double Dop[NBK];
-#pragma unroll
-            for (int k = 0; k < NBK; ++k) Dop[k] = Dm[(4 * i + x2) * LD + 4 * k + x0]; // D(i,k): as A operand D(k,i)
-            sfor<0, NBK>(MK_LAMBDA(kk) {
-                constexpr int k = decltype(kk)::value;
-#pragma unroll
-                for (int g = 0; g < NGR; ++g) Xm[k][g] = mfma4(Dop[k], JT[i][g], i == 0 ? 0.0 : Xm[k][g], 0, 0, 0);
-            });
-        });
-        sfor<0, NBK>(MK_LAMBDA(kk) {
-            constexpr int k = decltype(kk)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            {   // delta into the mean slot: column 0 of block column NBK
-                const double dv = dl[4 * k + x2];
-                Xm[k][MG] = (bs == MB) ? (x0 == 0 ? dv : 0.0) : Xm[k][MG];
-            }
-            sfor<0, NBK>(MK_LAMBDA(ii) {
-                constexpr int i = decltype(ii)::value;
-                constexpr int pat = 0x13 | (((i % 4) << 2) << 5); // and_mask 0b10011, or_mask (i % 4) << 2
-                const double src = JT[k][i / 4];
-                const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(src), pat);
-                const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(src), pat);
-                const double Jop = __hiloint2double(hi, lo); // J^T(k,i) in all four slots: as A operand J(i,k)
-                sfor<i / 4, NGR>(MK_LAMBDA(gg) {
-                    constexpr int g = decltype(gg)::value;
-                    Pacc[i][g] = mfma4(Jop, Xm[k][g], Pacc[i][g], 0, 0, 0);
-                });
-            });
-        });
-        }
-        // ---- Ps[t] back into the LDS matrix (both triangles), the smoothed mean to the lanes ----
-        wave_lds_sync(); // all reads of D and of the last J^T row block are done
-        sfor<0, NBK>(MK_LAMBDA(ii) {
-            constexpr int i = decltype(ii)::value;
-            sfor<i / 4, NGR>(MK_LAMBDA(gg) {
-                constexpr int g = decltype(gg)::value;
-                mfma_settle(Pacc[i][g]); // the stores below are inline asm: 9 wait states behind the accumulator's last MFMA
-                // block columns held by this register that belong to the upper triangle of block row i
-                constexpr int b_lo = (i > 4 * g ? i - 4 * g : 0), b_hi = (NBK - 4 * g < 4 ? NBK - 4 * g : 4); // [b_lo, b_hi)
-                if constexpr (b_lo < b_hi) {
-                    constexpr unsigned long long slots = []() constexpr {
-                        unsigned long long m = 0;
-                        for (int l = 0; l < 64; ++l) {
-                            const int b = (l >> 2) & 3;
-                            if (b >= b_lo && b < b_hi) m |= 1ull << l;
-                        }
-                        return m;
-                    }();
-                    const int col = 16 * g + 4 * bs + x0;
-                    lds_store_masked<slots, 0>(Dm + (4 * i + x2) * LD + col, Pacc[i][g]);
-                    // mirror: off-diagonal blocks only (b != i - 4 g)
-                    constexpr unsigned long long off = []() constexpr {
-                        unsigned long long m = 0;
-                        for (int l = 0; l < 64; ++l) {
-                            const int b = (l >> 2) & 3;
-                            if (b >= b_lo && b < b_hi && 4 * g + b != i) m |= 1ull << l;
-                        }
-                        return m;
-                    }();
-                    if constexpr (off != 0) lds_store_masked<off, 0>(Dm + col * LD + 4 * i + x2, Pacc[i][g]);
-                }
-                if constexpr (g == MG) { // the mean column: lanes (b = MB, x0 = 0) hold xs[4i + x2]
-                    constexpr unsigned long long ml = []() constexpr {
-                        unsigned long long m = 0;
-                        for (int l = 0; l < 64; ++l)
-                            if (((l >> 2) & 3) == MB && (l & 3) == 0) m |= 1ull << l;
-                        return m;
-                    }();
-                    lds_store_masked<ml, 0>(zb + XBASE + 4 * i + x2, Pacc[i][g]);
-                }
-            });
-        });
-        wave_lds_sync();
-        xs = zb[XBASE + r];
-        asm volatile("" : "+v"(xs));
-#endif
         }
         wave_lds_sync();
         {
@@ -1273,24 +1034,8 @@ static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
             if (proj) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
         } else {
-#ifdef MK_EXPERIMENTAL_BLK4
-#define MK_LAUNCH_BLK4(E, S)                                                                                       \
-    if constexpr ((N + K) % 4 == 0 && !S) {                                                                        \
-        if (a.variant & 8) {                                                                                       \
-            hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, false, true, true>), dim3(grid), dim3(64), 0, s, a);  \
-            break;                                                                                                 \
-        }                                                                                                          \
-        if (a.variant & 16) {                                                                                      \
-            hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, false, false, true>), dim3(grid), dim3(64), 0, s, a); \
-            break;                                                                                                 \
-        }                                                                                                          \
-    }
-#else
-#define MK_LAUNCH_BLK4(E, S)
-#endif
 #define MK_LAUNCH_WIDE(E, S)                                                                                      \
     do {                                                                                                          \
-        MK_LAUNCH_BLK4(E, S)                                                                                      \
         if (a.variant & 4) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, false>), dim3(grid), dim3(64), 0, s, a); \
         else hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, true>), dim3(grid), dim3(64), 0, s, a);          \
     } while (0)
@@ -1304,7 +1049,6 @@ static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
                 else MK_LAUNCH_WIDE(0, false);
             }
 #undef MK_LAUNCH_WIDE
-#undef MK_LAUNCH_BLK4
         }
         return hipGetLastError();
     } else {

@@ -88,10 +88,8 @@ class BatchedKalman:
             pass
 
     # ------------------------------------------------------------------ kernel variants (A/B measurements)
-    # ("mfma_blk4" / "mfma_blk4_unfolded": the 4x4x4 MFMA block path, accepted only by a library built with
-    #  -DMK_EXPERIMENTAL_BLK4 -- scripts/experiments/build_blk4.sh; the product library answers MK_ERR_INVALID)
     _VARIANTS = {"smoother16": (0, ("record", "blk")),
-                 "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded", "mfma_blk4", "mfma_blk4_unfolded")),
+                 "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded")),
                  "wide_filter": (2, ("split", "lane_per_state"))}
 
     def set_variant(self, which, name):

@@ -1,6 +1,6 @@
 """Same-box A/B of the wide-smoother variants at configs[3] size (4096 x (32,4), 30 % missing, projection path), interleaved.
   gpurun -- 'python scripts/experiments/ab_wide_variants.py [T [variant ...]]'      (default: mfma mfma_unfolded;
-  mfma_blk4 / mfma_blk4_unfolded need METRAN_HIP_LIBRARY=ab/libmetran_hip_blk4.so, scripts/experiments/build_blk4.sh)"""
+  (the block-path variants mfma_blk4 / mfma_blk4_unfolded were removed in round 4: README.md)"""
 import sys
 
 import torch

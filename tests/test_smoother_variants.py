@@ -127,85 +127,3 @@ def test_no_environment_variable_changes_a_result():
     env = dict(os.environ, MK_WIDE_TUNE="7", MK_WIDE_SMOOTHER="v1", MK_SMOOTHER16="blk", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", ENV_SCRIPT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "env ignored ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
-
-
-def test_product_library_has_no_experimental_variant():
-    """The 4x4x4 MFMA block path of the wide smoother (values 3 / 4 of MK_VARIANT_WIDE_SMOOTHER) exists only in a library built
-    with -DMK_EXPERIMENTAL_BLK4 (scripts/experiments/build_blk4.sh): the product library refuses the selector and keeps its
-    default, so that no switch of the shipped ABI reaches a kernel the GPU tier does not test."""
-    from metran_amd.engine import BatchedKalman
-
-    if os.environ.get("METRAN_HIP_LIBRARY"):
-        pytest.skip("a non-default library is loaded")
-    kf = BatchedKalman()
-    try:
-        for name in ("mfma_blk4", "mfma_blk4_unfolded"):
-            with pytest.raises(Exception):
-                kf.set_variant("wide_smoother", name)
-        assert kf.get_variant("wide_smoother") == "mfma"
-    finally:
-        kf.close()
-
-
-def _has_block_path():
-    from metran_amd.engine import BatchedKalman
-
-    kf = BatchedKalman()
-    try:
-        kf.set_variant("wide_smoother", "mfma_blk4")
-        return True
-    except Exception:
-        return False
-    finally:
-        kf.close()
-
-
-@pytest.mark.parametrize("variant", ["mfma_blk4", "mfma_blk4_unfolded"])
-def test_block_path_equals_the_oracle_and_the_tile_kernel_at_full_occupancy(variant):
-    """EXPERIMENTAL library only (``METRAN_HIP_LIBRARY=ab/libmetran_hip_blk4.so``, scripts/experiments/build_blk4.sh; skipped
-    with the product library): the 4x4x4 MFMA block path against the oracle in every output mode, and -- the round-3
-    failure -- against the shipped tile kernel on 4096 models (two wavefronts per SIMD), three runs, all bit-identical to
-    each other and within rounding of the tile kernel."""
-    import torch
-
-    import oracle
-    from metran_amd.engine import BatchedKalman
-    from metran_amd.synthetic import make_dfm_batch, make_dfm_batch_torch
-
-    if not _has_block_path():
-        pytest.skip("the loaded library has no block path (product build)")
-    N, K = 32, 4
-    d = make_dfm_batch(7, N, K, 45, seed=3632, missing=0.3, first_step="random")
-    ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
-    Z = np.concatenate([np.broadcast_to(np.eye(N), (7, N, N)), d["loadings"]], axis=2)
-    kf = BatchedKalman().set_variant("wide_smoother", variant)
-    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
-    r = kf.filter_smooth(d["phi"], d["q"])
-    np.testing.assert_allclose(npy(r["S"]), ref["S"], atol=1e-9)
-    np.testing.assert_allclose(npy(r["Ps"]), ref["Ps"], atol=1e-9)
-    assert int(npy(r["status"]).sum()) == 0
-    p = kf.simulate_smoothed(d["phi"], d["q"])
-    np.testing.assert_allclose(npy(p["sim_means"]), np.einsum("bjn,btn->btj", Z, ref["S"]), atol=1e-9)
-    np.testing.assert_allclose(npy(p["sim_vars"]), np.maximum(np.einsum("bjn,btnm,bjm->btj", Z, ref["Ps"], Z), 0), atol=1e-9)
-    v = kf.smooth_state_variances(d["phi"], d["q"])
-    np.testing.assert_allclose(npy(v["var"]), np.einsum("btnn->btn", ref["Ps"]), atol=1e-9)
-    kf.close()
-    # full occupancy
-    B, T = 4096, 40
-    dd = make_dfm_batch_torch(B, N, K, T, seed=4000, device=torch.device("cuda", 0), missing=0.3)
-    outs = {}
-    for var in ("mfma", variant):
-        kf = BatchedKalman(layout="time_major").set_variant("wide_smoother", var)
-        kf.set_observations(dd["obs"]).set_loadings(dd["loadings"])
-        runs = []
-        for _ in range(3):
-            r = kf.filter_smooth(dd["phi"], dd["q"])
-            torch.cuda.synchronize()
-            runs.append((r["S"].clone(), r["Ps"].clone()))
-        for x in runs[1:]:
-            assert torch.equal(runs[0][0], x[0]) and torch.equal(runs[0][1], x[1]), "%s is not reproducible" % var
-        outs[var] = runs[0]
-        kf.close()
-    scale = float(outs["mfma"][1].abs().max())
-    assert float((outs["mfma"][0] - outs[variant][0]).abs().max()) < 1e-10
-    assert float((outs["mfma"][1] - outs[variant][1]).abs().max()) < 1e-10 * max(scale, 1.0)
