@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define MK_API __attribute__((visibility("default")))
-#define MK_ABI_VERSION 4
+#define MK_ABI_VERSION 5
 
 typedef enum mk_status {
     MK_OK = 0,
@@ -134,10 +134,23 @@ typedef struct mk_outputs {
                                 d_Ps [B,T,n], both dense (time_major applies), instead of smoothed records --
                                 what Metran.get_state_means / get_state_variances / get_state consume
                                 (metran.py:655-756).  d_F/d_Pf stay a (full or packed-symmetric) record array;
-                                d_Xp/d_Pp must be NULL in mk_filter_smooth (filtered record only).          */
+                                d_Xp/d_Pp must be NULL in mk_filter_smooth (filtered record only).
+                              MK_OUT_TAPE        (ABI 5; mk_filter_smooth with d_sim_means / d_sim_vars only, shapes
+                                with mk_tape_supported(N, K) = 1, d_obsvar NULL) d_F is not a filtered record array
+                                but the BACKWARD TAPE of the inverse-free smoother, record_stride =
+                                mk_tape_stride(N, K) = N (n + 4) doubles per (model, step), same (b, t) addressing
+                                and time_major rule as records: per series one entry [ vector(n) | s0 | s1 | s2 | 0 ]
+                                in the observable basis -- the gain, v/f, 1/f and the observation of an observed
+                                series, T Pf z_u', the filtered observable, its variance and NaN for a series not
+                                observed at that step.  The backward pass (Durbin-Koopman r / N recursion of the
+                                sequential filter, kalmanfilter.py:341-378 walked backwards) then produces the same
+                                projected smoothed means / variances as kalmansmoother + simulate (:403-476,
+                                :569-603) without the pseudo-inverse of :455.  d_Pf, d_Xp, d_Pp, d_S, d_Ps must be
+                                NULL; d_sigmas / d_detfs, if given, are DENSE [B,T] arrays.                      */
 } mk_outputs;
 #define MK_OUT_PACKED_SYM 1
 #define MK_OUT_VAR_ONLY 2
+#define MK_OUT_TAPE 4
 
 /* ---- library / context ------------------------------------------------------------------ */
 MK_API int mk_abi_version(void);
@@ -174,6 +187,10 @@ MK_API int mk_register_shape_module(const char *path);
 MK_API int64_t mk_record_stride(int64_t n);
 /* ... per PACKED-SYMMETRIC record (mk_outputs.flags & MK_OUT_PACKED_SYM). */
 MK_API int64_t mk_record_stride_sym(int64_t n);
+/* Doubles per (model, step) of the backward tape (mk_outputs.flags & MK_OUT_TAPE): N (N + K + 4); and whether the
+ * tape path serves a shape (16 < N + K, N <= 32: the shapes of the split filter, mk_split.hip / mk_dk.hip). */
+MK_API int64_t mk_tape_stride(int64_t N, int64_t K);
+MK_API int mk_tape_supported(int64_t N, int64_t K);
 /* Writes up to `cap` supported (N,K) pairs into shapes[2*i], shapes[2*i+1]; returns the count. */
 MK_API int mk_supported_shapes(int64_t *shapes, int cap);
 

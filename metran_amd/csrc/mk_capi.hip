@@ -297,6 +297,28 @@ MK_API int mk_shape_supported(int64_t N, int64_t K)
 
 MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
 MK_API int64_t mk_record_stride_sym(int64_t n) { return mk::record_stride_sym((int)n); }
+MK_API int64_t mk_tape_stride(int64_t N, int64_t K) { return N * (N + K + 4); }
+MK_API int mk_tape_supported(int64_t N, int64_t K)
+{
+    return (N + K > 16 && N <= 32 && K <= 16 && N + K + 1 <= 64 && mk_shape_supported(N, K)) ? 1 : 0;
+}
+// MK_OUT_TAPE (mk_outputs.flags): 0 = not asked for, 1 = asked for and consistent, < 0 = an inconsistent description
+static int tape_outputs(const mk_problem *p, const mk_outputs *o)
+{
+    if (!(o->flags & MK_OUT_TAPE)) return 0;
+    if (o->flags & (MK_OUT_PACKED_SYM | MK_OUT_VAR_ONLY))
+        return fail(MK_ERR_INVALID, "MK_OUT_TAPE excludes MK_OUT_PACKED_SYM and MK_OUT_VAR_ONLY");
+    if (!mk_tape_supported(p->N, p->K))
+        return fail(MK_ERR_SHAPE, "MK_OUT_TAPE serves 16 < N + K, N <= 32 (got N=%lld, K=%lld)", (long long)p->N, (long long)p->K);
+    if (p->d_obsvar) return fail(MK_ERR_INVALID, "MK_OUT_TAPE needs d_obsvar = NULL (observation variance 0, metran.py:382-384)");
+    if (!o->d_F || o->d_Pf || o->d_Xp || o->d_Pp || o->d_S || o->d_Ps)
+        return fail(MK_ERR_INVALID, "MK_OUT_TAPE: d_F is the tape, d_Pf / d_Xp / d_Pp / d_S / d_Ps must be NULL");
+    if (o->record_stride != mk_tape_stride(p->N, p->K))
+        return fail(MK_ERR_INVALID, "MK_OUT_TAPE: record_stride must be mk_tape_stride(N, K) = %lld doubles",
+                    (long long)mk_tape_stride(p->N, p->K));
+    if (!p->d_loadings) return fail(MK_ERR_INVALID, "MK_OUT_TAPE needs d_loadings");
+    return 1;
+}
 
 MK_API int mk_supported_shapes(int64_t *shapes, int cap)
 {
@@ -425,14 +447,17 @@ static int records_filter(const mk_problem *p, const mk_outputs *o)
 static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
 {
     if (!p->d_obs || !p->d_loadings) return fail(MK_ERR_INVALID, "d_obs and d_loadings are required");
-    const int rec = records_filter(p, o);
+    const int tape = tape_outputs(p, o);
+    if (tape < 0) return tape;
+    const int rec = tape ? 0 : records_filter(p, o);
     if (rec < 0) return rec;
     mk::FilterArgs a;
     a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER] ? 1 : 0;
-    a.rs = rec ? o->record_stride : 0;
+    a.tape = tape;
+    a.rs = (rec || tape) ? o->record_stride : 0;
     a.sym = (rec && (o->flags & MK_OUT_PACKED_SYM)) ? 1 : 0;
     // dense sigmas/detfs are [B,T] (stride 1); inside filtered records they are RS doubles apart
-    a.sig_stride = o->record_stride ? o->record_stride : 1;
+    a.sig_stride = (o->record_stride && !tape) ? o->record_stride : 1;
     a.B = p->n_instances;
     a.R = p->n_records;
     a.T = p->T;
@@ -465,16 +490,23 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
 
 static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
 {
-    if (!o->d_F || !o->d_Pf)
+    const int tape = tape_outputs(p, o);
+    if (tape < 0) return tape;
+    if (!o->d_F || (!o->d_Pf && !tape))
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
+    if (tape && !(o->d_sim_means || o->d_sim_vars))
+        return fail(MK_ERR_INVALID, "MK_OUT_TAPE: nothing to write, give d_sim_means / d_sim_vars");
     mk::SmootherArgs a;
+    a.tape = tape;
     a.variant = (ctx->variant[MK_VARIANT_SMOOTHER16] ? 1 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 1 ? 2 : 0) |
                 (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 2 ? 4 : 0);
     a.rs = 0;
     a.sym = 0;
     a.state_means = a.state_vars = nullptr;
     const bool sym = (o->flags & MK_OUT_PACKED_SYM) != 0, var = (o->flags & MK_OUT_VAR_ONLY) != 0;
-    if (o->record_stride) {
+    if (tape) {
+        a.rs = o->record_stride;
+    } else if (o->record_stride) {
         const int64_t n = p->N + p->K;
         const int64_t want = sym ? mk::record_stride_sym((int)n) : mk::record_stride((int)n);
         if (o->record_stride != want)

@@ -1,0 +1,366 @@
+// mk_dk.hip -- inverse-free backward pass of the wide models (n = N + K > 16): smoothed projection from the filter's TAPE.
+// Reference semantics: kalmansmoother + simulate, /root/reference/metran/kalmanfilter.py:403-476, 569-603 with the scaled
+// observation matrix of /root/reference/metran/metran.py:944-961 -- the same smoothed means / variances of the observables,
+// computed WITHOUT the pseudo-inverse of the predicted covariance (:455) and without its five n x n products (:458-474).
+//
+// Formulation (round 4; Durbin & Koopman's r / N recursion for the sequential filter of :341-378).  Walk the scalar updates
+// backwards with the gains the filter formed:  r <- z v/f + L'r,  N <- z z'/f + L'NL,  L = I - k z';  at any point of the walk
+// the smoothed moments are  x_s = x + P r,  V = P - P N P  with the filter's (x, P) of that point;  across a step
+// r <- Phi'r, N <- Phi'N Phi.  No factorisation, no pivot chain, a singular predicted covariance is a non-event.
+// In Metran's own state basis z_j = e_j + sum_k g_jk e_{N+k} has 1 + K non-zeros, so every update would rewrite 1 + K rows and
+// columns of N.  The kernel therefore works in the OBSERVABLE basis xt = T x, T = [[I, G], [0, I]] (the N series states
+// replaced by the observables y_j): there z_j = e_j and an update rewrites ONE row / column,
+//     w = N kt,  beta = kt.r,  alpha = kt.w;   r_j += v/f - beta;   N[:,j] = N[j,:] = N[:,j] - w;   N[j][j] += alpha + 1/f - w_j
+// (kt = T k), at the price of a transition Pht = T Phi T^-1 = [[Phi_s, C], [0, Phi_f]], C[a][k] = g_ak (phi_{N+k} - phi_a),
+// that mixes the factor columns once per STEP instead of once per observation.  What is asked for -- the projected means and
+// variances of the series -- are components of xt itself: for a series u not observed at the step
+//     mean_u = z_u x_f + pt.r,   var_u = z_u Pf z_u' - pt' N pt,    pt = T Pf z_u'
+// with (r, N) as they stand BEFORE the step's updates; for an observed series (R = 0) the smoothed observable is the
+// observation and its variance is zero.  Both vectors (kt, pt) and their scalars come from the filter: filter_split_kernel
+// OUT = 4 writes one tape entry of n + 4 doubles per (step, series) (mk_split.hip; tests/dk_ref.py restates both sides).
+//
+// Mapping: one model per wavefront.  Lane a < n holds row a of N, lane n holds r as a ROW (the matrix-vector product then
+// yields beta = r.kt in lane n for free), lanes > n replicate lane n.  An entry's vector arrives straight from HBM in the
+// DPP-replicated layout (lane 16q + i holds x[16m + i], m = 0 .. ceil(N/16)-1, and the K factor entries), so the product is
+// n fused broadcast-multiply-adds (v_fmac_f64_dpp row_newbcast) with no LDS and no readlane.  alpha is one wavefront sum.
+// The new column j goes to the lanes' registers through a jump table and to lane j's row through LDS (36 doubles written by
+// 36 lanes, read back by one).  The unobserved entries change nothing: their products are parked in LDS and reduced once per
+// step (lane u sums its own row).  Transition: factor columns by n K broadcast-multiply-adds against replicated columns of C,
+// series columns by two scalings, the factor rows by transposition through LDS, the K x K factor block by one transposed
+// reduction.
+#include "mk_prims.h"
+#include "mk_jump.h"
+
+namespace mk {
+
+constexpr int tape_entry_c(int N, int K) { return N + K + 4; }
+constexpr int tape_stride_c(int N, int K) { return N * tape_entry_c(N, K); }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
+
+template <int N, int K>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
+{
+    constexpr int n = N + K, ES = tape_entry_c(N, K), RS = tape_stride_c(N, K);
+    static_assert(n > 16 && n + 1 <= 64 && K <= 16 && N >= 2, "one model per wavefront: rows 0..n-1 of N and the r row");
+    constexpr int NB = (N + 15) / 16;          // DPP-replicated registers holding the series entries of a vector
+    constexpr int NP = (n + 2) & ~1;           // >= n + 1, even: LDS rows of 16-byte pieces
+    constexpr bool PAIRS = (n % 2 == 0);       // tape entries are 16-byte aligned
+    constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
+    constexpr int QS = (N + 2) & ~1;           // series lanes 0..N-1 (+ one dummy slot)
+    // the step's tape block is copied HBM -> LDS by the wavefront itself (global_load_lds: no registers, asynchronous):
+    // 16 bytes a lane and instruction when the blocks are 16-byte aligned, 4 bytes otherwise
+    constexpr int CB_BYTES = (RS % 2 == 0) ? 16 : 4, CHUNK = 64 * CB_BYTES;
+    constexpr int NCH = (RS * 8 + CHUNK - 1) / CHUNK;
+    constexpr int TBD = NCH * CHUNK / 8;       // doubles of the LDS image (block + what the last chunk over-reads)
+    using G16 = Group<16>;
+
+    const int lane = threadIdx.x, i16 = lane & 15;
+    long inst = (long)blockIdx.x;
+    if (inst > a.B - 1) inst = a.B - 1;
+    const long rec = inst % a.R;
+    const int ra = lane < n ? lane : n;        // row held by this lane (n = the r row)
+    const int js = lane < N ? lane : N - 1;    // series whose projection this lane writes (lanes >= N replicate N-1)
+    const bool frow = lane >= N && lane < n;   // factor rows
+    const long T = a.T;
+
+    // wave-private LDS
+    __shared__ __attribute__((aligned(16))) double lds[TBD + NP + NP + K * NP + K * K * QS + ((K * K + 1) & ~1)];
+    double *tapeb = lds;                       // the step's tape block: N entries of ES doubles
+    double *phim = tapeb + TBD;                // diag(Phi) [n]
+    double *tbuf = phim + NP;                  // the new column j on its way to lane j's row
+    double *fbuf = tbuf + NP;                  // [K][NP] factor columns on their way to the factor rows
+    double *qbuf = fbuf + K * NP;              // [K*K][QS] products of the factor block
+    double *ffb = qbuf + K * K * QS;           // [K*K] factor block sums
+
+    const double phi_own = lane < n ? a.phi[inst * n + lane] : 1.0; // row scaling of the transition (none for the r row)
+    if (lane < n) phim[lane] = phi_own;
+    wave_lds_sync();
+    // C[a][k] = g_ak (phi_{N+k} - phi_a): own row (series lanes, for the factor block) and DPP-replicated columns
+    double Cown[K], CB[K][NB];
+    sfor<0, K>(MK_LAMBDA(kk) {
+        constexpr int k = decltype(kk)::value;
+        const double pfk = phim[N + k];
+        Cown[k] = lane < N ? a.loadings[(rec * N + lane) * K + k] * (pfk - phi_own) : 0.0;
+        sfor<0, NB>(MK_LAMBDA(mm) {
+            constexpr int m = decltype(mm)::value;
+            const int c = 16 * m + i16;
+            const int cc = c < N ? c : N - 1;
+            const double v = a.loadings[(rec * N + cc) * K + k] * (pfk - phim[cc]);
+            CB[k][m] = c < N ? v : 0.0;
+        });
+    });
+    const double scale = a.scale ? a.scale[rec * N + js] : 1.0;
+    const double offset = a.offset ? a.offset[rec * N + js] : 0.0;
+
+    double Nr[n];
+#pragma unroll
+    for (int c = 0; c < n; ++c) Nr[c] = 0.0;
+
+    // HBM -> LDS copy of one tape block (asynchronous; completion = vmcnt)
+    const long blk_bytes = (long)RS * 8;
+    auto fetch_block = [&](const double *blk) __attribute__((always_inline)) {
+        const char *g = reinterpret_cast<const char *>(blk);
+        sfor<0, NCH>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            long off = (long)c * CHUNK + (long)lane * CB_BYTES;
+            if constexpr ((c + 1) * CHUNK > RS * 8) off = off < blk_bytes - CB_BYTES ? off : blk_bytes - CB_BYTES; // stay inside
+            if constexpr (RS % 2 == 0)
+                __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + off), (lds_void_t *)((char *)tapeb + c * CHUNK), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + off), (lds_void_t *)((char *)tapeb + c * CHUNK), 4, 0, 0);
+        });
+    };
+
+    // one tape entry in registers
+    struct Ent {
+        double XB[NB], XF, xa, s0, s1;
+    };
+    int xoff_b[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) xoff_b[m] = 16 * m + i16 < ES ? 16 * m + i16 : ES - 1;
+    const int xoff_f = N + (i16 < K ? i16 : K - 1);
+    const int xoff_a = lane < n ? lane : n + 3; // lanes >= n read the entry's constant 0
+    auto load_ent = [&](int j, Ent &E) __attribute__((always_inline)) {
+        const double *e = tapeb + j * ES;
+        sfor<0, NB>(MK_LAMBDA(mm) { E.XB[decltype(mm)::value] = e[xoff_b[decltype(mm)::value]]; });
+        E.XF = e[xoff_f];
+        E.xa = e[xoff_a];
+        if constexpr (PAIRS) {
+            const v2d sc = *reinterpret_cast<const v2d *>(e + n);
+            E.s0 = sc.x;
+            E.s1 = sc.y;
+        } else {
+            E.s0 = e[n];
+            E.s1 = e[n + 1];
+        }
+    };
+    // w_a = sum_c N[a][c] x_c: the entry's vector broadcast inside the multiply-add (four per asm statement: hipcc pads
+    // every asm statement that follows another with an s_nop)
+    auto matvec = [&](const Ent &E) __attribute__((always_inline)) {
+        double acc0 = 0.0, acc1 = 0.0;
+        sfor<0, N / 4>(MK_LAMBDA(qq) {
+            constexpr int c = 4 * decltype(qq)::value;
+            G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16>(acc0, acc1, E.XB[c / 16], Nr[c], E.XB[(c + 1) / 16], Nr[c + 1],
+                                                                           E.XB[(c + 2) / 16], Nr[c + 2], E.XB[(c + 3) / 16], Nr[c + 3]);
+        });
+        sfor<4 * (N / 4), N>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            G16::fmac<c % 16>(c % 2 ? acc1 : acc0, E.XB[c / 16], Nr[c]);
+        });
+        if constexpr (K == 4) {
+            G16::fmac4<0, 1, 2, 3>(acc0, acc1, E.XF, Nr[N], E.XF, Nr[N + 1], E.XF, Nr[N + 2], E.XF, Nr[N + 3]);
+        } else {
+            sfor<0, K>(MK_LAMBDA(kk) {
+                constexpr int k = decltype(kk)::value;
+                G16::fmac<k>(k % 2 ? acc1 : acc0, E.XF, Nr[N + k]);
+            });
+        }
+        return acc0 + acc1;
+    };
+
+    const double *tb = a.F + (inst * a.bs + (T - 1) * a.ts) * a.rs; // tape block of the current step (in HBM)
+    const long tstep = a.ts * a.rs;
+    double *omean = a.sim_means ? a.sim_means + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
+    double *ovar = a.sim_vars ? a.sim_vars + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
+    const long ostep = a.ts * N;
+
+    int sink = 0; // destination of the L2-warming loads below
+    fetch_block(tb);
+    for (long t = T - 1; t >= 0; --t) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this step's block has landed in LDS
+        wave_lds_sync();
+        if (t > 1) {                            // warm L2 with the block two steps back (one 128-byte line per lane and load)
+            const char *g2 = reinterpret_cast<const char *>(tb - 2 * tstep);
+#pragma unroll
+            for (int c = 0; c * 64 * 128 < RS * 8; ++c) {
+                long off = ((long)c * 64 + lane) * 128;
+                off = off < blk_bytes - 4 ? off : blk_bytes - 4;
+                // (the destination register stays reserved for the whole kernel: the data lands long after the instruction)
+                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(g2 + off) : "memory");
+            }
+        }
+        // the scalars of this lane's series: (s0, s1, s2); s2 = NaN marks "not observed at this step"
+        double s0, s1, s2;
+        {
+            const double *e = tapeb + js * ES + n;
+            if constexpr (PAIRS) {
+                const v2d sc = *reinterpret_cast<const v2d *>(e);
+                s0 = sc.x;
+                s1 = sc.y;
+            } else {
+                s0 = e[0];
+                s1 = e[1];
+            }
+            s2 = e[2];
+        }
+        const bool unobs = (s2 != s2);
+        const unsigned obsm = (unsigned)__ballot(lane < N && !unobs) & NM; // series observed at this step
+        Ent ea, eb;
+
+        // ---- series not observed at this step: mean = s0 + pt.r, var = s1 - pt'N pt with (r, N) before the step's updates.
+        // The products x_a w_a go back into the entry's own (consumed) LDS slots, beta into its constant-0 slot; lane u sums
+        // its entry afterwards.
+        unsigned um = ~obsm & NM;
+        auto unobs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
+            const int u = (int)__builtin_ctz(um);
+            um &= um - 1u;
+            if (um) load_ent((int)__builtin_ctz(um), Enext);
+            const double w = matvec(E);
+            tapeb[u * ES + (lane < n ? lane : n + 3)] = lane < n ? E.xa * w : w;
+        };
+        if (um) {
+            load_ent((int)__builtin_ctz(um), ea);
+            while (true) {
+                unobs_step(ea, eb);
+                if (!um) break;
+                unobs_step(eb, ea);
+                if (!um) break;
+            }
+        }
+        wave_lds_sync();
+        double mean = s2, var = 0.0;              // observed (R = 0): the observation itself, variance 0
+        if (unobs) {
+            double q0 = 0.0, q1 = 0.0;
+            const double *pr = tapeb + js * ES;
+            double row[n];
+            load_row<n>(pr, row);
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                if (c % 2 == 0) q0 += row[c];
+                else q1 += row[c];
+            }
+            mean = s0 + pr[n + 3];
+            var = s1 - (q0 + q1);
+        }
+        {
+            const double v = scale * scale * var;
+            if (omean) *omean = fma(scale, mean, offset);
+            if (ovar) *ovar = v < 0.0 ? 0.0 : v;  // kalmanfilter.py:601-602 (np.maximum keeps a NaN)
+        }
+
+        // ---- observed series, last first: the scalar updates of the filter walked backwards
+        unsigned om = obsm;
+        auto obs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
+            const int j = 31 - (int)__builtin_clz(om);
+            om &= ~(1u << j);
+            if (om) load_ent(31 - (int)__builtin_clz(om), Enext);
+            const double w = matvec(E);
+            const double beta = readlane_f64(w, n);
+            const double alpha = wave_sum_f64(E.xa * w);
+            double picked = 0.0;
+            pick_column_all<N, n>(picked, j, Nr);
+            double nc = picked - w;                                       // N[a][j] - w_a
+            nc = (lane == j) ? (nc - w) + (alpha + E.s1) : nc;            // N[j][j] - 2 w_j + alpha + 1/f
+            nc = (lane >= n) ? picked + (E.s0 - beta) : nc;               // r_j + v/f - beta
+            set_column<N, n>(j, nc, Nr);
+            tbuf[ra] = nc;                                                // slot n: the r row's, unused
+            wave_lds_sync();
+            if (lane == j) load_row<n>(tbuf, Nr);                         // row j = the new column j
+        };
+        if (om) {
+            load_ent(31 - (int)__builtin_clz(om), ea);
+            while (true) {
+                obs_step(ea, eb);
+                if (!om) break;
+                obs_step(eb, ea);
+                if (!om) break;
+            }
+        }
+        // every entry of the step has been consumed: next step's block on its way while the transition runs
+        tb -= tstep;
+        if (t > 0) {
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): no LDS read of the old block is still in flight
+            fetch_block(tb);
+        }
+
+        // ---- transition: r <- Pht'r, N <- Pht'N Pht
+        if (t > 0) {
+            double Yf[K];
+            sfor<0, K>(MK_LAMBDA(kk) { // factor columns: Y[a][N+k] = sum_c N[a][c] C[c][k] + N[a][N+k] phi_{N+k}
+                constexpr int k = decltype(kk)::value;
+                double y0 = Nr[N + k] * phim[N + k], y1 = 0.0;
+                sfor<0, N / 4>(MK_LAMBDA(qq) {
+                    constexpr int c = 4 * decltype(qq)::value;
+                    G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16>(y0, y1, CB[k][c / 16], Nr[c], CB[k][(c + 1) / 16], Nr[c + 1],
+                                                                                   CB[k][(c + 2) / 16], Nr[c + 2], CB[k][(c + 3) / 16],
+                                                                                   Nr[c + 3]);
+                });
+                sfor<4 * (N / 4), N>(MK_LAMBDA(cc) {
+                    constexpr int c = decltype(cc)::value;
+                    G16::fmac<c % 16>(c % 2 ? y1 : y0, CB[k][c / 16], Nr[c]);
+                });
+                Yf[k] = y0 + y1;
+            });
+            {   // series columns: N[a][c] phi_a phi_c
+                double ph[NP];
+                load_row<NP>(phim, ph);
+#pragma unroll
+                for (int c = 0; c < N; ++c) Nr[c] = (Nr[c] * phi_own) * ph[c];
+            }
+            // factor block sums sum_a C[a][k] Y[a][N+k'] over the series rows, factor columns to the factor rows
+            const int qs = lane < N ? lane : N;
+            sfor<0, K>(MK_LAMBDA(kk) {
+                constexpr int k = decltype(kk)::value;
+                sfor<0, K>(MK_LAMBDA(ll) {
+                    constexpr int l = decltype(ll)::value;
+                    qbuf[(k * K + l) * QS + qs] = Cown[k] * Yf[l];
+                });
+                fbuf[k * NP + ra] = phi_own * Yf[k];
+            });
+            wave_lds_sync();
+            {
+                const int L = lane < K * K ? lane : K * K - 1;
+                double row[QS];
+                load_row<QS>(qbuf + L * QS, row);
+                double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    if (c % 2 == 0) q0 += row[c];
+                    else q1 += row[c];
+                }
+                ffb[L] = q0 + q1;
+            }
+            if (frow) { // rows N+k, series part: N'[N+k][c] = N'[c][N+k]
+                double row[NP];
+                load_row<NP>(fbuf + (lane - N) * NP, row);
+#pragma unroll
+                for (int c = 0; c < N; ++c) Nr[c] = row[c];
+            }
+            wave_lds_sync();
+            const int kf = frow ? lane - N : 0;
+            sfor<0, K>(MK_LAMBDA(ll) {
+                constexpr int l = decltype(ll)::value;
+                const double add = frow ? ffb[kf * K + l] : 0.0;
+                Nr[N + l] = fma(phi_own, Yf[l], add);
+            });
+        }
+        if (omean) omean -= ostep;
+        if (ovar) ovar -= ostep;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" : : "v"(sink));
+}
+
+// Which calls the tape path serves: the shapes of the split filter (16 < n, N <= 32), projection outputs.
+template <int N, int K>
+static hipError_t launch_dk_nk(const SmootherArgs &a, hipStream_t s)
+{
+    if constexpr (N + K > 16 && N <= 32 && N + K + 1 <= 64 && K <= 16) {
+        if (a.rs != tape_stride_c(N, K)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((smoother_dk_kernel<N, K>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+#define MK_CASE_DK(NN, KK) \
+    if (N == NN && K == KK) return launch_dk_nk<NN, KK>(a, s);
+hipError_t launch_smoother_dk(int N, int K, const SmootherArgs &a, hipStream_t s)
+{
+    MK_SHAPES(MK_CASE_DK)
+    return hipErrorNotSupported;
+}
+
+} // namespace mk

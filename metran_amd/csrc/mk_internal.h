@@ -34,6 +34,7 @@ struct FilterArgs {
     double *F, *Pf, *Xp, *Pp;
     unsigned *status;
     long variant;        // bit 0: wide models keep filter_kernel<N,K,64> (one state per lane) instead of the split layout
+    long tape;           // 1: F is the backward tape of the inverse-free smoother (MK_OUT_TAPE; rs = tape_stride(N, K))
 };
 
 // Timing experiments that skip phases of a kernel (and so produce wrong numbers) exist only in builds made with
@@ -60,6 +61,7 @@ struct SmootherArgs {
     unsigned *status;
     long variant;        // bit 0: n <= 15 records -> smoother_blk_kernel; bit 1: n > 16 -> smoother_wave_kernel (round 1); bit 2: n > 16 -> the MFMA kernel without the lane fold; bits 3 / 4: (-DMK_EXPERIMENTAL_BLK4 builds only) n > 16, n % 4 == 0 -> the 4x4x4 MFMA block path with / without the lane fold;
                          // set by the C ABI from mk_set_kernel_variant.  Every variant is a tested, equivalent kernel.
+    long tape;           // 1: F is the backward tape (MK_OUT_TAPE, rs = tape_stride(N, K)): smoother_dk_kernel (mk_dk.hip)
 };
 
 struct AdjointArgs {
@@ -93,6 +95,7 @@ hipError_t launch_alpha_grad(long B, long R, int N, int K, const double *alpha, 
                              const double *gphi, const double *gq, double *galpha, hipStream_t s);
 hipError_t launch_smoother(int N, int K, const SmootherArgs &a, hipStream_t s);
 hipError_t launch_smoother_wide(int N, int K, const SmootherArgs &a, hipStream_t s); // mk_wide.hip (n > 16)
+hipError_t launch_smoother_dk(int N, int K, const SmootherArgs &a, hipStream_t s);   // mk_dk.hip (a.tape)
 int record_stride(int n); // doubles per packed record for state dimension n
 int record_stride_sym(int n); // ... per packed-symmetric record
 int num_shapes();

@@ -1872,7 +1872,7 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     const bool book = a.sigmas || a.detfs;
     const bool any = a.F || a.Pf || a.Xp || a.Pp;
     if constexpr (n > 16 && N <= 32) { // wide models: several per wavefront in the split layout (mk_split.hip)
-        if (!(a.variant & 1)) {
+        if (!(a.variant & 1) || a.tape) {
             const hipError_t e = launch_filter_split(N, K, a, s);
             if (e != hipErrorNotSupported) return e;
         }
@@ -1972,6 +1972,7 @@ void get_shape(int i, int *N, int *K);
 } // namespace mk
 #include "mk_wide.hip" // one translation unit per run-time shape module
 #include "mk_split.hip"
+#include "mk_dk.hip"
 namespace mk {
 // ---------------------------------------------------------------------------------------------
 // Shape module: this same translation unit compiled at run time for ONE (N, K) that is not in the

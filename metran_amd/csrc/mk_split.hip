@@ -26,76 +26,18 @@
 // the series rows as K contiguous doubles per lane; the factor block from the replicated copy.
 // Modes: OUT 0 (objective only), 1 (predicted + filtered records), 3 (filtered record); full-square records only --
 // dense outputs and packed-symmetric records keep filter_kernel<N,K,64>.
+// OUT 4 (round 4): the BACKWARD TAPE of the inverse-free smoother (mk_dk.hip) instead of a covariance record -- per
+// (step, series) one entry of ES = n + 4 doubles in the OBSERVABLE basis xt = T x, T = [[I, G], [0, I]] (series states
+// replaced by the observables y_j = x_j + sum_k g_jk x_{N+k}, in which the observation rows are unit vectors):
+//     observed series j     [ kt = T k (n) | v/f | 1/f | y_j | 0 ]   k = P z_j^T / f, the gain of that scalar update
+//     unobserved series u   [ pt = T Pf z_u^T (n) | z_u x_f | z_u Pf z_u^T | NaN | 0 ]   (end of the step)
+// T k costs K multiply-adds a lane (kt_l = k_l + sum_k g_lk k_{N+k}: own loadings, replicated factor gains); the
+// unobserved entries are one extra pass per unobserved series and model (column pick, d = Pf z_u^T as in an update,
+// no rank-one update).  tests/dk_ref.py::filter_tape is the numpy restatement.
 #include "mk_prims.h"
+#include "mk_jump.h"
 
 namespace mk {
-
-#define MK_SPLIT_CASES(X)                                                                                              \
-    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) \
-    X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
-
-
-// dst (lanes of MASK only) = p[j - BASE] for a wavefront-uniform j in [BASE, BASE + 16): a jump table in place of the
-// decision tree hipcc builds for `switch (j)` (five levels of compare / structurised "Flow" blocks, ~40 scalar
-// instructions and ~10 branches per pick; there are 64 / H picks per scalar update).  Every case is 8 bytes
-// (v_mov_b64 + s_branch), the target is computed from the program counter; j outside the range falls through.
-template <int BASE, unsigned long long MASK>
-__device__ __forceinline__ void pick16(double &dst, int j, double p0, double p1, double p2, double p3, double p4, double p5,
-                                       double p6, double p7, double p8, double p9, double p10, double p11, double p12,
-                                       double p13, double p14, double p15)
-{
-    int t;
-    unsigned long long saved;
-    asm volatile("s_sub_i32 %[t], %[j], %[base]\n\t"
-                 "s_cmp_lt_u32 %[t], 16\n\t"
-                 "s_cbranch_scc0 .Lpick_end_%=\n\t"
-                 "s_lshl_b32 %[t], %[t], 3\n\t"
-                 "s_add_u32 %[t], %[t], 12\n\t"
-                 "s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b32 exec_lo, %[mlo]\n\t"
-                 "s_mov_b32 exec_hi, %[mhi]\n\t"
-                 "s_getpc_b64 vcc\n\t"
-                 "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"
-                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
-                 "s_setpc_b64 vcc\n\t"
-                 "v_mov_b64 %[d], %[p0]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p1]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p2]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p3]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p4]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p5]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p6]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p7]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p8]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p9]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p10]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p11]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p12]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p13]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p14]\n\ts_branch .Lpick_done_%=\n\t"
-                 "v_mov_b64 %[d], %[p15]\n\t"
-                 ".Lpick_done_%=:\n\t"
-                 "s_mov_b64 exec, %[sv]\n\t"
-                 ".Lpick_end_%=:"
-                 : [d] "+v"(dst), [t] "=&s"(t), [sv] "=&s"(saved)
-                 : [j] "s"(j), [base] "n"(BASE), [mlo] "n"((int)(unsigned)(MASK & 0xffffffffull)), [mhi] "n"((int)(unsigned)(MASK >> 32)),
-                   [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
-                   [p8] "v"(p8), [p9] "v"(p9), [p10] "v"(p10), [p11] "v"(p11), [p12] "v"(p12), [p13] "v"(p13), [p14] "v"(p14),
-                   [p15] "v"(p15)
-                 : "vcc", "scc");
-}
-// element j (wavefront-uniform, < N) of the lane's row, written to the lanes of MASK
-template <int N, int n, unsigned long long MASK>
-__device__ __forceinline__ void pick_column(double &dst, int j, const double (&P)[n])
-{
-#define MK_PE(i) P[(i) < N ? (i) : N - 1]
-    pick16<0, MASK>(dst, j, MK_PE(0), MK_PE(1), MK_PE(2), MK_PE(3), MK_PE(4), MK_PE(5), MK_PE(6), MK_PE(7), MK_PE(8), MK_PE(9),
-                    MK_PE(10), MK_PE(11), MK_PE(12), MK_PE(13), MK_PE(14), MK_PE(15));
-    if constexpr (N > 16)
-        pick16<16, MASK>(dst, j, MK_PE(16), MK_PE(17), MK_PE(18), MK_PE(19), MK_PE(20), MK_PE(21), MK_PE(22), MK_PE(23), MK_PE(24),
-                         MK_PE(25), MK_PE(26), MK_PE(27), MK_PE(28), MK_PE(29), MK_PE(30), MK_PE(31));
-#undef MK_PE
-}
 
 template <int N, int K, int H, int OUT, bool BOOK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) filter_split_kernel(FilterArgs a)
@@ -108,6 +50,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int KK2 = (K * K + 1) & ~1;
     constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
     constexpr bool RECF = (OUT == 1 || OUT == 3);
+    constexpr bool TAPE = (OUT == 4);
+    constexpr int ES = n + 4;                    // tape entry: [ vector (n) | s0 | s1 | s2 | 0 ]
+    constexpr bool PAIRS = (K % 2 == 0 && N % 2 == 0); // 16-byte accesses to the factor part / the entry's scalars
+    constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
     constexpr int TS = 16;                       // observation tile: time steps per LDS refill
     constexpr unsigned HM = H == 32 ? 0xffffffffu : 0xffffu;
     auto pf = [](int k, int k2) constexpr { return k * K - k * (k - 1) / 2 + (k2 - k); }; // k <= k2
@@ -162,6 +108,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *recP = (OUT == 1) ? a.Xp + inst * a.bs * RS : nullptr;
     double *recF = RECF ? a.F + inst * a.bs * RS : nullptr;
     const long rstep = a.ts * RS;
+    double *trec = TAPE ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step): N entries of ES doubles
+    const long tstep = a.ts * a.rs;
     const int kl = l < K ? l : K - 1;            // factor state whose mean this lane writes
     const int fl16 = l < K * K ? l : K * K - 1;  // factor-block element this lane writes
 
@@ -252,6 +200,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             double sigma = 0.0, fmant = 1.0;
             int fexp = 0, nupd = 0;
             unsigned many = 0;
+            [[maybe_unused]] unsigned urem[M]; // TAPE: the series NOT observed at this step, per model
+#pragma unroll
+            for (int g = 0; g < M; ++g) urem[g] = ~mrem[g] & NM;
 #pragma unroll
             for (int g = 0; g < M; ++g) many |= mrem[g];
             while (many) {
@@ -372,6 +323,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             xk[k] = fma(kf[k], v, xk[k]);
                         }
                     }
+                    if constexpr (TAPE) { // tape entry of the observed series jl: the gain in the observable basis
+                        double kt = kr;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) kt = fma(gam[k], kf[k], kt);
+                        if (okl) {
+                            double *e = trec + jl * ES;
+                            e[jr] = kt;
+                            if (l == jl) {
+                                if constexpr (PAIRS) {
+#pragma unroll
+                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(e + N + k) = v2d{kf[k], kf[k + 1]};
+                                    *reinterpret_cast<v2d *>(e + n) = v2d{v * rf, rf};
+                                    *reinterpret_cast<v2d *>(e + n + 2) = v2d{y, 0.0};
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < K; ++k) e[N + k] = kf[k];
+                                    e[n] = v * rf;
+                                    e[n + 1] = rf;
+                                    e[n + 2] = y;
+                                    e[n + 3] = 0.0;
+                                }
+                            }
+                        }
+                    }
                     double cur[DB], nxt[DB];
                     auto fetch = [&](auto bb, double(&dst)[DB]) __attribute__((always_inline)) {
                         constexpr int c0 = DB * decltype(bb)::value;
@@ -449,6 +424,92 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 emit(recF, x, xk, P, PF, pad0, pad1); // :384-390
                 recF += rstep;
             }
+            if constexpr (TAPE) {
+                // entries of the series NOT observed at this step, from the filtered moments: pt = T Pf z_u^T (what the
+                // backward pass multiplies r and N with), the filtered observable z_u x_f and its variance z_u Pf z_u^T
+                unsigned uany = 0;
+#pragma unroll
+                for (int g = 0; g < M; ++g) uany |= urem[g];
+                int upass = nupd;
+                while (uany) {
+                    int usel[M];
+                    bool uval[M];
+#pragma unroll
+                    for (int g = 0; g < M; ++g) {
+                        uval[g] = urem[g] != 0u;
+                        usel[g] = uval[g] ? (int)__builtin_ctz(urem[g]) : 0;
+                        urem[g] &= urem[g] - 1u;
+                    }
+                    uany = 0;
+#pragma unroll
+                    for (int g = 0; g < M; ++g) uany |= urem[g];
+                    int ul = usel[0];
+                    bool uok = uval[0];
+#pragma unroll
+                    for (int g = 1; g < M; ++g) {
+                        ul = (h == g) ? usel[g] : ul;
+                        uok = (h == g) ? uval[g] : uok;
+                    }
+                    double dr = 0.0;
+                    sfor<0, M>(MK_LAMBDA(gg) {
+                        constexpr int g = decltype(gg)::value;
+                        constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
+                        pick_column<N, n, GM>(dr, __builtin_amdgcn_readfirstlane(usel[g]), P);
+                    });
+                    double gj[K];
+                    {
+                        const double *gp = gtab + ul * K;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) gj[k] = gp[k];
+                    }
+                    double df[K]; // (Pf z_u^T)_{N+k}: right at lane l == u
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        dr = fma(P[N + k], gj[k], dr);
+                        double sdf = P[N + k];
+#pragma unroll
+                        for (int k2 = 0; k2 < K; ++k2) sdf = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], gj[k2], sdf);
+                        df[k] = sdf;
+                    }
+                    double *dv = dbuf + (upass & 1) * NP;
+                    ++upass;
+                    if (l == ul) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) dv[N + k] = df[k];
+                    }
+                    double yh = x, puu = dr; // lane u: z_u x_f and z_u Pf z_u^T
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        yh = fma(gam[k], xk[k], yh);
+                        puu = fma(gam[k], df[k], puu);
+                    }
+                    wave_lds_sync();
+                    double pt = dr;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) pt = fma(gam[k], dv[N + k], pt);
+                    if (uok) {
+                        double *e = trec + ul * ES;
+                        e[jr] = pt;
+                        if (l == ul) {
+                            const double qnan = __builtin_nan("");
+                            if constexpr (PAIRS) {
+#pragma unroll
+                                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(e + N + k) = v2d{df[k], df[k + 1]};
+                                *reinterpret_cast<v2d *>(e + n) = v2d{yh, puu};
+                                *reinterpret_cast<v2d *>(e + n + 2) = v2d{qnan, 0.0};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) e[N + k] = df[k];
+                                e[n] = yh;
+                                e[n + 1] = puu;
+                                e[n + 2] = qnan;
+                                e[n + 3] = 0.0;
+                            }
+                        }
+                    }
+                }
+                trec += tstep;
+            }
         }
     }
 
@@ -477,6 +538,11 @@ static hipError_t launch_split_nk(const FilterArgs &a, hipStream_t s)
         const bool book = a.sigmas || a.detfs;
         const bool any = a.F || a.Pf || a.Xp || a.Pp;
         if (a.sym) return hipErrorNotSupported;
+        if (a.tape) { // the backward tape of mk_dk.hip in a.F (a.rs = N (n + 4) doubles per model-step)
+            if (book) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, true>), dim3(grid), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, false>), dim3(grid), dim3(64), 0, s, a);
+            return hipGetLastError();
+        }
         if (!any && !book) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 0, false>), dim3(grid), dim3(64), 0, s, a);
         else if (!any) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 0, true>), dim3(grid), dim3(64), 0, s, a);
         else if (a.rs > 0 && a.Xp) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 1, true>), dim3(grid), dim3(64), 0, s, a);
@@ -511,92 +577,6 @@ namespace mk {
 //   step t-1, needed again by the prediction adjoint, waits in LDS.  The reference has no counterpart: scipy differences
 //   n + 1 filter runs (metran/solver.py:248-255) -- 37 of them at configs[3]'s shape.
 // =====================================================================================
-template <int CTRL>
-__device__ __forceinline__ double dpp_perm_f64(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// sum over the 64 lanes, result in every lane: xor-1, xor-2 inside the quads, half-row and row mirrors, then the four
-// row sums through readlanes
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-    v += dpp_perm_f64<0xB1>(v);  // quad_perm [1,0,3,2]
-    v += dpp_perm_f64<0x4E>(v);  // quad_perm [2,3,0,1]
-    v += dpp_perm_f64<0x141>(v); // row_half_mirror
-    v += dpp_perm_f64<0x140>(v); // row_mirror
-    using G64 = Group<64>;
-    return (G64::bcast<0>(v) + G64::bcast<16>(v)) + (G64::bcast<32>(v) + G64::bcast<48>(v));
-}
-
-// p[j - BASE] += h for a wavefront-uniform j in [BASE, BASE + 16) (jump table, 12 bytes per case: v_add_f64 + s_branch)
-template <int BASE>
-__device__ __forceinline__ void add16(int j, double h, double &p0, double &p1, double &p2, double &p3, double &p4, double &p5,
-                                      double &p6, double &p7, double &p8, double &p9, double &p10, double &p11, double &p12,
-                                      double &p13, double &p14, double &p15)
-{
-    int t;
-    asm volatile("s_sub_i32 %[t], %[j], %[base]\n\t"
-                 "s_cmp_lt_u32 %[t], 16\n\t"
-                 "s_cbranch_scc0 .Ladd_end_%=\n\t"
-                 "s_mul_i32 %[t], %[t], 12\n\t"
-                 "s_add_u32 %[t], %[t], 12\n\t"
-                 "s_getpc_b64 vcc\n\t"
-                 "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"
-                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
-                 "s_setpc_b64 vcc\n\t"
-                 "v_add_f64 %[p0], %[p0], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p1], %[p1], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p2], %[p2], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p3], %[p3], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p4], %[p4], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p5], %[p5], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p6], %[p6], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p7], %[p7], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p8], %[p8], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p9], %[p9], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p10], %[p10], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p11], %[p11], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p12], %[p12], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p13], %[p13], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p14], %[p14], %[h]\n\ts_branch .Ladd_end_%=\n\t"
-                 "v_add_f64 %[p15], %[p15], %[h]\n\t"
-                 ".Ladd_end_%=:"
-                 : [t] "=&s"(t), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [p4] "+v"(p4), [p5] "+v"(p5),
-                   [p6] "+v"(p6), [p7] "+v"(p7), [p8] "+v"(p8), [p9] "+v"(p9), [p10] "+v"(p10), [p11] "+v"(p11),
-                   [p12] "+v"(p12), [p13] "+v"(p13), [p14] "+v"(p14), [p15] "+v"(p15)
-                 : [j] "s"(j), [base] "n"(BASE), [h] "v"(h)
-                 : "vcc", "scc");
-}
-template <int N, int n>
-__device__ __forceinline__ void add_column(int j, double h, double (&P)[n])
-{
-    static_assert(N <= 64 && n >= 16, "wide models");
-    double dump = 0.0; // cases beyond N - 1 are never selected (j < N)
-#define MK_AE(i) ((i) < N ? P[(i) < N ? (i) : 0] : dump)
-    sfor<0, (N + 15) / 16>(MK_LAMBDA(bb) {
-        constexpr int B0 = 16 * decltype(bb)::value;
-        add16<B0>(j, h, MK_AE(B0 + 0), MK_AE(B0 + 1), MK_AE(B0 + 2), MK_AE(B0 + 3), MK_AE(B0 + 4), MK_AE(B0 + 5), MK_AE(B0 + 6),
-                  MK_AE(B0 + 7), MK_AE(B0 + 8), MK_AE(B0 + 9), MK_AE(B0 + 10), MK_AE(B0 + 11), MK_AE(B0 + 12), MK_AE(B0 + 13),
-                  MK_AE(B0 + 14), MK_AE(B0 + 15));
-    });
-#undef MK_AE
-}
-// all lanes: dst = P[j], wavefront-uniform j < N <= 64
-template <int N, int n>
-__device__ __forceinline__ void pick_column_all(double &dst, int j, const double (&P)[n])
-{
-#define MK_PE(i) P[(i) < N ? (i) : N - 1]
-    sfor<0, (N + 15) / 16>(MK_LAMBDA(bb) {
-        constexpr int B0 = 16 * decltype(bb)::value;
-        pick16<B0, ~0ull>(dst, j, MK_PE(B0 + 0), MK_PE(B0 + 1), MK_PE(B0 + 2), MK_PE(B0 + 3), MK_PE(B0 + 4), MK_PE(B0 + 5),
-                          MK_PE(B0 + 6), MK_PE(B0 + 7), MK_PE(B0 + 8), MK_PE(B0 + 9), MK_PE(B0 + 10), MK_PE(B0 + 11),
-                          MK_PE(B0 + 12), MK_PE(B0 + 13), MK_PE(B0 + 14), MK_PE(B0 + 15));
-    });
-#undef MK_PE
-}
-
 template <int N, int K>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) adjoint_wide_kernel(AdjointArgs a)
 {

@@ -1061,6 +1061,7 @@ static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
     if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_wide_nk<NN, KK>(a, s);
 hipError_t launch_smoother_wide(int N, int K, const SmootherArgs &a, hipStream_t s)
 {
+    if (a.tape) return launch_smoother_dk(N, K, a, s); // the inverse-free backward pass over the filter's tape (mk_dk.hip)
     MK_SHAPES(MK_CASE_WIDE)
     MK_SHAPES(MK_CASE_WIDE_N)
     return hipErrorInvalidValue;

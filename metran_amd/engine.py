@@ -57,6 +57,9 @@ class BatchedKalman:
             raise ValueError("layout must be 'model_major' or 'time_major'")
         self.time_major = layout == "time_major"
         self.packed_sym = bool(packed_sym)
+        # simulate_smoothed of wide models: "auto" = the inverse-free tape path where it applies (MK_OUT_TAPE: 16 < n,
+        # N <= 32, observation variance 0), else filtered records + RTS smoother; "tape" insists, "records" never uses it
+        self.projection_path = "auto"
         L = _lib.lib()  # raises MetranHipError when the HIP library is not built
         if not torch.cuda.is_available():
             raise MetranHipError("no GPU visible to PyTorch-ROCm; metran_amd has no CPU fallback")
@@ -494,7 +497,8 @@ class BatchedKalman:
                        self._p(g("F")), self._p(g("Pf")), self._p(g("Xp")), self._p(g("Pp")), self._p(g("S")),
                        self._p(g("Ps")), self._p(g("status")), 1 if self.time_major else 0,
                        self._p(g("sim_means")), self._p(g("sim_vars")), int(g("_rs", 0)),
-                       (1 if (self.packed_sym and g("_rs", 0)) else 0) | (2 if g("_var_only") else 0))
+                       (1 if (self.packed_sym and g("_rs", 0) and not g("_tape")) else 0) | (2 if g("_var_only") else 0)
+                       | (4 if g("_tape") else 0))
 
     def filter(self, phi, q, warmup=1, x0=None, P0=None, outputs=("F", "Pf", "Xp", "Pp"), buffers=None):
         """``run_filter`` for B instances (kalmanfilter.py:696-778).  Returns a dict of device tensors."""
@@ -532,13 +536,31 @@ class BatchedKalman:
         self.scale, self.offset = prep(scale), prep(offset)
         return self
 
+    def tape_path(self):
+        """True when ``simulate_smoothed`` runs the inverse-free backward pass over the filter's tape (``MK_OUT_TAPE``:
+        ``mk_split.hip`` OUT = 4 + ``mk_dk.hip``) instead of filtered records + the RTS smoother: wide models served by the
+        split filter (16 < n, N <= 32), observation variance 0, full-square engine, ``projection_path`` not "records"."""
+        ok = (self.loadings is not None and self.obsvar is None and not self.packed_sym
+              and bool(self._L.mk_tape_supported(self.N, self.K)))
+        if self.projection_path == "tape" and not ok:
+            raise MetranHipError("projection_path='tape' needs a model with 16 < N + K, N <= 32, no observation variance "
+                                 "and a full-square engine (got N=%s, K=%s)" % (self.N, getattr(self, "K", None)))
+        return ok and self.projection_path != "records"
+
     def alloc_projection(self, B):
-        """Buffers of ``simulate_smoothed`` for B instances (filtered record array + projected moments), for
-        callers that run it repeatedly (pass them back as ``buffers=``)."""
+        """Buffers of ``simulate_smoothed`` for B instances (filtered record array -- or the backward tape, see
+        ``tape_path`` -- + projected moments), for callers that run it repeatedly (pass them back as ``buffers=``)."""
         torch = _torch()
         res = {"mle": torch.empty(B, dtype=torch.float64, device=self.device),
                "status": torch.zeros(B, dtype=torch.int32, device=self.device),
                "sigmacount": torch.empty(B, dtype=torch.int64, device=self.device), "_rs": self.record_stride()}
+        if self.tape_path():
+            res["_rs"] = int(self._L.mk_tape_stride(self.N, self.K))
+            res["_tape"] = True
+            res["F"] = res["_rec_filt"] = self._empty_bt(B, self.T, res["_rs"])  # d_F = the tape
+            res["sim_means"] = self._empty_bt(B, self.T, self.N)
+            res["sim_vars"] = self._empty_bt(B, self.T, self.N)
+            return res
         res["_rec_filt"], res["F"], res["Pf"], res["sigmas"], res["detfs"] = self._alloc_records(B)
         res["sim_means"] = self._empty_bt(B, self.T, self.N)
         res["sim_vars"] = self._empty_bt(B, self.T, self.N)
@@ -549,7 +571,8 @@ class BatchedKalman:
         WITHOUT materialising the smoothed states: the filter writes only the filtered records, the
         smoother reads them and writes the projected means/variances ``[B,T,N]`` (fused epilogue,
         kalmanfilter.py:569-603 with the scaling set by ``set_scaling``).  Returns a dict with
-        ``sim_means, sim_vars, mle, sigmacount, status`` (and the filtered views ``F, Pf``)."""
+        ``sim_means, sim_vars, mle, sigmacount, status`` (and the filtered views ``F, Pf``; on the tape path of wide
+        models -- ``tape_path`` -- ``F`` is the tape and there is no ``Pf``)."""
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         res = buffers if buffers is not None else self.alloc_projection(B)
         o = self._outputs_struct(res)

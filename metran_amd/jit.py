@@ -23,7 +23,7 @@ _ROOT = os.path.dirname(_HERE)
 # every file a shape module is compiled from, directly or through an #include (mk_prims.h includes the GENERATED
 # mk_sweeps.h: regenerating the sweeps must invalidate cached modules too)
 _SOURCES = [os.path.join(_HERE, "csrc", "mk_kernels.hip"), os.path.join(_HERE, "csrc", "mk_wide.hip"),
-            os.path.join(_HERE, "csrc", "mk_split.hip")] + sorted(
+            os.path.join(_HERE, "csrc", "mk_split.hip"), os.path.join(_HERE, "csrc", "mk_dk.hip")] + sorted(
     os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h")) + [
     os.path.join(_ROOT, "include", "metran_hip.h")]
 

@@ -1,0 +1,121 @@
+"""numpy restatement of the TAPE path (test infrastructure): the forward filter of the wide models writing, per
+(step, series), one entry of the backward tape, and the inverse-free backward recursion (Durbin-Koopman r / N form)
+that turns the tape into the smoothed projection.  What it restates is metran_amd/csrc/mk_split.hip (OUT = 4) and
+metran_amd/csrc/mk_dk.hip; what it is checked against is the oracle (reference kalmansmoother + simulate,
+/root/reference/metran/kalmanfilter.py:403-476, 569-603) in tests/test_dk_ref.py.
+
+Observable basis.  Metran's state is x = [sdf_1..sdf_N | cdf_1..cdf_K] and series j observes z_j x = x_j + sum_k g_jk x_{N+k}
+(metran.py:365-370).  With T = [[I, G], [0, I]] the state xt = T x = [y_1..y_N | cdf] has observation rows e_j, so a scalar
+update touches ONE row / column of the backward information matrix; the price is a transition Pht = T Phi T^-1 =
+[[Phi_s, G Phi_f - Phi_s G], [0, Phi_f]] that is no longer diagonal (paid once per step, not once per observation).
+
+Tape entry (ES = n + 4 doubles) of series j at step t, written by the FILTER:
+  observed    [ kt (n) | v/f | 1/f | y_j | 0 ]    kt = T k, k = P z_j^T / f the gain of that scalar update (kalmanfilter.py:349-366)
+  unobserved  [ pt (n) | yhat_u | Ptt_uu | NaN | 0 ]   pt = T Pf z_u^T, yhat_u = z_u x_f, Ptt_uu = z_u Pf z_u^T  (END of the step)
+Backward, per step (r, N in the observable basis; both zero behind the last step):
+  unobserved u:  mean = yhat_u + pt.r,  var = Ptt_uu - pt' N pt                      (x_s = x_f + Pf r, V = Pf - Pf N Pf)
+  observed j, descending:  w = N kt, beta = kt.r, alpha = kt.w;
+        r_j += v/f - beta;   N[:, j] = N[j, :] = N[:, j] - w;   N[j, j] = (old) - 2 w_j + alpha + 1/f
+        (r <- L'r + z v/f, N <- L'NL + z z'/f with L = I - kt e_j'; for R = 0: mean = y_j, var = 0)
+  transition:  r <- Pht' r,  N <- Pht' N Pht
+"""
+import numpy as np
+
+
+def entry_stride(N, K):
+    return N + K + 4
+
+
+def transform(loadings):
+    N, K = loadings.shape
+    T = np.eye(N + K)
+    T[:N, N:] = loadings
+    return T
+
+
+def filter_tape(obs, phi, q, loadings, obsvar=None, x0=None, P0=None):
+    """One model.  obs [T,N] (NaN = missing).  Returns tape [T, N, n+4]."""
+    Tn, N = obs.shape
+    K = loadings.shape[1]
+    n = N + K
+    Z = np.concatenate([np.eye(N), loadings], axis=1)
+    Tm = transform(loadings)
+    R = np.zeros(N) if obsvar is None else np.asarray(obsvar, float)
+    x = np.zeros(n) if x0 is None else np.array(x0, float)
+    P = np.eye(n) if P0 is None else np.array(P0, float)
+    tape = np.zeros((Tn, N, n + 4))
+    for t in range(Tn):
+        x = phi * x
+        P = P * np.outer(phi, phi) + np.diag(q)
+        seen = np.isfinite(obs[t])
+        for j in np.nonzero(seen)[0]:
+            z = Z[j]
+            v = obs[t, j] - z @ x
+            d = P @ z
+            f = z @ d + R[j]
+            k = d / f
+            x = x + k * v
+            P = P - np.outer(k, k) * f
+            e = tape[t, j]
+            e[:n] = Tm @ k
+            e[n:] = (v / f, 1.0 / f, obs[t, j], 0.0)
+        for u in np.nonzero(~seen)[0]:
+            z = Z[u]
+            d = P @ z
+            e = tape[t, u]
+            e[:n] = Tm @ d
+            e[n:] = (z @ x, z @ d, np.nan, 0.0)
+    return tape
+
+
+def transition(phi, loadings):
+    """Pht = T Phi T^-1 = [[Phi_s, C], [0, Phi_f]], C[a][k] = g_ak (phi_{N+k} - phi_a)."""
+    N, K = loadings.shape
+    n = N + K
+    Pht = np.diag(phi).astype(float)
+    Pht[:N, N:] = loadings * (phi[None, N:] - phi[:N, None])
+    assert Pht.shape == (n, n)
+    return Pht
+
+
+def dk_smooth(tape, phi, loadings):
+    """One model.  Returns (means [T,N], variances [T,N]) of the smoothed observables z_j x_t (unscaled)."""
+    Tn, N, ES = tape.shape
+    n = ES - 4
+    Pht = transition(phi, loadings)
+    r = np.zeros(n)
+    Nm = np.zeros((n, n))
+    means, variances = np.empty((Tn, N)), np.empty((Tn, N))
+    for t in range(Tn - 1, -1, -1):
+        seen = ~np.isnan(tape[t, :, n + 2])
+        for u in np.nonzero(~seen)[0]:
+            e = tape[t, u]
+            p = e[:n]
+            means[t, u] = e[n] + p @ r
+            variances[t, u] = e[n + 1] - p @ Nm @ p
+        for j in np.nonzero(seen)[0][::-1]:
+            e = tape[t, j]
+            k = e[:n]
+            w = Nm @ k
+            beta = k @ r
+            alpha = k @ w
+            r[j] += e[n] - beta
+            col = Nm[:, j] - w
+            col[j] = Nm[j, j] - 2.0 * w[j] + alpha + e[n + 1]
+            Nm[:, j] = col
+            Nm[j, :] = col
+            means[t, j] = e[n + 2]
+            variances[t, j] = 0.0
+        r = Pht.T @ r
+        Nm = Pht.T @ Nm @ Pht
+    return means, variances
+
+
+def project(means, variances, scale=None, offset=None):
+    """simulate() with the series' standard deviations and means folded in (metran.py:944-961, kalmanfilter.py:597-602)."""
+    if scale is not None:
+        means = means * scale
+        variances = variances * scale * scale
+    if offset is not None:
+        means = means + offset
+    return means, np.maximum(variances, 0.0)

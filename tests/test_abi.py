@@ -82,7 +82,7 @@ def test_no_gpu_calls_fail_loudly_not_silently(lib):
 
     with pytest.raises(MetranHipError):
         BatchedKalman()
-    assert lib.mk_abi_version() == 4
+    assert lib.mk_abi_version() == 5
     assert lib.mk_shape_supported(8, 2) == 1 and lib.mk_shape_supported(32, 4) == 1
     assert lib.mk_shape_supported(7, 7) == 0
 
