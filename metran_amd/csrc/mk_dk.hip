@@ -206,7 +206,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         auto unobs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
             const int u = (int)__builtin_ctz(um);
             um &= um - 1u;
-            if (um) load_ent((int)__builtin_ctz(um), Enext);
+            load_ent(um ? (int)__builtin_ctz(um) : u, Enext); // the next entry's LDS reads in flight during this product
+            __builtin_amdgcn_sched_barrier(0);
             const double w = matvec(E);
             tapeb[u * ES + (lane < n ? lane : n + 3)] = lane < n ? E.xa * w : w;
         };
@@ -245,10 +246,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         auto obs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
             const int j = 31 - (int)__builtin_clz(om);
             om &= ~(1u << j);
-            if (om) load_ent(31 - (int)__builtin_clz(om), Enext);
+            load_ent(om ? 31 - (int)__builtin_clz(om) : j, Enext); // the next entry's LDS reads in flight during this product
+            __builtin_amdgcn_sched_barrier(0);
             const double w = matvec(E);
             const double beta = readlane_f64(w, n);
-            const double alpha = wave_sum_f64(E.xa * w);
+            const double alpha = wave_sum_mfma(E.xa * w);
             double picked = 0.0;
             pick_column_all<N, n>(picked, j, Nr);
             double nc = picked - w;                                       // N[a][j] - w_a

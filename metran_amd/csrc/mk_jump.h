@@ -72,8 +72,9 @@ __device__ __forceinline__ void pick_column(double &dst, int j, const double (&P
 template <int CTRL>
 __device__ __forceinline__ double dpp_perm_f64(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (bound_ctrl: every lane of these permutations has a source, so no "old" value has to be materialised)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // sum over the 64 lanes, result in every lane: xor-1, xor-2 inside the quads, half-row and row mirrors, then the four
@@ -86,6 +87,21 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     v += dpp_perm_f64<0x140>(v); // row_mirror
     using G64 = Group<64>;
     return (G64::bcast<0>(v) + G64::bcast<16>(v)) + (G64::bcast<32>(v) + G64::bcast<48>(v));
+}
+
+// Sum over the 64 lanes, result in every lane, on the matrix pipe: v_mfma_f64_4x4x4_4b_f64 contracts over the four DPP rows
+// (lane = j + 4 b + 16 k: element j of block b in row k), so with a matrix of ones as the other operand one instruction adds
+// the four rows for every lane position and a second one (operand roles swapped: the first result comes back transposed
+// between quad position and row) completes the sum over each 16-lane set {quad b of every row}; the four quad totals of a
+// row are then two rotate-and-add steps.  2 MFMA (16 cycles of the f64 pipe each) + 6 vector instructions against the 8
+// permutes, 8 readlanes and 11 additions of wave_sum_f64.
+__device__ __forceinline__ double wave_sum_mfma(double v)
+{
+    double t = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, t, 0.0, 0, 0, 0);
+    t += dpp_perm_f64<0x124>(t); // row_ror:4
+    t += dpp_perm_f64<0x128>(t); // row_ror:8
+    return t;
 }
 
 // p[j - BASE] += h for a wavefront-uniform j in [BASE, BASE + 16) (jump table, 12 bytes per case: v_add_f64 + s_branch)

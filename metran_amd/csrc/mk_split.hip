@@ -67,13 +67,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // wave-private LDS, one slice per model of the wavefront
     constexpr int KP = (K + 1) & ~1;
-    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N)];
+    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N + (TAPE ? N * KP : 0))];
     double *phim = lds + h * NP;                                   // diag(Phi) [n]
     double *dbuf = lds + M * NP + h * 2 * NP;                      // d = P Z_j^T, two buffers
     double *gtab = lds + M * 3 * NP + h * GT;                      // loadings [N][K]
     double *pfs = lds + M * (3 * NP + GT) + h * KK2;               // factor block staging for the record stores
     double *qtab = lds + M * (3 * NP + GT + KK2) + h * KP;         // diag(Q) of the factor states
     double *otile = lds + M * (3 * NP + GT + KK2 + KP) + h * TS * N; // observations of TS steps
+    [[maybe_unused]] double *fct = lds + M * (3 * NP + GT + KK2 + KP + TS * N) + h * N * KP; // TAPE: factor columns Pf[l][N+k]
 
     const double phi_l = a.phi[inst * n + jr];
     const double q_l = a.q[inst * n + jr];
@@ -426,84 +427,94 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             if constexpr (TAPE) {
                 // entries of the series NOT observed at this step, from the filtered moments: pt = T Pf z_u^T (what the
-                // backward pass multiplies r and N with), the filtered observable z_u x_f and its variance z_u Pf z_u^T
+                // backward pass multiplies r and N with), the filtered observable z_u x_f and its variance z_u Pf z_u^T.
+                //   pt_l = Pf[l][u] + sum_k g_uk Q[l][k] + sum_k g_lk Pf[u][N+k],   Q[l][k] = Pf[l][N+k] + sum_k' g_lk' PF[k'][k]
+                // Q (= the factor columns of T Pf) is formed once per step; Pf[u][N+k] comes from a table every lane fills
+                // with its own factor columns; at lane u, Q[u][.] IS the factor part of pt and pt_u IS z_u Pf z_u^T.
                 unsigned uany = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) uany |= urem[g];
-                int upass = nupd;
-                while (uany) {
-                    int usel[M];
-                    bool uval[M];
-#pragma unroll
-                    for (int g = 0; g < M; ++g) {
-                        uval[g] = urem[g] != 0u;
-                        usel[g] = uval[g] ? (int)__builtin_ctz(urem[g]) : 0;
-                        urem[g] &= urem[g] - 1u;
-                    }
-                    uany = 0;
-#pragma unroll
-                    for (int g = 0; g < M; ++g) uany |= urem[g];
-                    int ul = usel[0];
-                    bool uok = uval[0];
-#pragma unroll
-                    for (int g = 1; g < M; ++g) {
-                        ul = (h == g) ? usel[g] : ul;
-                        uok = (h == g) ? uval[g] : uok;
-                    }
-                    double dr = 0.0;
-                    sfor<0, M>(MK_LAMBDA(gg) {
-                        constexpr int g = decltype(gg)::value;
-                        constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
-                        pick_column<N, n, GM>(dr, __builtin_amdgcn_readfirstlane(usel[g]), P);
-                    });
-                    double gj[K];
-                    {
-                        const double *gp = gtab + ul * K;
-#pragma unroll
-                        for (int k = 0; k < K; ++k) gj[k] = gp[k];
-                    }
-                    double df[K]; // (Pf z_u^T)_{N+k}: right at lane l == u
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        dr = fma(P[N + k], gj[k], dr);
-                        double sdf = P[N + k];
-#pragma unroll
-                        for (int k2 = 0; k2 < K; ++k2) sdf = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], gj[k2], sdf);
-                        df[k] = sdf;
-                    }
-                    double *dv = dbuf + (upass & 1) * NP;
-                    ++upass;
-                    if (l == ul) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) dv[N + k] = df[k];
-                    }
-                    double yh = x, puu = dr; // lane u: z_u x_f and z_u Pf z_u^T
+                if (uany) {
+                    double Q[K], yh = x;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         yh = fma(gam[k], xk[k], yh);
-                        puu = fma(gam[k], df[k], puu);
+                        double sq = P[N + k];
+#pragma unroll
+                        for (int k2 = 0; k2 < K; ++k2) sq = fma(gam[k2], PF[k <= k2 ? pf(k, k2) : pf(k2, k)], sq);
+                        Q[k] = sq;
+                    }
+                    wave_lds_sync(); // the previous step's table reads are done
+                    if constexpr (K % 2 == 0) {
+#pragma unroll
+                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(fct + jr * KP + k) = v2d{P[N + k], P[N + k + 1]};
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) fct[jr * KP + k] = P[N + k];
                     }
                     wave_lds_sync();
-                    double pt = dr;
+                    while (uany) {
+                        int usel[M];
+                        bool uval[M];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) pt = fma(gam[k], dv[N + k], pt);
-                    if (uok) {
-                        double *e = trec + ul * ES;
-                        e[jr] = pt;
-                        if (l == ul) {
-                            const double qnan = __builtin_nan("");
-                            if constexpr (PAIRS) {
+                        for (int g = 0; g < M; ++g) {
+                            uval[g] = urem[g] != 0u;
+                            usel[g] = uval[g] ? (int)__builtin_ctz(urem[g]) : 0;
+                            urem[g] &= urem[g] - 1u;
+                        }
+                        uany = 0;
 #pragma unroll
-                                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(e + N + k) = v2d{df[k], df[k + 1]};
-                                *reinterpret_cast<v2d *>(e + n) = v2d{yh, puu};
-                                *reinterpret_cast<v2d *>(e + n + 2) = v2d{qnan, 0.0};
-                            } else {
+                        for (int g = 0; g < M; ++g) uany |= urem[g];
+                        int ul = usel[0];
+                        bool uok = uval[0];
 #pragma unroll
-                                for (int k = 0; k < K; ++k) e[N + k] = df[k];
-                                e[n] = yh;
-                                e[n + 1] = puu;
-                                e[n + 2] = qnan;
-                                e[n + 3] = 0.0;
+                        for (int g = 1; g < M; ++g) {
+                            ul = (h == g) ? usel[g] : ul;
+                            uok = (h == g) ? uval[g] : uok;
+                        }
+                        double pt = 0.0;
+                        sfor<0, M>(MK_LAMBDA(gg) {
+                            constexpr int g = decltype(gg)::value;
+                            constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
+                            pick_column<N, n, GM>(pt, __builtin_amdgcn_readfirstlane(usel[g]), P);
+                        });
+                        const double *gp = gtab + ul * K, *fp = fct + ul * KP;
+                        double pt2 = 0.0;
+                        if constexpr (K % 2 == 0) {
+#pragma unroll
+                            for (int k = 0; k < K; k += 2) {
+                                const v2d g2 = *reinterpret_cast<const v2d *>(gp + k), f2 = *reinterpret_cast<const v2d *>(fp + k);
+                                pt = fma(g2.x, Q[k], pt);
+                                pt2 = fma(g2.y, Q[k + 1], pt2);
+                                pt = fma(gam[k], f2.x, pt);
+                                pt2 = fma(gam[k + 1], f2.y, pt2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) {
+                                pt = fma(gp[k], Q[k], pt);
+                                pt2 = fma(gam[k], fp[k], pt2);
+                            }
+                        }
+                        pt += pt2;
+                        if (uok) {
+                            double *e = trec + ul * ES;
+                            e[jr] = pt;
+                            if (l == ul) {
+                                const double qnan = __builtin_nan("");
+                                if constexpr (PAIRS) {
+#pragma unroll
+                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(e + N + k) = v2d{Q[k], Q[k + 1]};
+                                    *reinterpret_cast<v2d *>(e + n) = v2d{yh, pt};
+                                    *reinterpret_cast<v2d *>(e + n + 2) = v2d{qnan, 0.0};
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < K; ++k) e[N + k] = Q[k];
+                                    e[n] = yh;
+                                    e[n + 1] = pt;
+                                    e[n + 2] = qnan;
+                                    e[n + 3] = 0.0;
+                                }
                             }
                         }
                     }
