@@ -297,7 +297,7 @@ MK_API int mk_shape_supported(int64_t N, int64_t K)
 
 MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
 MK_API int64_t mk_record_stride_sym(int64_t n) { return mk::record_stride_sym((int)n); }
-MK_API int64_t mk_tape_stride(int64_t N, int64_t K) { return N * (N + K + 4); }
+MK_API int64_t mk_tape_stride(int64_t N, int64_t K) { return mk::tape_stride_c((int)N, (int)K); }
 MK_API int mk_tape_supported(int64_t N, int64_t K)
 {
     return (N + K > 16 && N <= 32 && K <= 16 && N + K + 1 <= 64 && mk_shape_supported(N, K)) ? 1 : 0;

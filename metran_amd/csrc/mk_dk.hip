@@ -33,20 +33,17 @@
 
 namespace mk {
 
-constexpr int tape_entry_c(int N, int K) { return N + K + 4; }
-constexpr int tape_stride_c(int N, int K) { return N * tape_entry_c(N, K); }
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
 template <int N, int K>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
 {
-    constexpr int n = N + K, ES = tape_entry_c(N, K), RS = tape_stride_c(N, K);
+    constexpr int n = N + K, SW = tape_side_c(K), RS = tape_stride_c(N, K);
     static_assert(n > 16 && n + 1 <= 64 && K <= 16 && N >= 2, "one model per wavefront: rows 0..n-1 of N and the r row");
     constexpr int NB = (N + 15) / 16;          // DPP-replicated registers holding the series entries of a vector
     constexpr int NP = (n + 2) & ~1;           // >= n + 1, even: LDS rows of 16-byte pieces
-    constexpr bool PAIRS = (n % 2 == 0);       // tape entries are 16-byte aligned
+    constexpr bool PAIRS = (N % 2 == 0);       // side rows are 16-byte aligned
     constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
     constexpr int QS = (N + 2) & ~1;           // series lanes 0..N-1 (+ one dummy slot)
     // the step's tape block is copied HBM -> LDS by the wavefront itself (global_load_lds: no registers, asynchronous):
@@ -67,7 +64,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // wave-private LDS
     __shared__ __attribute__((aligned(16))) double lds[TBD + NP + NP + K * NP + K * K * QS + ((K * K + 1) & ~1)];
-    double *tapeb = lds;                       // the step's tape block: N entries of ES doubles
+    double *tapeb = lds;                       // the step's tape block: [N][N] series parts of the vectors, [N][SW] side rows
+    double *sideb = tapeb + N * N;
     double *phim = tapeb + TBD;                // diag(Phi) [n]
     double *tbuf = phim + NP;                  // the new column j on its way to lane j's row
     double *fbuf = tbuf + NP;                  // [K][NP] factor columns on their way to the factor rows
@@ -119,21 +117,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     int xoff_b[NB];
 #pragma unroll
-    for (int m = 0; m < NB; ++m) xoff_b[m] = 16 * m + i16 < ES ? 16 * m + i16 : ES - 1;
-    const int xoff_f = N + (i16 < K ? i16 : K - 1);
-    const int xoff_a = lane < n ? lane : n + 3; // lanes >= n read the entry's constant 0
+    for (int m = 0; m < NB; ++m) xoff_b[m] = 16 * m + i16 < N ? 16 * m + i16 : N - 1;
+    const int xoff_f = N * N + (i16 < K ? i16 : K - 1);
+    // element `lane` of the vector in its natural layout: series part, factor part, and for lanes >= n the entry's constant 0
+    // (the same slot later receives this lane's product x_a w_a, resp. beta: see the unobserved entries below)
+    const int xa_off = lane < N ? lane : N * N + (lane < n ? lane - N : SW - 1);
+    const int xa_str = lane < N ? N : SW;
     auto load_ent = [&](int j, Ent &E) __attribute__((always_inline)) {
-        const double *e = tapeb + j * ES;
+        const double *e = tapeb + j * N, *sd = tapeb + j * SW;
         sfor<0, NB>(MK_LAMBDA(mm) { E.XB[decltype(mm)::value] = e[xoff_b[decltype(mm)::value]]; });
-        E.XF = e[xoff_f];
-        E.xa = e[xoff_a];
+        E.XF = sd[xoff_f];
+        E.xa = tapeb[xa_off + j * xa_str];
         if constexpr (PAIRS) {
-            const v2d sc = *reinterpret_cast<const v2d *>(e + n);
+            const v2d sc = *reinterpret_cast<const v2d *>(sideb + j * SW + SW - 4);
             E.s0 = sc.x;
             E.s1 = sc.y;
         } else {
-            E.s0 = e[n];
-            E.s1 = e[n + 1];
+            E.s0 = sideb[j * SW + SW - 4];
+            E.s1 = sideb[j * SW + SW - 3];
         }
     };
     // w_a = sum_c N[a][c] x_c: the entry's vector broadcast inside the multiply-add (four per asm statement: hipcc pads
@@ -166,25 +167,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *ovar = a.sim_vars ? a.sim_vars + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
     const long ostep = a.ts * N;
 
-    int sink = 0; // destination of the L2-warming loads below
     fetch_block(tb);
     for (long t = T - 1; t >= 0; --t) {
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this step's block has landed in LDS
         wave_lds_sync();
-        if (t > 1) {                            // warm L2 with the block two steps back (one 128-byte line per lane and load)
-            const char *g2 = reinterpret_cast<const char *>(tb - 2 * tstep);
-#pragma unroll
-            for (int c = 0; c * 64 * 128 < RS * 8; ++c) {
-                long off = ((long)c * 64 + lane) * 128;
-                off = off < blk_bytes - 4 ? off : blk_bytes - 4;
-                // (the destination register stays reserved for the whole kernel: the data lands long after the instruction)
-                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(g2 + off) : "memory");
-            }
-        }
         // the scalars of this lane's series: (s0, s1, s2); s2 = NaN marks "not observed at this step"
         double s0, s1, s2;
         {
-            const double *e = tapeb + js * ES + n;
+            const double *e = sideb + js * SW + SW - 4;
             if constexpr (PAIRS) {
                 const v2d sc = *reinterpret_cast<const v2d *>(e);
                 s0 = sc.x;
@@ -209,9 +199,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             load_ent(um ? (int)__builtin_ctz(um) : u, Enext); // the next entry's LDS reads in flight during this product
             __builtin_amdgcn_sched_barrier(0);
             const double w = matvec(E);
-            tapeb[u * ES + (lane < n ? lane : n + 3)] = lane < n ? E.xa * w : w;
+            tapeb[xa_off + u * xa_str] = lane < n ? E.xa * w : w;
         };
-        if (um) {
+        if (um && !MK_TUNE_SKIP(a, 64)) {
             load_ent((int)__builtin_ctz(um), ea);
             while (true) {
                 unobs_step(ea, eb);
@@ -224,15 +214,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double mean = s2, var = 0.0;              // observed (R = 0): the observation itself, variance 0
         if (unobs) {
             double q0 = 0.0, q1 = 0.0;
-            const double *pr = tapeb + js * ES;
-            double row[n];
-            load_row<n>(pr, row);
+            double row[N], rowf[SW];
+            load_row<N>(tapeb + js * N, row);
+            load_row<SW>(sideb + js * SW, rowf);
 #pragma unroll
-            for (int c = 0; c < n; ++c) {
+            for (int c = 0; c < N; ++c) {
                 if (c % 2 == 0) q0 += row[c];
                 else q1 += row[c];
             }
-            mean = s0 + pr[n + 3];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (k % 2 == 0) q0 += rowf[k];
+                else q1 += rowf[k];
+            }
+            mean = s0 + rowf[SW - 1];
             var = s1 - (q0 + q1);
         }
         {
@@ -243,23 +238,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
         // ---- observed series, last first: the scalar updates of the filter walked backwards
         unsigned om = obsm;
+        int jp = -1;
         auto obs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
             const int j = 31 - (int)__builtin_clz(om);
             om &= ~(1u << j);
             load_ent(om ? 31 - (int)__builtin_clz(om) : j, Enext); // the next entry's LDS reads in flight during this product
-            __builtin_amdgcn_sched_barrier(0);
+            if (lane == jp) load_row<n>(tbuf, Nr);                 // row jp = the new column of the previous entry's series:
+            __builtin_amdgcn_sched_barrier(0);                     // the reads complete underneath the product
             const double w = matvec(E);
             const double beta = readlane_f64(w, n);
-            const double alpha = wave_sum_mfma(E.xa * w);
+            const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);
             double picked = 0.0;
             pick_column_all<N, n>(picked, j, Nr);
             double nc = picked - w;                                       // N[a][j] - w_a
             nc = (lane == j) ? (nc - w) + (alpha + E.s1) : nc;            // N[j][j] - 2 w_j + alpha + 1/f
             nc = (lane >= n) ? picked + (E.s0 - beta) : nc;               // r_j + v/f - beta
             set_column<N, n>(j, nc, Nr);
-            tbuf[ra] = nc;                                                // slot n: the r row's, unused
-            wave_lds_sync();
-            if (lane == j) load_row<n>(tbuf, Nr);                         // row j = the new column j
+            if (!MK_TUNE_SKIP(a, 16)) {
+                tbuf[ra] = nc;                                            // slot n: the r row's, unused
+                wave_lds_sync();
+                jp = j;                                                   // lane j fetches its row at the top of the next entry
+            }
         };
         if (om) {
             load_ent(31 - (int)__builtin_clz(om), ea);
@@ -269,6 +268,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 obs_step(eb, ea);
                 if (!om) break;
             }
+            if (lane == jp) load_row<n>(tbuf, Nr);
         }
         // every entry of the step has been consumed: next step's block on its way while the transition runs
         tb -= tstep;
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
 
         // ---- transition: r <- Pht'r, N <- Pht'N Pht
-        if (t > 0) {
+        if (t > 0 && !MK_TUNE_SKIP(a, 128)) {
             double Yf[K];
             sfor<0, K>(MK_LAMBDA(kk) { // factor columns: Y[a][N+k] = sum_c N[a][c] C[c][k] + N[a][N+k] phi_{N+k}
                 constexpr int k = decltype(kk)::value;
@@ -341,8 +341,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (omean) omean -= ostep;
         if (ovar) ovar -= ostep;
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" : : "v"(sink));
 }
 
 // Which calls the tape path serves: the shapes of the split filter (16 < n, N <= 32), projection outputs.

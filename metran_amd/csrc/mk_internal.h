@@ -21,6 +21,11 @@
 
 namespace mk {
 
+// backward tape of the wide models (MK_OUT_TAPE; mk_split.hip writes it, mk_dk.hip reads it): per (model, step) an N x N
+// array of the series parts of the N entry vectors and an N x SW array of side rows [ factor part (K) | .. | s0 | s1 | s2 | 0 ]
+constexpr int tape_side_c(int K) { return (K + 5) & ~1; }
+constexpr int tape_stride_c(int N, int K) { return N * (N + tape_side_c(K)); }
+
 struct FilterArgs {
     long B, R, T, warmup;
     long bs, ts;         // state/bookkeeping outputs: block (b, t) at index b*bs + t*ts

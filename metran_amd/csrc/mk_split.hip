@@ -27,10 +27,15 @@
 // Modes: OUT 0 (objective only), 1 (predicted + filtered records), 3 (filtered record); full-square records only --
 // dense outputs and packed-symmetric records keep filter_kernel<N,K,64>.
 // OUT 4 (round 4): the BACKWARD TAPE of the inverse-free smoother (mk_dk.hip) instead of a covariance record -- per
-// (step, series) one entry of ES = n + 4 doubles in the OBSERVABLE basis xt = T x, T = [[I, G], [0, I]] (series states
+// (step, series) one entry of n + 4 doubles in the OBSERVABLE basis xt = T x, T = [[I, G], [0, I]] (series states
 // replaced by the observables y_j = x_j + sum_k g_jk x_{N+k}, in which the observation rows are unit vectors):
 //     observed series j     [ kt = T k (n) | v/f | 1/f | y_j | 0 ]   k = P z_j^T / f, the gain of that scalar update
 //     unobserved series u   [ pt = T Pf z_u^T (n) | z_u x_f | z_u Pf z_u^T | NaN | 0 ]   (end of the step)
+// Block of one (model, step) in HBM (mk_tape_stride = N (N + SW) doubles, SW = tape_side_c(K)): the series parts of the N
+// vectors as an N x N array (entry j = row j: one 8 N-byte run per store instruction and model), then an N x SW "side"
+// array [ factor part (K) | .. | s0 | s1 | s2 | 0 ] that is collected in LDS during the step and written once, as whole
+// rows, at its end (measured: the 16- and 32-byte pieces of the side part written straight from the update loop cost the
+// filter 10 ms of 56 at configs[3] -- 100 tiny store instructions a step).
 // T k costs K multiply-adds a lane (kt_l = k_l + sum_k g_lk k_{N+k}: own loadings, replicated factor gains); the
 // unobserved entries are one extra pass per unobserved series and model (column pick, d = Pf z_u^T as in an update,
 // no rank-one update).  tests/dk_ref.py::filter_tape is the numpy restatement.
@@ -51,7 +56,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
     constexpr bool RECF = (OUT == 1 || OUT == 3);
     constexpr bool TAPE = (OUT == 4);
-    constexpr int ES = n + 4;                    // tape entry: [ vector (n) | s0 | s1 | s2 | 0 ]
+    constexpr int SW = tape_side_c(K);           // side row of a tape entry: [ factor part (K) | .. | s0 | s1 | s2 | 0 ]
     constexpr bool PAIRS = (K % 2 == 0 && N % 2 == 0); // 16-byte accesses to the factor part / the entry's scalars
     constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
     constexpr int TS = 16;                       // observation tile: time steps per LDS refill
@@ -67,7 +72,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // wave-private LDS, one slice per model of the wavefront
     constexpr int KP = (K + 1) & ~1;
-    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N + (TAPE ? N * KP : 0))];
+    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N + (TAPE ? N * KP + N * SW : 0))];
     double *phim = lds + h * NP;                                   // diag(Phi) [n]
     double *dbuf = lds + M * NP + h * 2 * NP;                      // d = P Z_j^T, two buffers
     double *gtab = lds + M * 3 * NP + h * GT;                      // loadings [N][K]
@@ -75,6 +80,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *qtab = lds + M * (3 * NP + GT + KK2) + h * KP;         // diag(Q) of the factor states
     double *otile = lds + M * (3 * NP + GT + KK2 + KP) + h * TS * N; // observations of TS steps
     [[maybe_unused]] double *fct = lds + M * (3 * NP + GT + KK2 + KP + TS * N) + h * N * KP; // TAPE: factor columns Pf[l][N+k]
+    [[maybe_unused]] double *side = lds + M * (3 * NP + GT + KK2 + KP + TS * N + N * KP) + h * N * SW; // TAPE: side rows of the step
 
     const double phi_l = a.phi[inst * n + jr];
     const double q_l = a.q[inst * n + jr];
@@ -109,7 +115,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *recP = (OUT == 1) ? a.Xp + inst * a.bs * RS : nullptr;
     double *recF = RECF ? a.F + inst * a.bs * RS : nullptr;
     const long rstep = a.ts * RS;
-    double *trec = TAPE ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step): N entries of ES doubles
+    double *trec = TAPE ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step): [N][N] vectors, [N][SW] side rows
     const long tstep = a.ts * a.rs;
     const int kl = l < K ? l : K - 1;            // factor state whose mean this lane writes
     const int fl16 = l < K * K ? l : K * K - 1;  // factor-block element this lane writes
@@ -328,22 +334,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         double kt = kr;
 #pragma unroll
                         for (int k = 0; k < K; ++k) kt = fma(gam[k], kf[k], kt);
-                        if (okl) {
-                            double *e = trec + jl * ES;
-                            e[jr] = kt;
+                        if (okl && !MK_TUNE_SKIP(a, 1)) {
+                            trec[jl * N + jr] = kt;
                             if (l == jl) {
+                                double *sd = side + jl * SW;
                                 if constexpr (PAIRS) {
 #pragma unroll
-                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(e + N + k) = v2d{kf[k], kf[k + 1]};
-                                    *reinterpret_cast<v2d *>(e + n) = v2d{v * rf, rf};
-                                    *reinterpret_cast<v2d *>(e + n + 2) = v2d{y, 0.0};
+                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{kf[k], kf[k + 1]};
+                                    *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{v * rf, rf};
+                                    *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{y, 0.0};
                                 } else {
 #pragma unroll
-                                    for (int k = 0; k < K; ++k) e[N + k] = kf[k];
-                                    e[n] = v * rf;
-                                    e[n + 1] = rf;
-                                    e[n + 2] = y;
-                                    e[n + 3] = 0.0;
+                                    for (int k = 0; k < K; ++k) sd[k] = kf[k];
+                                    sd[SW - 4] = v * rf;
+                                    sd[SW - 3] = rf;
+                                    sd[SW - 2] = y;
+                                    sd[SW - 1] = 0.0;
                                 }
                             }
                         }
@@ -434,7 +440,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 unsigned uany = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) uany |= urem[g];
-                if (uany) {
+                if (uany && !MK_TUNE_SKIP(a, 2)) {
                     double Q[K], yh = x;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
@@ -497,26 +503,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             }
                         }
                         pt += pt2;
-                        if (uok) {
-                            double *e = trec + ul * ES;
-                            e[jr] = pt;
+                        if (uok && !MK_TUNE_SKIP(a, 4)) {
+                            trec[ul * N + jr] = pt;
                             if (l == ul) {
                                 const double qnan = __builtin_nan("");
+                                double *sd = side + ul * SW;
                                 if constexpr (PAIRS) {
 #pragma unroll
-                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(e + N + k) = v2d{Q[k], Q[k + 1]};
-                                    *reinterpret_cast<v2d *>(e + n) = v2d{yh, pt};
-                                    *reinterpret_cast<v2d *>(e + n + 2) = v2d{qnan, 0.0};
+                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{Q[k], Q[k + 1]};
+                                    *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{yh, pt};
+                                    *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
                                 } else {
 #pragma unroll
-                                    for (int k = 0; k < K; ++k) e[N + k] = Q[k];
-                                    e[n] = yh;
-                                    e[n + 1] = pt;
-                                    e[n + 2] = qnan;
-                                    e[n + 3] = 0.0;
+                                    for (int k = 0; k < K; ++k) sd[k] = Q[k];
+                                    sd[SW - 4] = yh;
+                                    sd[SW - 3] = pt;
+                                    sd[SW - 2] = qnan;
+                                    sd[SW - 1] = 0.0;
                                 }
                             }
                         }
+                    }
+                }
+                // the side rows of all N entries of this step (every series was either observed or not): whole rows, once
+                wave_lds_sync();
+                {
+                    const double *sr = side + jr * SW;
+                    double *ds = trec + N * N + jr * SW;
+                    if constexpr (PAIRS) {
+#pragma unroll
+                        for (int c = 0; c < SW; c += 2) *reinterpret_cast<v2d *>(ds + c) = *reinterpret_cast<const v2d *>(sr + c);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < SW; ++c) ds[c] = sr[c];
                     }
                 }
                 trec += tstep;
