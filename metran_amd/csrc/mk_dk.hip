@@ -36,7 +36,13 @@ namespace mk {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
-template <int N, int K>
+#ifdef MK_DK_DYNAMIC
+constexpr bool kDkStatic = false; // A/B builds: the entry loops over the set bits of the step's masks (jump-table column access)
+#else
+constexpr bool kDkStatic = true;
+#endif
+
+template <int N, int K, bool STATICJ = kDkStatic>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, SW = tape_side_c(K), RS = tape_stride_c(N, K);
@@ -260,7 +266,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 jp = j;                                                   // lane j fetches its row at the top of the next entry
             }
         };
-        if (om) {
+        if constexpr (STATICJ) {
+            // the loop over the series is UNROLLED (static j: an entry's LDS addresses are immediates, the column N[.][j] is a
+            // named register -- no bit scan, no address arithmetic, no jump tables for N[.][j]); every position prefetches the
+            // next entry whether it runs or not, a wavefront-uniform branch skips the bodies of the unobserved series
+            if (om) {
+                Ent eo[2];
+                load_ent(N - 1, eo[(N - 1) & 1]);
+                sfor_down<0, N>(MK_LAMBDA(jj) {
+                    constexpr int j = decltype(jj)::value;
+                    if constexpr (j > 0) load_ent(j - 1, eo[(j - 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (om & (1u << j)) {
+                        const Ent &E = eo[j & 1];
+                        if (lane == jp) load_row<n>(tbuf, Nr);                // row jp = the new column of the previous observed series
+                        __builtin_amdgcn_sched_barrier(0);                    // (its reads complete underneath the product)
+                        const double w = matvec(E);
+                        const double beta = readlane_f64(w, n);
+                        const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);
+                        double nc = Nr[j] - w;                                // N[a][j] - w_a
+                        nc = (lane >= n) ? Nr[j] + (E.s0 - beta) : nc;        // r_j + v/f - beta
+                        Nr[j] = nc;
+                        if (!MK_TUNE_SKIP(a, 16)) {
+                            tbuf[ra] = nc;                                    // slot n: the r row's, unused
+                            // the diagonal N[j][j] - 2 w_j + alpha + 1/f: lane j rewrites its slot when alpha has arrived (its own
+                            // register is refreshed from there with the rest of row j)
+                            if (lane == j) tbuf[j] = (nc - w) + (alpha + E.s1);
+                            wave_lds_sync();
+                            jp = j;
+                        }
+                    }
+                });
+                if (lane == jp) load_row<n>(tbuf, Nr);
+            }
+        } else if (om) {
             load_ent(31 - (int)__builtin_clz(om), ea);
             while (true) {
                 obs_step(ea, eb);
