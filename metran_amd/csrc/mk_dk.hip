@@ -46,10 +46,11 @@ template <int N, int K, bool STATICJ = kDkStatic>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, SW = tape_side_c(K), RS = tape_stride_c(N, K);
+    constexpr int XS = tape_xs_c(N, K), SS = tape_ss_c(N, K), SO = tape_so_c(N, K); // tape block addressing (mk_internal.h)
     static_assert(n > 16 && n + 1 <= 64 && K <= 16 && N >= 2, "one model per wavefront: rows 0..n-1 of N and the r row");
     constexpr int NB = (N + 15) / 16;          // DPP-replicated registers holding the series entries of a vector
     constexpr int NP = (n + 2) & ~1;           // >= n + 1, even: LDS rows of 16-byte pieces
-    constexpr bool PAIRS = (N % 2 == 0);       // side rows are 16-byte aligned
+    constexpr bool PAIRS = (N % 2 == 0 && K % 2 == 0); // side rows and their scalars are 16-byte aligned
     constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
     constexpr int QS = (N + 2) & ~1;           // series lanes 0..N-1 (+ one dummy slot)
     // the step's tape block is copied HBM -> LDS by the wavefront itself (global_load_lds: no registers, asynchronous):
@@ -70,8 +71,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // wave-private LDS
     __shared__ __attribute__((aligned(16))) double lds[TBD + NP + NP + K * NP + K * K * QS + ((K * K + 1) & ~1)];
-    double *tapeb = lds;                       // the step's tape block: [N][N] series parts of the vectors, [N][SW] side rows
-    double *sideb = tapeb + N * N;
+    double *tapeb = lds;                       // the step's tape block: N entries [ series part (N) | side row (SW) ]
+    double *sideb = tapeb + SO;
     double *phim = tapeb + TBD;                // diag(Phi) [n]
     double *tbuf = phim + NP;                  // the new column j on its way to lane j's row
     double *fbuf = tbuf + NP;                  // [K][NP] factor columns on their way to the factor rows
@@ -124,35 +125,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int xoff_b[NB];
 #pragma unroll
     for (int m = 0; m < NB; ++m) xoff_b[m] = 16 * m + i16 < N ? 16 * m + i16 : N - 1;
-    const int xoff_f = N * N + (i16 < K ? i16 : K - 1);
+    const int xoff_f = SO + (i16 < K ? i16 : K - 1);
     // element `lane` of the vector in its natural layout: series part, factor part, and for lanes >= n the entry's constant 0
     // (the same slot later receives this lane's product x_a w_a, resp. beta: see the unobserved entries below)
-    const int xa_off = lane < N ? lane : N * N + (lane < n ? lane - N : SW - 1);
-    const int xa_str = lane < N ? N : SW;
+    const int xa_off = lane < N ? lane : SO + (lane < n ? lane - N : SW - 1);
+    const int xa_str = lane < N ? XS : SS;
     auto load_ent = [&](int j, Ent &E) __attribute__((always_inline)) {
-        const double *e = tapeb + j * N, *sd = tapeb + j * SW;
+        const double *e = tapeb + j * XS, *sd = tapeb + j * SS;
         sfor<0, NB>(MK_LAMBDA(mm) { E.XB[decltype(mm)::value] = e[xoff_b[decltype(mm)::value]]; });
         E.XF = sd[xoff_f];
         E.xa = tapeb[xa_off + j * xa_str];
         if constexpr (PAIRS) {
-            const v2d sc = *reinterpret_cast<const v2d *>(sideb + j * SW + SW - 4);
+            const v2d sc = *reinterpret_cast<const v2d *>(sideb + j * SS + SW - 4);
             E.s0 = sc.x;
             E.s1 = sc.y;
         } else {
-            E.s0 = sideb[j * SW + SW - 4];
-            E.s1 = sideb[j * SW + SW - 3];
+            E.s0 = sideb[j * SS + SW - 4];
+            E.s1 = sideb[j * SS + SW - 3];
         }
     };
     // w_a = sum_c N[a][c] x_c: the entry's vector broadcast inside the multiply-add (four per asm statement: hipcc pads
     // every asm statement that follows another with an s_nop)
     auto matvec = [&](const Ent &E) __attribute__((always_inline)) {
         double acc0 = 0.0, acc1 = 0.0;
-        sfor<0, N / 4>(MK_LAMBDA(qq) {
-            constexpr int c = 4 * decltype(qq)::value;
+        sfor<0, N / 16>(MK_LAMBDA(bb) { // sixteen columns per asm statement
+            constexpr int c = 16 * decltype(bb)::value;
+            G16::fmac16(acc0, acc1, E.XB[c / 16], Nr[c], Nr[c + 1], Nr[c + 2], Nr[c + 3], Nr[c + 4], Nr[c + 5], Nr[c + 6], Nr[c + 7], Nr[c + 8],
+                        Nr[c + 9], Nr[c + 10], Nr[c + 11], Nr[c + 12], Nr[c + 13], Nr[c + 14], Nr[c + 15]);
+        });
+        sfor<0, (N % 16) / 4>(MK_LAMBDA(qq) {
+            constexpr int c = 16 * (N / 16) + 4 * decltype(qq)::value;
             G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16>(acc0, acc1, E.XB[c / 16], Nr[c], E.XB[(c + 1) / 16], Nr[c + 1],
                                                                            E.XB[(c + 2) / 16], Nr[c + 2], E.XB[(c + 3) / 16], Nr[c + 3]);
         });
-        sfor<4 * (N / 4), N>(MK_LAMBDA(cc) {
+        sfor<16 * (N / 16) + 4 * ((N % 16) / 4), N>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
             G16::fmac<c % 16>(c % 2 ? acc1 : acc0, E.XB[c / 16], Nr[c]);
         });
@@ -180,7 +186,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // the scalars of this lane's series: (s0, s1, s2); s2 = NaN marks "not observed at this step"
         double s0, s1, s2;
         {
-            const double *e = sideb + js * SW + SW - 4;
+            const double *e = sideb + js * SS + SW - 4;
             if constexpr (PAIRS) {
                 const v2d sc = *reinterpret_cast<const v2d *>(e);
                 s0 = sc.x;
@@ -207,6 +213,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const double w = matvec(E);
             tapeb[xa_off + u * xa_str] = lane < n ? E.xa * w : w;
         };
+        // (Measured and dropped, round 4: pt vanishes on the coordinates observed at the step, so a column loop over the
+        // unobserved series and the factors only -- 13.6 of 36 columns at configs[3], x_c as wavefront-uniform LDS reads for
+        // ten entries at a time -- does 0.4x the multiply-adds; it ran the kernel at 71 ms against 56: a uniform LDS read per
+        // multiply-add costs more than the 22 broadcast multiply-adds it saves.)
         if (um && !MK_TUNE_SKIP(a, 64)) {
             load_ent((int)__builtin_ctz(um), ea);
             while (true) {
@@ -221,8 +231,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (unobs) {
             double q0 = 0.0, q1 = 0.0;
             double row[N], rowf[SW];
-            load_row<N>(tapeb + js * N, row);
-            load_row<SW>(sideb + js * SW, rowf);
+            load_row<N>(tapeb + js * XS, row);
+            load_row<SW>(sideb + js * SS, rowf);
 #pragma unroll
             for (int c = 0; c < N; ++c) {
                 if (c % 2 == 0) q0 += row[c];

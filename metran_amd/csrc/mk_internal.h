@@ -21,10 +21,15 @@
 
 namespace mk {
 
-// backward tape of the wide models (MK_OUT_TAPE; mk_split.hip writes it, mk_dk.hip reads it): per (model, step) an N x N
-// array of the series parts of the N entry vectors and an N x SW array of side rows [ factor part (K) | .. | s0 | s1 | s2 | 0 ]
-constexpr int tape_side_c(int K) { return (K + 5) & ~1; }
-constexpr int tape_stride_c(int N, int K) { return N * (N + tape_side_c(K)); }
+// backward tape of the wide models (MK_OUT_TAPE; mk_split.hip writes it, mk_dk.hip reads it).  Block of one (model, step):
+// N entries of XS doubles, entry j = [ series part of the vector (N) | side row: factor part (K), s0, s1, s2, 0 ] -- the series
+// part of entry j starts at j * tape_xs_c, its side row at tape_so_c + j * tape_ss_c.  (Round 4 also measured the split
+// form -- an N x N array of series parts followed by an N x SW array of side rows -- and kept the contiguous entries.)
+constexpr int tape_side_c(int K) { return K + 4; }
+constexpr int tape_xs_c(int N, int K) { return N + tape_side_c(K); }
+constexpr int tape_ss_c(int N, int K) { return tape_xs_c(N, K); }
+constexpr int tape_so_c(int N, int K) { return N; }
+constexpr int tape_stride_c(int N, int K) { return N * tape_xs_c(N, K); }
 
 struct FilterArgs {
     long B, R, T, warmup;

@@ -31,11 +31,9 @@
 // replaced by the observables y_j = x_j + sum_k g_jk x_{N+k}, in which the observation rows are unit vectors):
 //     observed series j     [ kt = T k (n) | v/f | 1/f | y_j | 0 ]   k = P z_j^T / f, the gain of that scalar update
 //     unobserved series u   [ pt = T Pf z_u^T (n) | z_u x_f | z_u Pf z_u^T | NaN | 0 ]   (end of the step)
-// Block of one (model, step) in HBM (mk_tape_stride = N (N + SW) doubles, SW = tape_side_c(K)): the series parts of the N
-// vectors as an N x N array (entry j = row j: one 8 N-byte run per store instruction and model), then an N x SW "side"
-// array [ factor part (K) | .. | s0 | s1 | s2 | 0 ] that is collected in LDS during the step and written once, as whole
-// rows, at its end (measured: the 16- and 32-byte pieces of the side part written straight from the update loop cost the
-// filter 10 ms of 56 at configs[3] -- 100 tiny store instructions a step).
+// Block of one (model, step) in HBM: mk_tape_stride = N (n + 4) doubles, the N entries one after the other (mk_internal.h);
+// the vector's series part is one 8 N-byte run per store instruction and model, the side row (factor part and scalars) is
+// written by lane j alone.
 // T k costs K multiply-adds a lane (kt_l = k_l + sum_k g_lk k_{N+k}: own loadings, replicated factor gains); the
 // unobserved entries are one extra pass per unobserved series and model (column pick, d = Pf z_u^T as in an update,
 // no rank-one update).  tests/dk_ref.py::filter_tape is the numpy restatement.
@@ -56,7 +54,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
     constexpr bool RECF = (OUT == 1 || OUT == 3);
     constexpr bool TAPE = (OUT == 4);
-    constexpr int SW = tape_side_c(K);           // side row of a tape entry: [ factor part (K) | .. | s0 | s1 | s2 | 0 ]
+    constexpr int SW = tape_side_c(K);           // side row of a tape entry: [ factor part (K) | s0 | s1 | s2 | 0 ]
+    constexpr int XS = tape_xs_c(N, K), SS = tape_ss_c(N, K), SO = tape_so_c(N, K); // tape block addressing (mk_internal.h)
     constexpr bool PAIRS = (K % 2 == 0 && N % 2 == 0); // 16-byte accesses to the factor part / the entry's scalars
     constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
     constexpr int TS = 16;                       // observation tile: time steps per LDS refill
@@ -72,7 +71,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // wave-private LDS, one slice per model of the wavefront
     constexpr int KP = (K + 1) & ~1;
-    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N + (TAPE ? N * KP + N * SW : 0))];
+    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N + (TAPE ? N * KP : 0))];
     double *phim = lds + h * NP;                                   // diag(Phi) [n]
     double *dbuf = lds + M * NP + h * 2 * NP;                      // d = P Z_j^T, two buffers
     double *gtab = lds + M * 3 * NP + h * GT;                      // loadings [N][K]
@@ -80,7 +79,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *qtab = lds + M * (3 * NP + GT + KK2) + h * KP;         // diag(Q) of the factor states
     double *otile = lds + M * (3 * NP + GT + KK2 + KP) + h * TS * N; // observations of TS steps
     [[maybe_unused]] double *fct = lds + M * (3 * NP + GT + KK2 + KP + TS * N) + h * N * KP; // TAPE: factor columns Pf[l][N+k]
-    [[maybe_unused]] double *side = lds + M * (3 * NP + GT + KK2 + KP + TS * N + N * KP) + h * N * SW; // TAPE: side rows of the step
 
     const double phi_l = a.phi[inst * n + jr];
     const double q_l = a.q[inst * n + jr];
@@ -115,7 +113,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *recP = (OUT == 1) ? a.Xp + inst * a.bs * RS : nullptr;
     double *recF = RECF ? a.F + inst * a.bs * RS : nullptr;
     const long rstep = a.ts * RS;
-    double *trec = TAPE ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step): [N][N] vectors, [N][SW] side rows
+    double *trec = TAPE ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step): N entries of XS doubles
     const long tstep = a.ts * a.rs;
     const int kl = l < K ? l : K - 1;            // factor state whose mean this lane writes
     const int fl16 = l < K * K ? l : K * K - 1;  // factor-block element this lane writes
@@ -335,9 +333,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                         for (int k = 0; k < K; ++k) kt = fma(gam[k], kf[k], kt);
                         if (okl && !MK_TUNE_SKIP(a, 1)) {
-                            trec[jl * N + jr] = kt;
+                            trec[jl * XS + jr] = kt;
                             if (l == jl) {
-                                double *sd = side + jl * SW;
+                                double *sd = trec + SO + jl * SS;
                                 if constexpr (PAIRS) {
 #pragma unroll
                                     for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{kf[k], kf[k + 1]};
@@ -504,10 +502,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         }
                         pt += pt2;
                         if (uok && !MK_TUNE_SKIP(a, 4)) {
-                            trec[ul * N + jr] = pt;
+                            trec[ul * XS + jr] = pt;
                             if (l == ul) {
                                 const double qnan = __builtin_nan("");
-                                double *sd = side + ul * SW;
+                                double *sd = trec + SO + ul * SS;
                                 if constexpr (PAIRS) {
 #pragma unroll
                                     for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{Q[k], Q[k + 1]};
@@ -523,19 +521,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                 }
                             }
                         }
-                    }
-                }
-                // the side rows of all N entries of this step (every series was either observed or not): whole rows, once
-                wave_lds_sync();
-                {
-                    const double *sr = side + jr * SW;
-                    double *ds = trec + N * N + jr * SW;
-                    if constexpr (PAIRS) {
-#pragma unroll
-                        for (int c = 0; c < SW; c += 2) *reinterpret_cast<v2d *>(ds + c) = *reinterpret_cast<const v2d *>(sr + c);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < SW; ++c) ds[c] = sr[c];
                     }
                 }
                 trec += tstep;

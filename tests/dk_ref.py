@@ -26,18 +26,16 @@ def entry_stride(N, K):
     return N + K + 4
 
 
-def side_width(K):
-    """Doubles per side row of the DEVICE tape block (mk_internal.h tape_side_c): [ factor part (K) | .. | s0 | s1 | s2 | 0 ]."""
-    return (K + 5) & ~1
-
-
 def unpack_block(block, N, K):
-    """Device layout of one (model, step) tape block -- [N][N] series parts, then [N][SW] side rows -- to entries [N, n+4]."""
-    SW = side_width(K)
+    """Device layout of one (model, step) tape block (mk_internal.h: entry j = series part at j*XS, side row at SO + j*SS,
+    side row = [ factor part (K) | s0 | s1 | s2 | 0 ]) to entries [N, n+4]."""
+    SW = K + 4
+    XS = SS = N + SW
+    SO = N
     block = np.asarray(block).reshape(-1)
-    X = block[:N * N].reshape(N, N)
-    S = block[N * N:N * N + N * SW].reshape(N, SW)
-    return np.concatenate([X, S[:, :K], S[:, SW - 4:]], axis=1)
+    X = np.stack([block[j * XS:j * XS + N] for j in range(N)])
+    S = np.stack([block[SO + j * SS:SO + j * SS + SW] for j in range(N)])
+    return np.concatenate([X, S], axis=1)
 
 
 def transform(loadings):
