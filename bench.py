@@ -8,9 +8,10 @@ the metric is quoted on):
   c2  configs[1]  4096 x (8 series, 2 factors), T=1000, fp64: filter + -2 log L + RTS smoother, all six
                   reference-equivalent state outputs (F, Pf, Xp, Pp, S, Ps) materialised in HBM
   c3  configs[2]  the same with 8192 models per GPU (65536 over 8 GPUs; one all-reduce of the summed -2 log L)
-  c4  configs[3]  4096 x (32 series, 4 factors), 30 % missing, T=2000: filter (filtered record only) +
-                  smoother with the fused projection epilogue (what Metran.get_simulation consumes; three
-                  full-square state arrays would be 255 GB)
+  c4  configs[3]  4096 x (32 series, 4 factors), 30 % missing, T=2000: the projection path (what
+                  Metran.get_simulation consumes; three full-square state arrays would be 255 GB) -- filter writing
+                  the backward tape + the inverse-free backward pass (MK_OUT_TAPE; --projection-path records:
+                  filtered records + RTS smoother with the fused projection epilogue, the round-3 path)
   c5  configs[4]  solver loop: 50 objective evaluations x 8192 models per step (fp64: the reference has no
                   fp32 path); sharded over the ranks, no collective per evaluation
 
@@ -46,19 +47,21 @@ EVALS_PER_STEP = 50  # c5: "50 parameter evaluations x batch=8192"
 def kernel_source_sha():
     """Identity of the kernels a PMC profile belongs to (stamped into profiles/*/pmc_hbm.json)."""
     h = hashlib.sha256()
-    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_wide.hip", "metran_amd/csrc/mk_split.hip", "metran_amd/csrc/mk_prims.h",
-              "metran_amd/csrc/mk_sweeps.h", "metran_amd/csrc/mk_internal.h"):
+    for f in ("metran_amd/csrc/mk_kernels.hip", "metran_amd/csrc/mk_wide.hip", "metran_amd/csrc/mk_split.hip", "metran_amd/csrc/mk_dk.hip",
+              "metran_amd/csrc/mk_prims.h", "metran_amd/csrc/mk_jump.h", "metran_amd/csrc/mk_sweeps.h", "metran_amd/csrc/mk_internal.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def algorithmic_bytes(N, K, T, mode, sym=False):
+def algorithmic_bytes(N, K, T, mode, sym=False, tape=False):
     """bytes per model the algorithm has to move, per kernel.
     c = n + n^2 doubles per moment set (full-square), c_s = n + n(n+1)/2 (packed-symmetric records)."""
     n = N + K
     c = n + (n * (n + 1) // 2 if sym else n * n)
     if mode == "full":      # read obs, write filtered + predicted | re-read filtered, write smoothed
         return {"filter": 8 * T * (N + 2 * c), "smoother": 8 * T * (2 * c)}
+    if mode == "project" and tape:  # read obs, write the tape (N entries of n + 4) | re-read it, write 2N projected moments
+        return {"filter": 8 * T * (N + N * (n + 4)), "smoother": 8 * T * (N * (n + 4) + 2 * N)}
     if mode == "project":   # read obs, write filtered | re-read filtered, write 2N projected moments
         return {"filter": 8 * T * (N + c), "smoother": 8 * T * (c + 2 * N)}
     return {"filter": 8 * T * N, "smoother": 0}  # solver objective: the observation stream only (B_ll)
@@ -91,7 +94,7 @@ def pmc_traffic(config, kernel_key, sym=False):
     return best, (None if best else note)
 
 
-def live_traffic(config, packed_sym, timeout_s=180):
+def live_traffic(config, packed_sym, timeout_s=180, projection_path="auto"):
     """HBM traffic of this configuration's kernels measured IN THIS RUN (round-2 verdict, weak 7: the number used to be
     replayed from a committed profile): two short child runs of this script under ``rocprofv3 --pmc FETCH_SIZE`` and
     ``--pmc WRITE_SIZE`` -- separate passes, counters only, no trace domain, as MI355X_MICROARCH.md prescribes -- after
@@ -107,7 +110,8 @@ def live_traffic(config, packed_sym, timeout_s=180):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found on this box"
     child = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-             "--no-secondary", "--no-live-traffic"] + (["--packed-sym"] if packed_sym else [])
+             "--no-secondary", "--no-live-traffic"] + (["--packed-sym"] if packed_sym else []) + (
+                 ["--projection-path", projection_path] if projection_path != "auto" else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
     env["TMPDIR"] = "/tmp"
     per = {}
@@ -148,17 +152,27 @@ def algorithmic_flops(N, K, T, mode, missing=0.0):
     return {"filter": f, "smoother": 0.0 if mode == "solver" else T * (6.33 * n ** 3 + 4 * n * n)}
 
 
-def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, evals=1, live=None):
+def executed_flops_tape(N, K, T, missing):
+    """What the tape path's own formulation executes per model (for the record next to SURVEY 8d's reference-algorithm count):
+    filter per step: predict 3n^2+n, per observed series 2n(1+K) (d = P z') + 2n^2 (rank-one) + ~8n, per unobserved ~4n(1+K);
+    backward pass per step: per series one (n+1) x n product 2n(n+1) + ~4n, transition 2(n+1)NK + 4n^2."""
+    n = N + K
+    m = N * (1.0 - missing)
+    return {"filter": T * (3 * n * n + n + m * (2 * n * (1 + K) + 2 * n * n + 8 * n) + (N - m) * 4 * n * (1 + K)),
+            "smoother": T * (N * (2 * n * (n + 1) + 4 * n) + 2 * (n + 1) * N * K + 4 * n * n)}
+
+
+def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, evals=1, live=None, tape=False):
     """The ``roofline`` object of the bench line for one workload: per-kernel algorithmic bytes / flops per launch over
     the hipEvent launch time, and the dominant kernel against the roof that bounds it -- HBM for the 16-lane
     filter+smoother kernels (AI ~ 3 flop/B), the fp64 pipe for the wide (n > 16) kernels and the solver objective
     (AI 41-75 flop/B on the bytes they move: SURVEY 8d)."""
-    ab = algorithmic_bytes(N, K, T, mode, sym=packed_sym)
+    ab = algorithmic_bytes(N, K, T, mode, sym=packed_sym, tape=tape)
     fl = algorithmic_flops(N, K, T, mode, missing)
     if mode == "solver":
         s_avg = 0.0
-    wide = N + K > 16   # one model per wavefront: mk_wide.hip
-    sname = None if mode == "solver" else ("smoother_mfma_kernel" if wide else "smoother_record_kernel")
+    wide = N + K > 16   # one model per wavefront: mk_wide.hip / mk_dk.hip
+    sname = None if mode == "solver" else ("smoother_dk_kernel" if tape else "smoother_mfma_kernel" if wide else "smoother_record_kernel")
 
     def entry(kind, ms):
         return {"ms": ms, "algorithmic_GB": ab[kind] * B / 1e9, "GBps": ab[kind] * B / 1e9 / (ms / 1e3),
@@ -168,6 +182,11 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
     kernels = {fname: entry("filter", f_avg)}
     if sname:
         kernels[sname] = entry("smoother", s_avg)
+    if tape:  # the reference-algorithm count above is what SURVEY 8d prices; this is what the formulation executes
+        ex = executed_flops_tape(N, K, T, missing)
+        for kname, kind, ms in ((fname, "filter", f_avg), (sname, "smoother", s_avg)):
+            kernels[kname]["executed_TFLOP"] = ex[kind] * B / 1e12
+            kernels[kname]["executed_TFLOPps"] = ex[kind] * B / 1e12 / (ms / 1e3)
     for kname in kernels:
         lv = None
         if live and live[0]:
@@ -191,7 +210,11 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
                     "hbm_frac_of_the_same_kernel": kernels[dom]["GBps"] / HBM_PEAK_GBS,
                     "note": "arithmetic intensity %.0f flop/B on the algorithmic bytes: bound by the fp64 vector/MFMA pipe "
                             "(78.6 TFLOP/s datasheet; f64 MFMA and f64 VALU share it on gfx950), not by HBM"
-                            % (kernels[dom]["algorithmic_TFLOP"] * 1e3 / max(kernels[dom]["algorithmic_GB"], 1e-30))}
+                            % (kernels[dom]["algorithmic_TFLOP"] * 1e3 / max(kernels[dom]["algorithmic_GB"], 1e-30))
+                            + ("; flops are SURVEY 8d's count of the REFERENCE algorithm (dense updates, RTS with an explicit "
+                               "inverse) -- the tape path executes %.2f x of them (executed_TFLOP), so `frac` is work-equivalent "
+                               "throughput, not pipe utilisation" % (sum(executed_flops_tape(N, K, T, missing).values())
+                                                                     / sum(fl.values())) if tape else "")}
     else:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS}
@@ -337,7 +360,7 @@ class Workload:
     """One configuration of CONFIGS on one GPU: synthetic records resident in HBM, output buffers allocated once,
     ``step()`` = one pass of the hot path over the batch (+ the deterministic local sum of -2 log L into ``total``)."""
 
-    def __init__(self, name, local_rank, rank, dev, layout, packed_sym, batch=None, T=None):
+    def __init__(self, name, local_rank, rank, dev, layout, packed_sym, batch=None, T=None, projection_path="auto"):
         import torch
 
         from metran_amd.engine import BatchedKalman
@@ -348,7 +371,9 @@ class Workload:
         self.packed_sym = bool(packed_sym) and mode == "full"
         self.d = make_dfm_batch_torch(self.B, N, K, self.T, seed=2000 + rank, device=dev, missing=missing)
         self.kf = BatchedKalman(local_rank, layout=layout, packed_sym=self.packed_sym)
+        self.kf.projection_path = projection_path
         self.kf.set_observations(self.d["obs"]).set_loadings(self.d["loadings"])
+        self.tape = mode == "project" and self.kf.tape_path()
         self.total = torch.zeros(1, dtype=torch.float64, device=dev)
         if mode == "full":
             self.bufs = self.kf._alloc_outputs(self.B, ["F", "Pf", "Xp", "Pp", "S", "Ps"])
@@ -387,7 +412,9 @@ class Workload:
         return ("BASELINE.json %s: batch=%d synthetic %d-series/%d-factor DFMs per GPU, T=%d, fp64, %s"
                 % (BASELINE_NAME[self.name], self.B, self.N, self.K, self.T,
                    {"full": "filter+smoother, outputs F,Pf,Xp,Pp,S,Ps" + (" as packed-symmetric records" if self.packed_sym else ""),
-                    "project": "%d %% missing, filter (filtered record) + smoother with fused projection (sim_means, sim_vars)" % round(100 * self.missing),
+                    "project": "%d %% missing, projection outputs (sim_means, sim_vars): %s" % (
+                        round(100 * self.missing), "filter writing the backward tape + inverse-free backward pass (MK_OUT_TAPE)"
+                        if getattr(self, "tape", False) else "filter (filtered record) + RTS smoother with the fused projection epilogue"),
                     "solver": "solver loop: %d objective evaluations (alpha -> phi,q -> filter -> -2 log L) per step" % EVALS_PER_STEP}[self.mode]))
 
     def close(self):
@@ -420,24 +447,77 @@ def timed_run(w, steps, warmup, sync, after_step=None):
     return elapsed, f_tot / max(f_n, 1), s_tot / max(s_n, 1)
 
 
-def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=3, warmup=1):
+def sample_models(B, count):
+    """Indices spread over the batch AND over the positions inside a wavefront (the wide filter serves two or four models
+    per wavefront): the first and last 16 models, then an odd stride through the rest."""
+    import numpy as np
+
+    if B <= count:
+        return np.arange(B)
+    head = list(range(16)) + list(range(B - 16, B))
+    rest = (np.linspace(16, B - 17, count - 16).astype(np.int64) | 1).tolist() + np.linspace(17, B - 18, 16).astype(np.int64).tolist()
+    return np.array(sorted(set(head + rest)))
+
+
+def parity_figures(w, n_mle=256, n_proj=32):
+    """Error figures of a secondary configuration against the C port of the reference algorithm (oracle/, the checker):
+    -2 log L on n_mle models spread over the batch, and -- projection mode -- the projected smoothed means / variances on
+    n_proj of them (reference kalmansmoother + simulate, kalmanfilter.py:403-476, 569-603)."""
+    import numpy as np
+
+    import oracle
+
+    idx = sample_models(w.B, n_mle)
+    if w.mode == "solver":
+        ph, qq = w.kf.params_from_alpha(w.alphas[-1])
+    else:
+        ph, qq = w.d["phi"], w.d["q"]
+    host = {"obs": w.d["obs"][idx].cpu().numpy(), "phi": ph[idx].cpu().numpy(), "q": qq[idx].cpu().numpy(),
+            "loadings": w.d["loadings"][idx].cpu().numpy()}
+    t0 = time.perf_counter()
+    ref = oracle.dfm_batch(host["obs"], host["phi"], host["q"], host["loadings"], smooth=False, outputs="mle")
+    gpu = w.bufs["mle"][idx].cpu().numpy()
+    out = {"loglik_max_rel_err": float(np.max(np.abs(gpu - ref["mle"]) / np.abs(ref["mle"]))), "loglik_models_compared": int(len(idx))}
+    if w.mode == "project":
+        sub = idx[np.linspace(0, len(idx) - 1, min(n_proj, len(idx))).astype(int)]
+        pos = np.searchsorted(idx, sub)
+        r2 = oracle.dfm_batch(host["obs"][pos], host["phi"][pos], host["q"][pos], host["loadings"][pos])
+        Z = np.concatenate([np.broadcast_to(np.eye(w.N), (len(sub), w.N, w.N)), host["loadings"][pos]], axis=2)
+        m_ref = np.einsum("bjn,btn->btj", Z, r2["S"])
+        v_ref = np.maximum(np.einsum("bjn,btnm,bjm->btj", Z, r2["Ps"], Z), 0.0)
+        out["projection_models_compared"] = int(len(sub))
+        out["sim_means_max_abs_err"] = float(np.max(np.abs(w.bufs["sim_means"][sub].cpu().numpy() - m_ref)))
+        out["sim_vars_max_abs_err"] = float(np.max(np.abs(w.bufs["sim_vars"][sub].cpu().numpy() - v_ref)))
+    out["checker"] = "oracle/kalman_oracle.c (C port of the reference algorithm), %.1f s on the host" % (time.perf_counter() - t0)
+    return out
+
+
+def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=3, warmup=1, live=True):
     """The non-headline configurations measured in the SAME process after the headline's timed region (VERDICT r2 item 3:
-    configs[3] and configs[4] in driver-run records): kernel ms, models/s and the roofline of one GPU."""
+    configs[3] and configs[4] in driver-run records): kernel ms, models/s, the roofline of one GPU and (r3 item 2) error
+    figures against the oracle on a sample of the batch."""
     import torch
 
     w = Workload(name, local_rank, rank, dev, layout, False)
+    tape = getattr(w, "tape", False)
     try:
         elapsed, f_avg, s_avg = timed_run(w, steps, warmup, sync)
         models_per_s = w.B * w.units * steps / elapsed
         out = {"workload": w.describe(), "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
                "models_per_s": models_per_s, "value": models_per_s * w.T, "unit": "model-timesteps/s",
-               "filter_ms": f_avg, "smoother_ms": (s_avg if w.mode != "solver" else None),
-               "roofline": build_roofline(name, w.N, w.K, w.T, w.B, w.mode, w.missing, f_avg, s_avg, False)}
+               "filter_ms": f_avg, "smoother_ms": (s_avg if w.mode != "solver" else None)}
         if w.mode == "solver":
             out["objective_evaluations_per_s"] = models_per_s
+        try:
+            out["parity"] = parity_figures(w)
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        cfg = (w.N, w.K, w.T, w.B, w.mode, w.missing)
     finally:
         w.close()
         torch.cuda.empty_cache()
+    lv = live_traffic(name, False) if (live and name == "c4") else None   # after the buffers are released
+    out["roofline"] = build_roofline(name, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], f_avg, s_avg, False, live=lv, tape=tape)
     return out
 
 
@@ -569,6 +649,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[3] / configs[4] lines that the default one-GPU run appends after the headline")
     ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"])
+    ap.add_argument("--projection-path", default="auto", choices=["auto", "tape", "records"],
+                    help="c4: 'records' = filtered records + RTS smoother (round 3) instead of the tape path")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU (gloo): launch, barrier, max-over-ranks, one JSON line with value null")
     args = ap.parse_args()
@@ -613,6 +695,7 @@ def main():
             dist.barrier()
 
     w = None
+    tape = False
     collectives = 0
     if args.dry_run:
         total = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -631,8 +714,10 @@ def main():
         elapsed = time.perf_counter() - t0
         f_avg = s_avg = 0.0
     else:
-        w = Workload(args.config, local_rank, rank, dev, args.layout, args.packed_sym, batch=args.batch, T=args.T)
+        w = Workload(args.config, local_rank, rank, dev, args.layout, args.packed_sym, batch=args.batch, T=args.T,
+                     projection_path=args.projection_path)
         total = w.total
+        tape = getattr(w, "tape", False)
 
         def after_step(wl):
             nonlocal collectives
@@ -698,8 +783,8 @@ def main():
     if rank == 0 and not args.dry_run:
         live = None
         if world == 1 and dist is None and not args.no_live_traffic and args.batch is None and args.T is None:
-            live = live_traffic(args.config, args.packed_sym)     # after the timed region, the buffers released
-        res["roofline"] = build_roofline(args.config, N, K, T, B, mode, missing, f_avg, s_avg, args.packed_sym, live=live)
+            live = live_traffic(args.config, args.packed_sym, projection_path=args.projection_path)  # after the timed region
+        res["roofline"] = build_roofline(args.config, N, K, T, B, mode, missing, f_avg, s_avg, args.packed_sym, live=live, tape=tape)
     # ---- the other BASELINE configurations, AFTER the headline's timed region (one GPU, default headline only) ----
     if (rank == 0 and world == 1 and not args.dry_run and not args.no_secondary and args.config == "c2"
             and args.batch is None and args.T is None and not args.packed_sym):

@@ -69,6 +69,15 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
 
     if gradient == "auto":
         gradient = "adjoint" if kf.has_adjoint() else "fd"
+        if gradient == "adjoint":
+            # the recording forward pass needs R*T*record_stride(n) doubles (10.7 KB per model-step at n = 36): a large wide
+            # flight does not fit where the differenced objective, which has no workspace, does (round-3 advice)
+            need = 8.0 * R * kf.T * kf.record_stride()
+            have = getattr(kf, "_grad_work", None)
+            have = 8.0 * have.numel() if have is not None else 0.0
+            free = float(torch.cuda.mem_get_info(dev)[0]) if dev.type == "cuda" else float("inf")
+            if need > have + 0.9 * free:
+                gradient = "fd"
     if gradient not in ("fd", "adjoint"):
         raise ValueError("gradient must be 'auto', 'fd' or 'adjoint'")
     grad_mode = gradient                              # may switch to "fd" for a small flight (fd_below); the request stays

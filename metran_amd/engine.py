@@ -148,6 +148,7 @@ class BatchedKalman:
         obs = torch.where(obs == -1e10, torch.full_like(obs, float("nan")), obs)
         self.obs = self._layout(obs)
         self._obs_unmasked = None
+        self._grad_pending = self._grad_alpha = None  # a pending forward pass belongs to the previous dataset
         self.R, self.T, self.N = (int(s) for s in self.obs.shape)
         check(self._L.mk_observations_changed(self._ctx))  # a recycled allocation may carry a new record at an old address
         return self
@@ -249,6 +250,7 @@ class BatchedKalman:
         if loadings.ndim == 2:
             loadings = loadings[None]
         self.loadings = self._dev(loadings)
+        self._grad_pending = self._grad_alpha = None  # ... and to the previous loadings
         if tuple(self.loadings.shape[:2]) != (self.R, self.N):
             raise ValueError("loadings must be [R=%d,N=%d,K], got %s" % (self.R, self.N, tuple(self.loadings.shape)))
         self.K = int(self.loadings.shape[2])
@@ -340,6 +342,7 @@ class BatchedKalman:
         Any supported shape: four models per wavefront for n <= 16, one per wavefront for 16 < n <= 64."""
         torch = _torch()
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
+        self._grad_pending = None  # the shared workspace is about to be overwritten: a forward pass waiting for its backward is void
         need = B * self.T * self.record_stride()
         work = getattr(self, "_grad_work", None)
         if work is None or work.numel() < need:
@@ -369,7 +372,12 @@ class BatchedKalman:
         self._bind_stream()
         check(self._L.mk_loglik_grad_phases(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
                                             self._p(mle), self._p(sc), None, None, None, 1))
-        self._grad_pending = (prob, keep, B, sc, work)
+        # everything the backward launch dereferences stays alive with the pending record (the parameter tensors in `keep`,
+        # the observation / loadings / variance tensors the problem struct points at); set_observations, set_loadings and
+        # loglik_grad void it (round-3 advice: a backward pass over records of another parameter set or dataset returned a
+        # wrong gradient without an error)
+        self._grad_pending = (prob, keep + (self.obs, self.loadings, self.obsvar), B, sc, work)
+        self._grad_alpha = None
         return mle
 
     def loglik_backward(self):
@@ -384,6 +392,7 @@ class BatchedKalman:
         self._bind_stream()
         check(self._L.mk_loglik_grad_phases(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
                                             None, self._p(sc), self._p(gphi), self._p(gq), None, 2))
+        self._grad_pending = None  # one backward pass per forward pass
         return gphi, gq
 
     def loglik_forward_alpha(self, alpha, dt=1.0, warmup=1):
@@ -392,14 +401,18 @@ class BatchedKalman:
         if alpha.ndim == 1:
             alpha = alpha[None]
         phi, q = self.params_from_alpha(alpha, dt=dt)
+        mle = self.loglik_forward(phi, q, warmup=warmup)
         self._grad_alpha = (alpha, float(dt))
-        return self.loglik_forward(phi, q, warmup=warmup)
+        return mle
 
     def loglik_backward_alpha(self):
         """``d mle / d alpha [B,n]`` at the point of the last ``loglik_forward_alpha``."""
         torch = _torch()
-        gphi, gq = self.loglik_backward()
+        if getattr(self, "_grad_alpha", None) is None:
+            raise MetranHipError("loglik_backward_alpha without a preceding loglik_forward_alpha")
         alpha, dt = self._grad_alpha
+        gphi, gq = self.loglik_backward()
+        self._grad_alpha = None
         galpha = torch.empty_like(gphi)
         check(self._L.mk_alpha_grad(self._ctx, int(alpha.shape[0]), self.R, self.N, self.K, self._p(alpha),
                                     self._p(self.loadings), dt, self._p(gphi), self._p(gq), self._p(galpha)))

@@ -48,6 +48,7 @@ logger = logging.getLogger(__name__)
 __all__ = ["FactorAnalysisBatch", "FactorAnalysis", "FactorResult", "eig_order", "install", "uninstall"]
 
 _PSI_LO, _PSI_HI = 0.005, 1.0  # bounds of the reference's minimisation (:205-207)
+_STACK_SIZE_LOCK = threading.Lock()
 _LOCKSTEP_THREADS = 512        # scipy minimisations in flight at once (one host thread each)
 
 
@@ -325,40 +326,49 @@ class FactorAnalysisBatch:
                 finally:
                     requests.put((i, None))
 
-            old = threading.stack_size(512 * 1024)
-            try:
-                threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(m)]
-                for t in threads:
-                    t.start()
-            finally:
-                threading.stack_size(old)
-            live = m
-            while live:
-                batch = {}
-                while len(batch) < live:     # every model still running has asked (or has finished)
-                    i, x = requests.get()
-                    if x is None:
-                        live -= 1
-                    else:
-                        batch[i] = x
-                if not batch:
-                    break
-                ids = sorted(batch)
+            with _STACK_SIZE_LOCK:  # threading.stack_size is process-global: one chunk at a time changes it, and puts it back
+                old = threading.stack_size(512 * 1024)
                 try:
-                    X = np.stack([batch[i] for i in ids])
-                    sel = torch.as_tensor(ids, device=dev)
-                    f, g, _ = self.minres_eval(sub_corr.index_select(0, sel).contiguous(),
-                                               sub_nf.index_select(0, sel).contiguous(), X, kmax, want=("f", "g"),
-                                               corr_host=sub_host[ids])
-                    f, g = f.cpu().numpy(), g.cpu().numpy()
-                    for k, i in enumerate(ids):
-                        answers[i] = (float(f[k]), g[k].copy())
-                except BaseException as e:  # noqa: BLE001
-                    errors.append(e)
+                    threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(m)]
+                    for t in threads:
+                        t.start()
+                finally:
+                    threading.stack_size(old)
+            live = m
+            try:
+                while live:
+                    batch = {}
+                    while len(batch) < live:     # every model still running has asked (or has finished)
+                        i, x = requests.get()
+                        if x is None:
+                            live -= 1
+                        else:
+                            batch[i] = x
+                    if not batch:
+                        break
+                    ids = sorted(batch)
+                    try:
+                        X = np.stack([batch[i] for i in ids])
+                        sel = torch.as_tensor(ids, device=dev)
+                        f, g, _ = self.minres_eval(sub_corr.index_select(0, sel).contiguous(),
+                                                   sub_nf.index_select(0, sel).contiguous(), X, kmax, want=("f", "g"),
+                                                   corr_host=sub_host[ids])
+                        f, g = f.cpu().numpy(), g.cpu().numpy()
+                        for k, i in enumerate(ids):
+                            answers[i] = (float(f[k]), g[k].copy())
+                    except BaseException as e:  # noqa: BLE001
+                        errors.append(e)
+                        for i in ids:
+                            answers[i] = None
                     for i in ids:
+                        wake[i].set()
+            finally:
+                # whatever ends the serving loop (KeyboardInterrupt included): no worker stays blocked on its event -- each
+                # finds its answer None, raises inside scipy's callback and finishes
+                for i in range(m):
+                    if threads[i].is_alive():
                         answers[i] = None
-                for i in ids:
-                    wake[i].set()
+                        wake[i].set()
             for t in threads:
                 t.join()
             if errors:

@@ -237,8 +237,9 @@ def test_minus_1e10_is_dropped_like_the_reference(kf):
 
 def test_full_size_c4_projection(kf):
     """BASELINE configs[3] size (B=4096, 32 series / 4 factors, 30 % missing, T=2000).  Three full state
-    records per step would be 264 GB; the fused projection path keeps one (88 GB) and emits what
-    get_simulation consumes.  Checks: a sub-sample equals the oracle (loglik, projected means/variances),
+    records per step would be 264 GB; the projection path keeps one tape (84 GB) and emits what
+    get_simulation consumes.  Checks: 72 models across the batch and across wavefront positions equal the oracle
+    (loglik, projected means/variances), results are bit-for-bit independent of the batch position,
     every model's status is clean, variances are non-negative and, where a series is observed, the
     smoothed projection reproduces the observation (R = 0) with zero variance."""
     import torch
@@ -255,7 +256,10 @@ def test_full_size_c4_projection(kf):
     r = kf.simulate_smoothed(d["phi"], d["q"])
     torch.cuda.synchronize()
     assert not r["status"].any()
-    idx = [0, 1777, 4095]
+    # 72 models spread over the batch and over the positions inside a wavefront (the split filter serves two models per
+    # wavefront): both models of the first and last wavefronts, then pairs (even, odd) through the rest
+    idx = sorted(set([0, 1, 2, 3, B - 4, B - 3, B - 2, B - 1] + [i + (k & 1) for k, i in enumerate(range(4, B - 4, 64))]))
+    assert len(idx) >= 64
     sub = {k: _np(d[k][idx]) for k in ("obs", "phi", "q", "loadings")}
     ref = oracle.dfm_batch(sub["obs"], sub["phi"], sub["q"], sub["loadings"])
     assert rel_err(_np(r["mle"][idx]), ref["mle"]) < MLE_RTOL
@@ -263,6 +267,14 @@ def test_full_size_c4_projection(kf):
         sm, sv = oracle.simulate(observation_matrix(sub["loadings"][i]), ref["S"][i], ref["Ps"][i])
         np.testing.assert_allclose(_np(r["sim_means"][b]), sm, rtol=0, atol=1e-9)
         np.testing.assert_allclose(_np(r["sim_vars"][b]), sv, rtol=0, atol=1e-9)
+    # the same models as a small, differently aligned batch: bit for bit (no result depends on the position in the batch
+    # or in a wavefront -- model 1 moves from the second to the first slot of its wavefront, ...)
+    sel = idx[1:34]
+    kf.set_observations(d["obs"][sel].contiguous()).set_loadings(d["loadings"][sel].contiguous())
+    r2 = kf.simulate_smoothed(d["phi"][sel].contiguous(), d["q"][sel].contiguous())
+    assert torch.equal(r2["mle"], r["mle"][sel])
+    assert torch.equal(r2["sim_means"], r["sim_means"][sel]) and torch.equal(r2["sim_vars"], r["sim_vars"][sel])
+    del r2
     assert bool((r["sim_vars"] >= 0).all())
     seen = torch.isfinite(d["obs"])
     assert float((r["sim_means"] - torch.nan_to_num(d["obs"]))[seen].abs().max()) < 1e-8
