@@ -569,12 +569,16 @@ def measure_transfers(dev, B, T, N, K, ms_per_step):
     return out
 
 
-def secondary_factor_analysis(dev, R=4096, T=1000, N=8, K=2, reps=3):
+def secondary_factor_analysis(dev, R=4096, T=1000, N=8, K=2, reps=3, scipy_subset=0):
     """SURVEY section 8 row f4 in the driver's record: ``FactorAnalysisBatch.solve`` on R synthetic block-structure models
     (observations generated on the device, 10 % missing): correlations -> eigenvalues / MAP test -> minres -> loadings ->
-    varimax, best of ``reps`` calls after one warm-up call."""
+    varimax, best of ``reps`` calls after one warm-up call, with the host's share split out (the batched ``numpy.linalg.eig``
+    that supplies LAPACK's pair ORDER, factoranalysis.py:396-398; the lock-step scipy L-BFGS-B of the models that may leave
+    their start vector, :173-217).  ``scipy_subset`` > 0: additionally the first that many models with ``always_scipy=True``
+    (the reference's minimisation for EVERY model, as the one-model mirror class runs it)."""
     import torch
 
+    from metran_amd import factoranalysis as fa_mod
     from metran_amd.factoranalysis import FactorAnalysisBatch
 
     g = torch.Generator(device=dev).manual_seed(100 + N)
@@ -587,19 +591,66 @@ def secondary_factor_analysis(dev, R=4096, T=1000, N=8, K=2, reps=3):
     y[torch.rand(R, T, N, device=dev, generator=g) < 0.1] = float("nan")
     del f
     fb = FactorAnalysisBatch()
-    fb.solve(obs=y)
-    torch.cuda.synchronize()
-    best = None
-    for _ in range(reps):
+    host = {"eig_order_s": 0.0, "eig_order_calls": 0, "lockstep_s": 0.0, "lockstep_models": 0}
+    orig_eig, orig_lock = fa_mod.eig_order, FactorAnalysisBatch._lockstep_minres
+
+    def timed_eig(*a, **k):
         t0 = time.perf_counter()
-        r = fb.solve(obs=y)
+        r = orig_eig(*a, **k)
+        host["eig_order_s"] += time.perf_counter() - t0
+        host["eig_order_calls"] += 1
+        return r
+
+    def timed_lock(self, *a, **k):
+        t0 = time.perf_counter()
+        e0 = host["eig_order_s"]
+        r = orig_lock(self, *a, **k)
+        host["lockstep_s"] += (time.perf_counter() - t0) - (host["eig_order_s"] - e0)   # eig calls inside are booked as eig
+        host["lockstep_models"] += int(len(r))
+        return r
+
+    fa_mod.eig_order = timed_eig
+    FactorAnalysisBatch._lockstep_minres = timed_lock
+    try:
+        fb.solve(obs=y)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-    hist = torch.bincount(r.nfactors.to(torch.int64).clamp(min=0)).tolist()
-    return {"workload": "FactorAnalysisBatch.solve: %d x (%d series, %d true factors), T=%d, 10 %% missing, fp64" % (R, N, K, T),
-            "seconds": best, "models_per_s": R / best, "models_moved_by_lbfgsb": int((~r.stalled).sum().item()),
-            "nfactors_histogram": {str(i): c for i, c in enumerate(hist) if c}}
+        best = None
+        for _ in range(reps):
+            for k in host:
+                host[k] = 0 if k.endswith(("calls", "models")) else 0.0
+            t0 = time.perf_counter()
+            r = fb.solve(obs=y)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, dict(host), r)
+        dt, h, r = best
+        hist = torch.bincount(r.nfactors.to(torch.int64).clamp(min=0)).tolist()
+        out = {"workload": "FactorAnalysisBatch.solve: %d x (%d series, %d true factors), T=%d, 10 %% missing, fp64" % (R, N, K, T),
+               "seconds": dt, "models_per_s": R / dt, "models_moved_by_lbfgsb": int((~r.stalled).sum().item()),
+               "nfactors_histogram": {str(i): c for i, c in enumerate(hist) if c},
+               "split_s": {"host_eig_order": h["eig_order_s"], "host_eig_order_calls": h["eig_order_calls"],
+                           "lockstep_scipy": h["lockstep_s"], "lockstep_models": h["lockstep_models"],
+                           "device_kernels_and_transfers": dt - h["eig_order_s"] - h["lockstep_s"]}}
+        if scipy_subset:
+            m = min(scipy_subset, R)
+            for k in host:
+                host[k] = 0 if k.endswith(("calls", "models")) else 0.0
+            t0 = time.perf_counter()
+            r2 = fb.solve(obs=y[:m], always_scipy=True)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t0
+            out["always_scipy_subset"] = {"models": m, "seconds": d2, "models_per_s": m / d2,
+                                          "host_eig_order_s": host["eig_order_s"], "host_eig_order_calls": host["eig_order_calls"],
+                                          "lockstep_scipy_s": host["lockstep_s"],
+                                          "models_moved_by_lbfgsb": int((~r2.stalled).sum().item()),
+                                          "max_abs_loading_difference_vs_stall_checked_path":
+                                              float((r2.factors - r.factors[:m, :, :r2.factors.shape[2]]).abs().max())
+                                              if r2.factors.shape[2] <= r.factors.shape[2] else None}
+        return out
+    finally:
+        fa_mod.eig_order = orig_eig
+        FactorAnalysisBatch._lockstep_minres = orig_lock
 
 
 def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200):
@@ -629,6 +680,66 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
     finally:
         kf.close()
         torch.cuda.empty_cache()
+
+
+def secondary_dropin():
+    """BASELINE configs[0] / north_star's "drop-in ... with the CPU path timed in the same run": the UNMODIFIED reference class
+    (oracle/_ref, the staged verbatim copy, through the pastas stub) on examples/data (5 series, 1 factor, T = 6255):
+    ``Metran.solve()`` + ``get_simulation()`` (/root/reference/metran/metran.py:991-1042, 831-883) once with the reference's own
+    numpy engine on the host and once with ``metran_amd.kalmanfilter.install`` (every ``get_mle`` = one B = 1 launch of the HIP
+    engine), then plug point A: ``solve(solver=HipSolve)`` (objective + forward differences in one launch) and
+    ``HipSolveAdjoint``.  Wall seconds, nfev and the objective of each."""
+    import glob
+
+    import pandas as pd
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _refshim
+
+    if not _refshim.reference_available():
+        return {"error": "oracle/_ref not staged (oracle/make_ref.sh where the reference is mounted)"}
+    metran = _refshim.install()
+    import metran_amd.kalmanfilter as hip
+    from metran_amd.solver import HipSolve, HipSolveAdjoint
+
+    files = sorted(glob.glob(os.path.join(_refshim.REFERENCE_ROOT, "examples", "data", "*_res.csv")))
+    series = []
+    for f in files:
+        x = pd.read_csv(f, header=0, index_col=0, parse_dates=True).squeeze()
+        x.name = os.path.basename(f).split("_")[0]
+        series.append(x)
+
+    def run(solver=None):
+        mt = metran.Metran(series, name="B21B0214")
+        t0 = time.perf_counter()
+        if solver is None:
+            mt.solve(report=False)
+        else:
+            mt.solve(solver=solver, report=False)
+        t1 = time.perf_counter()
+        sim = mt.get_simulation(series[-1].name)
+        t2 = time.perf_counter()
+        return {"solve_s": t1 - t0, "get_simulation_s": t2 - t1, "nfev": int(mt.fit.nfev), "obj": float(mt.fit.obj_func),
+                "simulation_rows": int(sim.shape[0])}
+
+    out = {"workload": "BASELINE.json configs[0]: examples/data (5 series, 1 factor, T=6255), the reference's Metran class, "
+                       "solve() + get_simulation(); reference objective at the optimum 2332.3270694, nfev 77"}
+    out["reference_engine_on_host"] = dict(run(), engine="seqkalmanfilter_np + Python kalmansmoother (numba %s), one core"
+                                           % ("importable" if "numba" in sys.modules else "not importable"))
+    hip.install(metran)
+    try:
+        run(HipSolveAdjoint)   # warm-up outside the timings: context creation, kernel load, first upload
+        out["hip_engine_scipy_solver"] = dict(run(), engine="metran_amd.kalmanfilter.install(metran): seqkalmanfilter_hip / "
+                                              "kalmansmoother_hip, scipy L-BFGS-B unchanged (77 x get_mle = 77 launches)")
+        out["hip_solver_fd"] = dict(run(HipSolve), engine="Metran.solve(solver=HipSolve): objective + P forward differences per launch")
+        out["hip_solver_adjoint"] = dict(run(HipSolveAdjoint), engine="Metran.solve(solver=HipSolveAdjoint): adjoint gradient")
+    finally:
+        hip.uninstall(metran)
+    ref = out["reference_engine_on_host"]
+    for k in ("hip_engine_scipy_solver", "hip_solver_fd", "hip_solver_adjoint"):
+        out[k]["obj_minus_reference"] = out[k]["obj"] - ref["obj"]
+        out[k]["solve_speedup_vs_reference_engine"] = ref["solve_s"] / out[k]["solve_s"]
+    return out
 
 
 def main():
@@ -729,9 +840,27 @@ def main():
         collectives -= warmup if (dist is not None and mode != "solver") else 0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nranks = torch.ones(1, dtype=torch.float64, device=dev)
+    per_rank_ms = ar_ms = None
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(nranks)  # ranks that actually took part in the collective
+        # so that a 1 -> N run explains itself: every rank's own kernel times, and -- measured AFTER the
+        # timed region, never inside it -- the wall time of the 8-byte all-reduce alone
+        km = torch.tensor([f_avg, s_avg, elapsed], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(gathered, km)
+        per_rank_ms = [{"rank": i, "filter_ms": float(g[0]), "smoother_ms": float(g[1]), "elapsed_s": float(g[2])}
+                       for i, g in enumerate(gathered)]
+        probe = torch.zeros(1, dtype=torch.float64, device=dev)
+        for _ in range(5):
+            dist.all_reduce(probe)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(probe)
+        if not args.dry_run:
+            torch.cuda.synchronize()
+        ar_ms = 1e3 * (time.perf_counter() - t0) / 50
     elapsed = float(el.item())
 
     if rank == 0:
@@ -759,7 +888,10 @@ def main():
             # how rccl_ranks was obtained: the process-group backend whose all_reduce summed one 1.0 per rank
             # ("nccl" = RCCL on ROCm), or None when no process group exists (plain `python bench.py`, one GPU)
             "collective": {"backend": backend, "allreduces_in_timed_region": collectives,
-                           "what": "summed -2 log L, 8 bytes, once per step" if backend else "none (no process group)"},
+                           "what": "summed -2 log L, 8 bytes, once per step" if backend else "none (no process group)",
+                           "ms_per_allreduce": ar_ms, "ms_per_allreduce_note": (
+                               "50 back-to-back 8-byte all-reduces after the timed region, rank 0's wall clock" if backend else None),
+                           "per_rank": per_rank_ms},
         }
         if args.dry_run:
             res["dry_run"] = "plumbing only (gloo, no kernels): not a measurement"
@@ -795,7 +927,9 @@ def main():
             except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure here
                 res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
         for name, fn in (("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
-                         ("f1_calibration", lambda: secondary_calibration(local_rank, dev))):
+                         ("f4_factor_analysis_32x4", lambda: secondary_factor_analysis(dev, N=32, K=4, reps=2, scipy_subset=256)),
+                         ("f1_calibration", lambda: secondary_calibration(local_rank, dev)),
+                         ("c1_dropin", secondary_dropin)):
             try:
                 res["secondary"][name] = fn()
             except Exception as e:  # noqa: BLE001

@@ -161,7 +161,43 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         # accepted trial needs no second launch for its gradient
         speculate = grad_mode == "fd" and (n + 1) * R <= 4096
         g_acc = g
+        # ... and SEVERAL step lengths of every searching model ride in one launch while they fit (S_tr x (n+1) x R instances
+        # <= 4096): with models in lock-step some model needs a short step in most iterations, and on a small flight every
+        # back-tracking round is a latency-bound launch of its own (round 3: 4.6 launches per iteration over the tail).  The
+        # largest of the simultaneous trials that passes the Armijo test is taken.
+        S_tr = max(1, min(4, 4096 // ((n + 1) * R))) if speculate else 1
+        ratios = torch.tensor([1.0, 0.35, 0.12, 0.04][:S_tr], **f64)
         for _ in range(max_backtracks):
+            if S_tr > 1:
+                steps_s = step[None, :] * ratios[:, None]                                   # [S,R]
+                xt_s = torch.maximum(x[None] + steps_s[:, :, None] * d[None], lo[None])     # [S,R,n]
+                xe_s = torch.where(searching[None, :, None], xt_s, x_new[None])
+                pts = torch.cat([xe_s[:, None], xe_s[:, None] + eye[None, :, None, :]], 1)  # [S, n+1, R, n]: instance ((s, j), r)
+                phi_t, q_t = kf.params_from_alpha(pts.reshape(S_tr * (n + 1) * R, n), dt=dt)
+                fv = kf.loglik(phi_t, q_t, warmup=warmup).reshape(S_tr, n + 1, R)
+                nfev += S_tr * (n + 1) * R
+                launches += 1
+                ft_s = fv[:, 0]
+                gd_s = (pg[None] * (xt_s - x[None])).sum(2)
+                ok_s = searching[None] & (ft_s <= f[None] + 1e-4 * gd_s) & torch.isfinite(ft_s)
+                ok = ok_s.any(0)
+                first = torch.argmax(ok_s.to(torch.int8), 0)                                # largest passing step of each model
+                sel = first[None, :, None].expand(1, R, n)
+                xt = torch.gather(xt_s, 0, sel)[0]
+                ft = torch.gather(ft_s, 0, first[None])[0]
+                gt = ((torch.gather(fv[:, 1:], 0, first[None, None, :].expand(1, n, R))[0] - ft[None]) / eps).transpose(0, 1)
+                x_new = torch.where(ok[:, None], xt, x_new)
+                f_new = torch.where(ok, ft, f_new)
+                g_acc = torch.where(ok[:, None], gt, g_acc)
+                searching &= ~ok
+                if not bool(searching.any()):
+                    break
+                # nobody among a model's trials passed: go on below its shortest one
+                ft_l, gd_l = ft_s[-1], gd_s[-1]
+                curv = ft_l - f - gd_l
+                theta = torch.where(torch.isfinite(ft_l) & (curv > 0), -gd_l / (2.0 * curv), torch.full_like(ft_l, 0.1))
+                step = torch.where(searching, step * float(ratios[-1]) * theta.clamp(0.1, 0.5), step)
+                continue
             xt = torch.maximum(x + step[:, None] * d, lo)
             xe = torch.where(searching[:, None], xt, x_new)          # settled models: at the point they settled on
             if speculate:

@@ -76,3 +76,31 @@ def test_secondary_factor_analysis_and_calibration(line):
     assert "error" not in f1, f1
     assert f1["converged_frac"] > 0.95 and f1["frac_at_or_below_true_parameter_objective"] > 0.95, f1
     assert f1["models_per_s"] >= 4000.0, f1
+
+
+def test_secondary_dropin_configs0(line):
+    """BASELINE configs[0] in the driver's line: the unmodified reference class on examples/data, solve()
+    + get_simulation() with the reference's own engine on the host and with the HIP engine installed, plus plug point A."""
+    c1 = line["secondary"]["c1_dropin"]
+    assert "error" not in c1, c1
+    ref = c1["reference_engine_on_host"]
+    assert abs(ref["obj"] - 2332.3270694) < 1e-5 and ref["nfev"] == 77
+    for k in ("hip_engine_scipy_solver", "hip_solver_fd", "hip_solver_adjoint"):
+        assert abs(c1[k]["obj"] - 2332.3270694) < 1e-5, (k, c1[k])
+        assert c1[k]["solve_s"] > 0 and c1[k]["get_simulation_s"] > 0 and c1[k]["simulation_rows"] == ref["simulation_rows"]
+    assert abs(c1["hip_engine_scipy_solver"]["nfev"] - 77) <= 14
+    assert c1["hip_solver_adjoint"]["nfev"] < 40
+
+
+def test_secondary_factor_analysis_wide(line):
+    """Row f4 where it is hard: 4096 x 32 series with four true factors -- every model takes the
+    multi-factor path (varimax, the host eig order), and the host / device split of the call is in the record."""
+    f4 = line["secondary"]["f4_factor_analysis_32x4"]
+    assert "error" not in f4, f4
+    hist = {int(k): v for k, v in f4["nfactors_histogram"].items()}
+    assert sum(hist.values()) == 4096 and min(hist) >= 2, hist
+    sp = f4["split_s"]
+    assert sp["host_eig_order"] > 0 and sp["device_kernels_and_transfers"] > 0
+    assert f4["models_per_s"] >= 8000.0, f4          # round 3 (builder-side probe): 26 k models/s
+    sub = f4["always_scipy_subset"]
+    assert sub["models"] == 256 and sub["lockstep_scipy_s"] > 0
