@@ -303,7 +303,11 @@ MK_API int mk_fa_correlation(mk_context *ctx, int64_t R, int64_t T, int64_t N, i
 /* _get_eigval (:420-460), _maptest (:220-312), the factor-count rules of solve (:66-82; maxfactors <= 0 =
  * None) and the start vector of _minres (:188-203) for B correlation matrices.  d_eigval [B,N] descending,
  * clipped at 0; d_nfactors / d_nfactors_map / d_nfactors_map4 [B]; d_psi0 [B,N]; d_status [B]: 1 = no factors
- * can be derived (NaN correlation or singular matrix; the reference returns None).  Outputs may be NULL. */
+ * can be derived (NaN correlation or singular matrix; the reference returns None).  Outputs may be NULL.
+ * "Singular" is decided on the eigenvalues of the device's own decomposition: smallest eigenvalue <= 1e-14 x the largest.
+ * DIVERGENCE from the reference: numpy.linalg.inv (factoranalysis.py:195) raises only on an EXACTLY zero pivot, so a
+ * correlation matrix with a condition number above ~1e14 that is not exactly singular (nearly collinear series) makes
+ * the reference proceed with an inverse that has no correct digits, while this routine reports status 1 (no factors). */
 MK_API int mk_fa_analyse(mk_context *ctx, int64_t B, int64_t N, int64_t maxfactors, const double *d_corr,
                          double *d_eigval, int64_t *d_nfactors, int64_t *d_nfactors_map, int64_t *d_nfactors_map4,
                          double *d_psi0, uint32_t *d_status);

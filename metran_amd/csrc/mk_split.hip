@@ -457,71 +457,56 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         for (int k = 0; k < K; ++k) fct[jr * KP + k] = P[N + k];
                     }
                     wave_lds_sync();
-                    while (uany) {
-                        int usel[M];
-                        bool uval[M];
+                    // static loop over the series (the column P[.][c] is a named register, the loadings / factor-column
+                    // rows of series c sit at immediate LDS offsets): a wavefront-uniform branch skips the series every model
+                    // of the wavefront observed; a model that observed c computes along and does not store
+                    unsigned uml = urem[0];
 #pragma unroll
-                        for (int g = 0; g < M; ++g) {
-                            uval[g] = urem[g] != 0u;
-                            usel[g] = uval[g] ? (int)__builtin_ctz(urem[g]) : 0;
-                            urem[g] &= urem[g] - 1u;
-                        }
-                        uany = 0;
+                    for (int g = 1; g < M; ++g) uml = (h == g) ? urem[g] : uml;
+                    sfor<0, N>(MK_LAMBDA(cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (uany & (1u << c)) {
+                            const double *gp = gtab + c * K, *fp = fct + c * KP;
+                            double pt = P[c], pt2 = 0.0;
+                            if constexpr (K % 2 == 0) {
 #pragma unroll
-                        for (int g = 0; g < M; ++g) uany |= urem[g];
-                        int ul = usel[0];
-                        bool uok = uval[0];
+                                for (int k = 0; k < K; k += 2) {
+                                    const v2d g2 = *reinterpret_cast<const v2d *>(gp + k), f2 = *reinterpret_cast<const v2d *>(fp + k);
+                                    pt = fma(g2.x, Q[k], pt);
+                                    pt2 = fma(g2.y, Q[k + 1], pt2);
+                                    pt = fma(gam[k], f2.x, pt);
+                                    pt2 = fma(gam[k + 1], f2.y, pt2);
+                                }
+                            } else {
 #pragma unroll
-                        for (int g = 1; g < M; ++g) {
-                            ul = (h == g) ? usel[g] : ul;
-                            uok = (h == g) ? uval[g] : uok;
-                        }
-                        double pt = 0.0;
-                        sfor<0, M>(MK_LAMBDA(gg) {
-                            constexpr int g = decltype(gg)::value;
-                            constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
-                            pick_column<N, n, GM>(pt, __builtin_amdgcn_readfirstlane(usel[g]), P);
-                        });
-                        const double *gp = gtab + ul * K, *fp = fct + ul * KP;
-                        double pt2 = 0.0;
-                        if constexpr (K % 2 == 0) {
-#pragma unroll
-                            for (int k = 0; k < K; k += 2) {
-                                const v2d g2 = *reinterpret_cast<const v2d *>(gp + k), f2 = *reinterpret_cast<const v2d *>(fp + k);
-                                pt = fma(g2.x, Q[k], pt);
-                                pt2 = fma(g2.y, Q[k + 1], pt2);
-                                pt = fma(gam[k], f2.x, pt);
-                                pt2 = fma(gam[k + 1], f2.y, pt2);
+                                for (int k = 0; k < K; ++k) {
+                                    pt = fma(gp[k], Q[k], pt);
+                                    pt2 = fma(gam[k], fp[k], pt2);
+                                }
                             }
-                        } else {
+                            pt += pt2;
+                            if (((uml >> c) & 1u) && !MK_TUNE_SKIP(a, 4)) {
+                                trec[c * XS + jr] = pt;
+                                if (l == c) {
+                                    const double qnan = __builtin_nan("");
+                                    double *sd = trec + SO + c * SS;
+                                    if constexpr (PAIRS) {
 #pragma unroll
-                            for (int k = 0; k < K; ++k) {
-                                pt = fma(gp[k], Q[k], pt);
-                                pt2 = fma(gam[k], fp[k], pt2);
-                            }
-                        }
-                        pt += pt2;
-                        if (uok && !MK_TUNE_SKIP(a, 4)) {
-                            trec[ul * XS + jr] = pt;
-                            if (l == ul) {
-                                const double qnan = __builtin_nan("");
-                                double *sd = trec + SO + ul * SS;
-                                if constexpr (PAIRS) {
+                                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{Q[k], Q[k + 1]};
+                                        *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{yh, pt};
+                                        *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
+                                    } else {
 #pragma unroll
-                                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{Q[k], Q[k + 1]};
-                                    *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{yh, pt};
-                                    *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
-                                } else {
-#pragma unroll
-                                    for (int k = 0; k < K; ++k) sd[k] = Q[k];
-                                    sd[SW - 4] = yh;
-                                    sd[SW - 3] = pt;
-                                    sd[SW - 2] = qnan;
-                                    sd[SW - 1] = 0.0;
+                                        for (int k = 0; k < K; ++k) sd[k] = Q[k];
+                                        sd[SW - 4] = yh;
+                                        sd[SW - 3] = pt;
+                                        sd[SW - 2] = qnan;
+                                        sd[SW - 1] = 0.0;
+                                    }
                                 }
                             }
                         }
-                    }
+                    });
                 }
                 trec += tstep;
             }
