@@ -136,7 +136,7 @@ typedef struct mk_outputs {
                                 (metran.py:655-756).  d_F/d_Pf stay a (full or packed-symmetric) record array;
                                 d_Xp/d_Pp must be NULL in mk_filter_smooth (filtered record only).
                               MK_OUT_TAPE        (ABI 5; mk_filter_smooth with d_sim_means / d_sim_vars only, shapes
-                                with mk_tape_supported(N, K) = 1, d_obsvar NULL) d_F is not a filtered record array
+                                with mk_tape_supported(N, K) = 1) d_F is not a filtered record array
                                 but the BACKWARD TAPE of the inverse-free smoother, record_stride =
                                 mk_tape_stride(N, K) = N (n + 4) doubles per (model, step), same (b, t) addressing
                                 and time_major rule as records: per series one entry [ vector(n) | s0 | s1 | s2 | 0 ]

@@ -310,7 +310,6 @@ static int tape_outputs(const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_INVALID, "MK_OUT_TAPE excludes MK_OUT_PACKED_SYM and MK_OUT_VAR_ONLY");
     if (!mk_tape_supported(p->N, p->K))
         return fail(MK_ERR_SHAPE, "MK_OUT_TAPE serves 16 < N + K, N <= 32 (got N=%lld, K=%lld)", (long long)p->N, (long long)p->K);
-    if (p->d_obsvar) return fail(MK_ERR_INVALID, "MK_OUT_TAPE needs d_obsvar = NULL (observation variance 0, metran.py:382-384)");
     if (!o->d_F || o->d_Pf || o->d_Xp || o->d_Pp || o->d_S || o->d_Ps)
         return fail(MK_ERR_INVALID, "MK_OUT_TAPE: d_F is the tape, d_Pf / d_Xp / d_Pp / d_S / d_Ps must be NULL");
     if (o->record_stride != mk_tape_stride(p->N, p->K))
@@ -498,6 +497,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_INVALID, "MK_OUT_TAPE: nothing to write, give d_sim_means / d_sim_vars");
     mk::SmootherArgs a;
     a.tape = tape;
+    a.obsvar = tape ? p->d_obsvar : nullptr;
     a.variant = (ctx->variant[MK_VARIANT_SMOOTHER16] ? 1 : 0) | (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 1 ? 2 : 0) |
                 (ctx->variant[MK_VARIANT_WIDE_SMOOTHER] == 2 ? 4 : 0);
     a.rs = 0;

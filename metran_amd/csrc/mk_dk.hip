@@ -42,7 +42,11 @@ constexpr bool kDkStatic = false; // A/B builds: the entry loops over the set bi
 constexpr bool kDkStatic = true;
 #endif
 
-template <int N, int K, bool STATICJ = kDkStatic>
+// HASR: the observation variances R_j (mk_problem.d_obsvar) are not all zero.  Right after its update the filter's moments of
+// an observed series are  z x = y - v R/f  and  P z' = k R,  so its smoothed observable is  y - R (v/f - beta)  with variance
+// R (1 - R/f) - R^2 alpha  -- the update's own beta and alpha; R = 0 (Metran: metran.py:382-384) gives (y, 0) and the
+// instantiation without the four extra operations per entry.
+template <int N, int K, bool HASR, bool STATICJ = kDkStatic>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, SW = tape_side_c(K), RS = tape_stride_c(N, K);
@@ -96,6 +100,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             CB[k][m] = c < N ? v : 0.0;
         });
     });
+    [[maybe_unused]] const double rvar = HASR ? a.obsvar[rec * N + js] : 0.0;
     const double scale = a.scale ? a.scale[rec * N + js] : 1.0;
     const double offset = a.offset ? a.offset[rec * N + js] : 0.0;
 
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
         wave_lds_sync();
-        double mean = s2, var = 0.0;              // observed (R = 0): the observation itself, variance 0
+        double mean = s2, var = 0.0;              // observed, R = 0: the observation itself, variance 0 (HASR: set in the observed pass)
         if (unobs) {
             double q0 = 0.0, q1 = 0.0;
             double row[N], rowf[SW];
@@ -246,12 +251,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             mean = s0 + rowf[SW - 1];
             var = s1 - (q0 + q1);
         }
-        {
-            const double v = scale * scale * var;
-            if (omean) *omean = fma(scale, mean, offset);
-            if (ovar) *ovar = v < 0.0 ? 0.0 : v;  // kalmanfilter.py:601-602 (np.maximum keeps a NaN)
-        }
-
         // ---- observed series, last first: the scalar updates of the filter walked backwards
         unsigned om = obsm;
         int jp = -1;
@@ -264,6 +263,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const double w = matvec(E);
             const double beta = readlane_f64(w, n);
             const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);
+            if constexpr (HASR) {
+                if (js == j) {
+                    mean = s2 - rvar * (E.s0 - beta);
+                    var = rvar * (1.0 - rvar * E.s1) - rvar * rvar * alpha;
+                }
+            }
             double picked = 0.0;
             pick_column_all<N, n>(picked, j, Nr);
             double nc = picked - w;                                       // N[a][j] - w_a
@@ -289,25 +294,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     __builtin_amdgcn_sched_barrier(0);
                     if (om & (1u << j)) {
                         const Ent &E = eo[j & 1];
-                        if (lane == jp) load_row<n>(tbuf, Nr);                // row jp = the new column of the previous observed series
-                        __builtin_amdgcn_sched_barrier(0);                    // (its reads complete underneath the product)
                         const double w = matvec(E);
                         const double beta = readlane_f64(w, n);
-                        const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);
+                        const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);   // its MFMA chain runs under what follows
                         double nc = Nr[j] - w;                                // N[a][j] - w_a
                         nc = (lane >= n) ? Nr[j] + (E.s0 - beta) : nc;        // r_j + v/f - beta
                         Nr[j] = nc;
                         if (!MK_TUNE_SKIP(a, 16)) {
                             tbuf[ra] = nc;                                    // slot n: the r row's, unused
-                            // the diagonal N[j][j] - 2 w_j + alpha + 1/f: lane j rewrites its slot when alpha has arrived (its own
-                            // register is refreshed from there with the rest of row j)
-                            if (lane == j) tbuf[j] = (nc - w) + (alpha + E.s1);
                             wave_lds_sync();
-                            jp = j;
+                            if (lane == j) load_row<n>(tbuf, Nr);             // row j = the new column j (18 x 16 bytes into one lane)
+                        }
+                        // the diagonal N[j][j] - 2 w_j + alpha + 1/f, in lane j's own register, once alpha has arrived: neither the
+                        // LDS write nor the row's reads wait for the wavefront sum
+                        if (lane == j) Nr[j] = (nc - w) + (alpha + E.s1);
+                        if constexpr (HASR) {
+                            if (js == j) { // (lanes >= N replicate series N-1: the same values to the same address)
+                                mean = s2 - rvar * (E.s0 - beta);
+                                var = rvar * (1.0 - rvar * E.s1) - rvar * rvar * alpha;
+                            }
                         }
                     }
                 });
-                if (lane == jp) load_row<n>(tbuf, Nr);
             }
         } else if (om) {
             load_ent(31 - (int)__builtin_clz(om), ea);
@@ -318,6 +326,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (!om) break;
             }
             if (lane == jp) load_row<n>(tbuf, Nr);
+        }
+        {
+            const double v = scale * scale * var;
+            if (omean) *omean = fma(scale, mean, offset);
+            if (ovar) *ovar = v < 0.0 ? 0.0 : v;  // kalmanfilter.py:601-602 (np.maximum keeps a NaN)
         }
         // every entry of the step has been consumed: next step's block on its way while the transition runs
         tb -= tstep;
@@ -398,7 +411,8 @@ static hipError_t launch_dk_nk(const SmootherArgs &a, hipStream_t s)
 {
     if constexpr (N + K > 16 && N <= 32 && N + K + 1 <= 64 && K <= 16) {
         if (a.rs != tape_stride_c(N, K)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((smoother_dk_kernel<N, K>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        if (a.obsvar) hipLaunchKernelGGL((smoother_dk_kernel<N, K, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((smoother_dk_kernel<N, K, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

@@ -72,6 +72,7 @@ struct SmootherArgs {
     long variant;        // bit 0: n <= 15 records -> smoother_blk_kernel; bit 1: n > 16 -> smoother_wave_kernel (round 1); bit 2: n > 16 -> the MFMA kernel without the lane fold; bits 3 / 4: (-DMK_EXPERIMENTAL_BLK4 builds only) n > 16, n % 4 == 0 -> the 4x4x4 MFMA block path with / without the lane fold;
                          // set by the C ABI from mk_set_kernel_variant.  Every variant is a tested, equivalent kernel.
     long tape;           // 1: F is the backward tape (MK_OUT_TAPE, rs = tape_stride(N, K)): smoother_dk_kernel (mk_dk.hip)
+    const double *obsvar; // tape path: observation variances [R,N] or NULL = zeros
 };
 
 struct AdjointArgs {

@@ -552,12 +552,11 @@ class BatchedKalman:
     def tape_path(self):
         """True when ``simulate_smoothed`` runs the inverse-free backward pass over the filter's tape (``MK_OUT_TAPE``:
         ``mk_split.hip`` OUT = 4 + ``mk_dk.hip``) instead of filtered records + the RTS smoother: wide models served by the
-        split filter (16 < n, N <= 32), observation variance 0, full-square engine, ``projection_path`` not "records"."""
-        ok = (self.loadings is not None and self.obsvar is None and not self.packed_sym
-              and bool(self._L.mk_tape_supported(self.N, self.K)))
+        split filter (16 < n, N <= 32), full-square engine, ``projection_path`` not "records"."""
+        ok = (self.loadings is not None and not self.packed_sym and bool(self._L.mk_tape_supported(self.N, self.K)))
         if self.projection_path == "tape" and not ok:
-            raise MetranHipError("projection_path='tape' needs a model with 16 < N + K, N <= 32, no observation variance "
-                                 "and a full-square engine (got N=%s, K=%s)" % (self.N, getattr(self, "K", None)))
+            raise MetranHipError("projection_path='tape' needs a model with 16 < N + K, N <= 32 and a full-square engine "
+                                 "(got N=%s, K=%s)" % (self.N, getattr(self, "K", None)))
         return ok and self.projection_path != "records"
 
     def alloc_projection(self, B):

@@ -90,10 +90,13 @@ def transition(phi, loadings):
     return Pht
 
 
-def dk_smooth(tape, phi, loadings):
-    """One model.  Returns (means [T,N], variances [T,N]) of the smoothed observables z_j x_t (unscaled)."""
+def dk_smooth(tape, phi, loadings, obsvar=None):
+    """One model.  Returns (means [T,N], variances [T,N]) of the smoothed observables z_j x_t (unscaled).
+    ``obsvar`` R_j != 0: right after its update the filter's moments of an observed series are z x = y - v R/f and
+    P z' = k R, so  mean = y - R (v/f - beta),  var = R (1 - R/f) - R^2 alpha  with the update's own beta and alpha."""
     Tn, N, ES = tape.shape
     n = ES - 4
+    R = np.zeros(N) if obsvar is None else np.asarray(obsvar, float)
     Pht = transition(phi, loadings)
     r = np.zeros(n)
     Nm = np.zeros((n, n))
@@ -116,8 +119,8 @@ def dk_smooth(tape, phi, loadings):
             col[j] = Nm[j, j] - 2.0 * w[j] + alpha + e[n + 1]
             Nm[:, j] = col
             Nm[j, :] = col
-            means[t, j] = e[n + 2]
-            variances[t, j] = 0.0
+            means[t, j] = e[n + 2] - R[j] * (e[n] - beta)
+            variances[t, j] = R[j] * (1.0 - R[j] * e[n + 1]) - R[j] * R[j] * alpha
         r = Pht.T @ r
         Nm = Pht.T @ Nm @ Pht
     return means, variances
