@@ -303,10 +303,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         if (!MK_TUNE_SKIP(a, 16)) {
                             tbuf[ra] = nc;                                    // slot n: the r row's, unused
                             wave_lds_sync();
-                            if (lane == j) load_row<n>(tbuf, Nr);             // row j = the new column j (18 x 16 bytes into one lane)
+                            // row j = the new column j, 16 bytes at a time into ONE lane -- every element but the diagonal, whose
+                            // register is written below from alpha: no read lands in it, so that write waits for no LDS
+                            // operation and the next entry's product starts as soon as the first reads are back
+                            if (lane == j) {
+                                sfor<0, (n + 1) / 2>(MK_LAMBDA(mm) {
+                                    constexpr int c0 = 2 * decltype(mm)::value;
+                                    if constexpr (c0 == (j & ~1) || c0 + 1 >= n) {
+                                        if constexpr (c0 != j) Nr[c0] = tbuf[c0];
+                                        if constexpr (c0 + 1 != j && c0 + 1 < n) Nr[c0 + 1] = tbuf[c0 + 1];
+                                    } else {
+                                        const v2d t2 = *reinterpret_cast<const v2d *>(tbuf + c0);
+                                        Nr[c0] = t2.x;
+                                        Nr[c0 + 1] = t2.y;
+                                    }
+                                });
+                            }
                         }
-                        // the diagonal N[j][j] - 2 w_j + alpha + 1/f, in lane j's own register, once alpha has arrived: neither the
-                        // LDS write nor the row's reads wait for the wavefront sum
+                        // the diagonal N[j][j] - 2 w_j + alpha + 1/f, in lane j's own register, once alpha has arrived
                         if (lane == j) Nr[j] = (nc - w) + (alpha + E.s1);
                         if constexpr (HASR) {
                             if (js == j) { // (lanes >= N replicate series N-1: the same values to the same address)
