@@ -58,7 +58,7 @@ class BatchedKalman:
         self.time_major = layout == "time_major"
         self.packed_sym = bool(packed_sym)
         # simulate_smoothed of wide models: "auto" = the inverse-free tape path where it applies (MK_OUT_TAPE: 16 < n,
-        # N <= 32, observation variance 0), else filtered records + RTS smoother; "tape" insists, "records" never uses it
+        # N <= 32), else filtered records + RTS smoother; "tape" insists, "records" never uses it
         self.projection_path = "auto"
         L = _lib.lib()  # raises MetranHipError when the HIP library is not built
         if not torch.cuda.is_available():
