@@ -167,7 +167,9 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         # largest of the simultaneous trials that passes the Armijo test is taken.
         S_tr = max(1, min(4, 4096 // ((n + 1) * R))) if speculate else 1
         ratios = torch.tensor([1.0, 0.35, 0.12, 0.04][:S_tr], **f64)
-        for _ in range(max_backtracks):
+        # the same budget of trial POINTS per model either way (max_backtracks): a straggler whose differenced gradient no longer
+        # yields an acceptable step uses all of it before it is declared done, and on a small flight every round is a launch
+        for _ in range(-(-max_backtracks // S_tr)):
             if S_tr > 1:
                 steps_s = step[None, :] * ratios[:, None]                                   # [S,R]
                 xt_s = torch.maximum(x[None] + steps_s[:, :, None] * d[None], lo[None])     # [S,R,n]
