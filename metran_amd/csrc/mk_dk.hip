@@ -20,14 +20,18 @@
 // OUT = 4 writes one tape entry of n + 4 doubles per (step, series) (mk_split.hip; tests/dk_ref.py restates both sides).
 //
 // Mapping: one model per wavefront.  Lane a < n holds row a of N, lane n holds r as a ROW (the matrix-vector product then
-// yields beta = r.kt in lane n for free), lanes > n replicate lane n.  An entry's vector arrives straight from HBM in the
-// DPP-replicated layout (lane 16q + i holds x[16m + i], m = 0 .. ceil(N/16)-1, and the K factor entries), so the product is
-// n fused broadcast-multiply-adds (v_fmac_f64_dpp row_newbcast) with no LDS and no readlane.  alpha is one wavefront sum.
-// The new column j goes to the lanes' registers through a jump table and to lane j's row through LDS (36 doubles written by
-// 36 lanes, read back by one).  The unobserved entries change nothing: their products are parked in LDS and reduced once per
-// step (lane u sums its own row).  Transition: factor columns by n K broadcast-multiply-adds against replicated columns of C,
-// series columns by two scalings, the factor rows by transposition through LDS, the K x K factor block by one transposed
-// reduction.
+// yields beta = r.kt in lane n for free), lanes > n replicate lane n.  The step's tape block (10 KB at configs[3]) is copied
+// HBM -> LDS by the wavefront itself (global_load_lds_dwordx4: no registers, asynchronous), issued when the previous block's last
+// entry has been consumed, so the copy runs under the transition.  An entry's vector is read from LDS in the DPP-replicated
+// layout (lane 16q + i holds x[16m + i], m = 0 .. ceil(N/16)-1, and the K factor entries), so the product is n fused
+// broadcast-multiply-adds (v_fmac_f64_dpp row_newbcast), sixteen per asm statement.  alpha is one wavefront sum on the matrix
+// pipe (wave_sum_mfma, mk_jump.h).  The observed pass is UNROLLED over the series (static j: the column is a named register,
+// LDS addresses are immediates).  The new column j goes to lane j's ROW through LDS (36 lanes write, lane j reads back every
+// element but the diagonal, whose register is written from alpha: its reads complete under the wavefront sum and the next
+// entry's product).  The unobserved entries change nothing: their products x_a w_a go back into the entry's own consumed LDS
+// slots and lane u sums its entry once per step.  Transition: factor columns by n K broadcast-multiply-adds against replicated
+// columns of C, series columns by two scalings, the factor rows by transposition through LDS, the K x K factor block by one
+// transposed LDS reduction.  Measurements, and the variants that were measured and dropped: DESIGN.md section 4.
 #include "mk_prims.h"
 #include "mk_jump.h"
 
@@ -36,17 +40,11 @@ namespace mk {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
-#ifdef MK_DK_DYNAMIC
-constexpr bool kDkStatic = false; // A/B builds: the entry loops over the set bits of the step's masks (jump-table column access)
-#else
-constexpr bool kDkStatic = true;
-#endif
-
 // HASR: the observation variances R_j (mk_problem.d_obsvar) are not all zero.  Right after its update the filter's moments of
 // an observed series are  z x = y - v R/f  and  P z' = k R,  so its smoothed observable is  y - R (v/f - beta)  with variance
 // R (1 - R/f) - R^2 alpha  -- the update's own beta and alpha; R = 0 (Metran: metran.py:382-384) gives (y, 0) and the
 // instantiation without the four extra operations per entry.
-template <int N, int K, bool HASR, bool STATICJ = kDkStatic>
+template <int N, int K, bool HASR>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
 {
     constexpr int n = N + K, SW = tape_side_c(K), RS = tape_stride_c(N, K);
@@ -253,35 +251,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         // ---- observed series, last first: the scalar updates of the filter walked backwards
         unsigned om = obsm;
-        int jp = -1;
-        auto obs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
-            const int j = 31 - (int)__builtin_clz(om);
-            om &= ~(1u << j);
-            load_ent(om ? 31 - (int)__builtin_clz(om) : j, Enext); // the next entry's LDS reads in flight during this product
-            if (lane == jp) load_row<n>(tbuf, Nr);                 // row jp = the new column of the previous entry's series:
-            __builtin_amdgcn_sched_barrier(0);                     // the reads complete underneath the product
-            const double w = matvec(E);
-            const double beta = readlane_f64(w, n);
-            const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);
-            if constexpr (HASR) {
-                if (js == j) {
-                    mean = s2 - rvar * (E.s0 - beta);
-                    var = rvar * (1.0 - rvar * E.s1) - rvar * rvar * alpha;
-                }
-            }
-            double picked = 0.0;
-            pick_column_all<N, n>(picked, j, Nr);
-            double nc = picked - w;                                       // N[a][j] - w_a
-            nc = (lane == j) ? (nc - w) + (alpha + E.s1) : nc;            // N[j][j] - 2 w_j + alpha + 1/f
-            nc = (lane >= n) ? picked + (E.s0 - beta) : nc;               // r_j + v/f - beta
-            set_column<N, n>(j, nc, Nr);
-            if (!MK_TUNE_SKIP(a, 16)) {
-                tbuf[ra] = nc;                                            // slot n: the r row's, unused
-                wave_lds_sync();
-                jp = j;                                                   // lane j fetches its row at the top of the next entry
-            }
-        };
-        if constexpr (STATICJ) {
+        {
             // the loop over the series is UNROLLED (static j: an entry's LDS addresses are immediates, the column N[.][j] is a
             // named register -- no bit scan, no address arithmetic, no jump tables for N[.][j]); every position prefetches the
             // next entry whether it runs or not, a wavefront-uniform branch skips the bodies of the unobserved series
@@ -331,15 +301,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 });
             }
-        } else if (om) {
-            load_ent(31 - (int)__builtin_clz(om), ea);
-            while (true) {
-                obs_step(ea, eb);
-                if (!om) break;
-                obs_step(eb, ea);
-                if (!om) break;
-            }
-            if (lane == jp) load_row<n>(tbuf, Nr);
         }
         {
             const double v = scale * scale * var;

@@ -172,58 +172,4 @@ __device__ __forceinline__ void pick_column_all(double &dst, int j, const double
 }
 
 
-// p[j - BASE] = h for a wavefront-uniform j in [BASE, BASE + 16) (jump table, 8 bytes per case: v_mov_b64 + s_branch)
-template <int BASE>
-__device__ __forceinline__ void set16(int j, double h, double &p0, double &p1, double &p2, double &p3, double &p4, double &p5,
-                                      double &p6, double &p7, double &p8, double &p9, double &p10, double &p11, double &p12,
-                                      double &p13, double &p14, double &p15)
-{
-    int t;
-    asm volatile("s_sub_i32 %[t], %[j], %[base]\n\t"
-                 "s_cmp_lt_u32 %[t], 16\n\t"
-                 "s_cbranch_scc0 .Lset_end_%=\n\t"
-                 "s_lshl_b32 %[t], %[t], 3\n\t"
-                 "s_add_u32 %[t], %[t], 12\n\t"
-                 "s_getpc_b64 vcc\n\t"
-                 "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"
-                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
-                 "s_setpc_b64 vcc\n\t"
-                 "v_mov_b64 %[p0], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p1], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p2], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p3], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p4], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p5], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p6], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p7], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p8], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p9], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p10], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p11], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p12], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p13], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p14], %[h]\n\ts_branch .Lset_end_%=\n\t"
-                 "v_mov_b64 %[p15], %[h]\n\t"
-                 ".Lset_end_%=:"
-                 : [t] "=&s"(t), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [p4] "+v"(p4), [p5] "+v"(p5),
-                   [p6] "+v"(p6), [p7] "+v"(p7), [p8] "+v"(p8), [p9] "+v"(p9), [p10] "+v"(p10), [p11] "+v"(p11),
-                   [p12] "+v"(p12), [p13] "+v"(p13), [p14] "+v"(p14), [p15] "+v"(p15)
-                 : [j] "s"(j), [base] "n"(BASE), [h] "v"(h)
-                 : "vcc", "scc");
-}
-template <int N, int n>
-__device__ __forceinline__ void set_column(int j, double h, double (&P)[n])
-{
-    static_assert(N <= 64 && n >= 16, "wide models");
-    double dump = 0.0; // cases beyond N - 1 are never selected (j < N)
-#define MK_SE(i) ((i) < N ? P[(i) < N ? (i) : 0] : dump)
-    sfor<0, (N + 15) / 16>(MK_LAMBDA(bb) {
-        constexpr int B0 = 16 * decltype(bb)::value;
-        set16<B0>(j, h, MK_SE(B0 + 0), MK_SE(B0 + 1), MK_SE(B0 + 2), MK_SE(B0 + 3), MK_SE(B0 + 4), MK_SE(B0 + 5), MK_SE(B0 + 6),
-                  MK_SE(B0 + 7), MK_SE(B0 + 8), MK_SE(B0 + 9), MK_SE(B0 + 10), MK_SE(B0 + 11), MK_SE(B0 + 12), MK_SE(B0 + 13),
-                  MK_SE(B0 + 14), MK_SE(B0 + 15));
-    });
-#undef MK_SE
-}
-
 } // namespace mk

@@ -2,9 +2,9 @@
 # Box-side: the round's profiles.  For every bench configuration: rocprofv3 kernel-trace stats, HBM traffic from two
 # separate PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains), the bench line of the same
 # command; SQ counters for c2 and c4.  Everything lands in gpurun_out/prof_${ROUND}/ -- copy into profiles/${ROUND}/.
-#   ROUND=r03 bash scripts/collect_profiles.sh [configs...]        (default: c2 c3 c4 c5; c2sym / c3sym: packed-symmetric records)
+#   ROUND=r04 bash scripts/collect_profiles.sh [configs...]        (default: c2 c3 c4 c5; c2sym / c3sym: packed-symmetric records)
 set -u
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${ROUND}; mkdir -p $OUT
 CFGS="${@:-c2 c3 c4 c5}"
