@@ -71,14 +71,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // wave-private LDS, one slice per model of the wavefront
     constexpr int KP = (K + 1) & ~1;
-    __shared__ __attribute__((aligned(16))) double lds[M * (3 * NP + GT + KK2 + KP + TS * N + (TAPE ? N * KP : 0))];
+    constexpr int DVS = NP + 2;                  // a d buffer: d [n] (+ pad), then the innovation v and its variance f of lane j
+    __shared__ __attribute__((aligned(16))) double lds[M * (NP + 2 * DVS + GT + KK2 + KP + TS * N + (TAPE ? N * KP : 0))];
     double *phim = lds + h * NP;                                   // diag(Phi) [n]
-    double *dbuf = lds + M * NP + h * 2 * NP;                      // d = P Z_j^T, two buffers
-    double *gtab = lds + M * 3 * NP + h * GT;                      // loadings [N][K]
-    double *pfs = lds + M * (3 * NP + GT) + h * KK2;               // factor block staging for the record stores
-    double *qtab = lds + M * (3 * NP + GT + KK2) + h * KP;         // diag(Q) of the factor states
-    double *otile = lds + M * (3 * NP + GT + KK2 + KP) + h * TS * N; // observations of TS steps
-    [[maybe_unused]] double *fct = lds + M * (3 * NP + GT + KK2 + KP + TS * N) + h * N * KP; // TAPE: factor columns Pf[l][N+k]
+    double *dbuf = lds + M * NP + h * 2 * DVS;                     // d = P Z_j^T, two buffers
+    double *gtab = lds + M * (NP + 2 * DVS) + h * GT;              // loadings [N][K]
+    double *pfs = lds + M * (NP + 2 * DVS + GT) + h * KK2;         // factor block staging for the record stores
+    double *qtab = lds + M * (NP + 2 * DVS + GT + KK2) + h * KP;   // diag(Q) of the factor states
+    double *otile = lds + M * (NP + 2 * DVS + GT + KK2 + KP) + h * TS * N; // observations of TS steps
+    [[maybe_unused]] double *fct = lds + M * (NP + 2 * DVS + GT + KK2 + KP + TS * N) + h * N * KP; // TAPE: factor columns Pf[l][N+k]
 
     const double phi_l = a.phi[inst * n + jr];
     const double q_l = a.q[inst * n + jr];
@@ -237,12 +238,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     else vl2 = fma(-gam[k], xk[k], vl2);
                 }
                 vl += vl2;
-                double v = readlane_f64(vl, jsel[0]);
-#pragma unroll
-                for (int g = 1; g < M; ++g) {
-                    const double vg = readlane_f64(vl, g * H + jsel[g]);
-                    v = (h == g) ? vg : v;
-                }
                 // d = P Z_j^T (:349-357): column j of the own row through a wavefront-uniform switch per model
                 double dr = 0.0;
                 sfor<0, M>(MK_LAMBDA(gg) { // lanes of group g: dr = P[l][j_g] (jump table, exec = the group's lanes)
@@ -274,12 +269,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int k2 = 0; k2 < K; ++k2) s = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], gj[k2], s);
                     df[k] = s;
                 }
-                double *dv = dbuf + (nupd & 1) * NP; // two buffers: one fence per update
+                double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
                 dv[jr] = dr;
-                if (l == jl) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) dv[N + k] = df[k];
-                }
                 // innovation variance f = R_j + Z_j d (:359-362), all from lane j's own values
                 double fl = rvar + dr, fl2 = 0.0;
 #pragma unroll
@@ -288,18 +279,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     else fl2 = fma(gam[k], df[k], fl2);
                 }
                 fl += fl2;
-                double f = readlane_f64(fl, jsel[0]);
+                if (l == jl) {
 #pragma unroll
-                for (int g = 1; g < M; ++g) {
-                    const double fg = readlane_f64(fl, g * H + jsel[g]);
-                    f = (h == g) ? fg : f;
+                    for (int k = 0; k < K; ++k) dv[N + k] = df[k];
+                    // lane j's innovation and its variance travel with d through LDS (round 4: gathering them with two readlane
+                    // pairs + selects per model cost the wide filter 6 %: 52.9 -> 49.8 ms at configs[3])
+                    *reinterpret_cast<v2d *>(dv + NP) = v2d{vl, fl};
                 }
+                wave_lds_sync();
+                const v2d vf = *reinterpret_cast<const v2d *>(dv + NP);
+                double v = vf.x, f = vf.y;
                 f = okl ? f : 1.0;             // a model with no observation left: the body is a no-op
                 v = okl ? v : 0.0;
                 double rf = rcp_nr(f);
                 rf = okl ? rf : 0.0;
                 const double kr = dr * rf;     // Kalman gain element l (:364-366)
-                wave_lds_sync();
                 {
                     // P -= k k^T f (:368-372): P[l][c] -= d_c k_l.  d is read back from LDS (group-uniform addresses) in
                     // pieces of DB doubles, one piece ahead of its multiply-adds: the whole vector at once is 2n VGPRs
