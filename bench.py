@@ -230,6 +230,7 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
         roofline["survey_8d_full_output_accounting"] = {
             "bytes_per_model": b_fs, "equivalent_GBps": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3),
             "frac_of_peak": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3) / HBM_PEAK_GBS,
+            "north_star_bar": {"frac_of_peak": 0.40, "models_per_s": 0.40 * HBM_PEAK_GBS * 1e9 / b_fs},
             "note": "kernel-time rate of this GPU x bytes a full-square six-output pass would move"}
     return roofline
 
