@@ -167,8 +167,10 @@ MK_API int mk_sync(mk_context *ctx);
  *   MK_VARIANT_SMOOTHER16     n <= 15, packed records: 0 smoother_record_kernel (DPP), 1 smoother_blk_kernel (4x4x4 MFMA)
  *   MK_VARIANT_WIDE_SMOOTHER  n > 16: 0 the blocked MFMA smoother (n <= 36: rows of A folded into the idle lanes),
  *                             1 smoother_wave_kernel (round 1, row per lane), 2 the MFMA smoother without the fold
- *   MK_VARIANT_WIDE_FILTER    n > 16, N <= 32: 0 filter_split_kernel (series on the lanes, factor block replicated:
- *                             2 or 4 models per wavefront), 1 filter_kernel<N,K,64> (one state per lane) */
+ *   MK_VARIANT_WIDE_FILTER    n > 16, N <= 32: 0 by batch size -- filter_split_kernel (series on the lanes, factor block
+ *                             replicated: 2 or 4 models per wavefront) for more than 2 instances per SIMD of the device,
+ *                             filter_kernel<N,K,64> (one state per lane) below; 1 the latter always; 2 the former always
+ *                             (the MK_OUT_TAPE path always runs the split kernel: the tape exists in that layout only) */
 enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_COUNT = 3 };
 MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value);
 MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value);

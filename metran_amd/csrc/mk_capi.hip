@@ -261,9 +261,8 @@ MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
 {
     MK_CTX(ctx);
     if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
-    constexpr int wide_max = 2;
-    if (value < 0 || value > (which == MK_VARIANT_WIDE_SMOOTHER ? wide_max : 1))
-        return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for MK_VARIANT_WIDE_SMOOTHER)");
+    if (value < 0 || value > (which == MK_VARIANT_SMOOTHER16 ? 1 : 2))
+        return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for the two wide selectors)");
     ctx->variant[which] = value;
     return MK_OK;
 }
@@ -451,7 +450,7 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     const int rec = tape ? 0 : records_filter(p, o);
     if (rec < 0) return rec;
     mk::FilterArgs a;
-    a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER] ? 1 : 0;
+    a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER]; // 0 auto, 1 lane per state, 2 split
     a.tape = tape;
     a.rs = (rec || tape) ? o->record_stride : 0;
     a.sym = (rec && (o->flags & MK_OUT_PACKED_SYM)) ? 1 : 0;

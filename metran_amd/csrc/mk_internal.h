@@ -43,7 +43,7 @@ struct FilterArgs {
     long long *sigmacount;
     double *F, *Pf, *Xp, *Pp;
     unsigned *status;
-    long variant;        // bit 0: wide models keep filter_kernel<N,K,64> (one state per lane) instead of the split layout
+    long variant;        // wide models: 0 = split layout when B > 2 x #SIMDs, else filter_kernel<N,K,64> (one state per lane); 1 = one state per lane always; 2 = split always
     long tape;           // 1: F is the backward tape of the inverse-free smoother (MK_OUT_TAPE; rs = tape_stride(N, K))
 };
 

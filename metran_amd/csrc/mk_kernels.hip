@@ -1872,7 +1872,18 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
     const bool book = a.sigmas || a.detfs;
     const bool any = a.F || a.Pf || a.Xp || a.Pp;
     if constexpr (n > 16 && N <= 32) { // wide models: several per wavefront in the split layout (mk_split.hip)
-        if (!(a.variant & 1) || a.tape) {
+        // ... when the batch is large enough for it to pay: a split wavefront serves two (four) models in little more than the
+        // time a lane-per-state wavefront serves one, but with B <= 2 x #SIMDs the lane-per-state kernel still has a SIMD per
+        // one or two wavefronts and the split one leaves half of them idle (measured, (32,4), T = 400, records / objective:
+        // B = 1024: 4.5 / 4.2 ms against 6.9 / 6.2; B = 2048: 6.8 / 5.7 against 7.7 / 6.3; B = 3072: 10.8 / 9.1 against 10.0 / 8.0).
+        // variant bit 0: lane per state always; bit 1: split always; the tape (MK_OUT_TAPE) exists in the split layout only.
+        static const long simds = [] {
+            int dev = 0, cu = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+            return 4L * cu;
+        }();
+        const bool split = a.tape || (a.variant & 2) || (!(a.variant & 1) && a.B > 2 * simds);
+        if (split) {
             const hipError_t e = launch_filter_split(N, K, a, s);
             if (e != hipErrorNotSupported) return e;
         }

@@ -24,8 +24,8 @@
 // The records written are the same full-square [ mean(n) | covariance(n x n) | sigma, detf | pad ] records the smoothers
 // read (mk_prims.h): rows 0 .. n-1, columns < N through the symmetric column runs of the series rows; columns >= N of
 // the series rows as K contiguous doubles per lane; the factor block from the replicated copy.
-// Modes: OUT 0 (objective only), 1 (predicted + filtered records), 3 (filtered record); full-square records only --
-// dense outputs and packed-symmetric records keep filter_kernel<N,K,64>.
+// Modes: OUT 0 (objective only), 1 (predicted + filtered records), 3 (filtered record), full-square or (SYM, round 4)
+// packed-symmetric records; dense outputs keep filter_kernel<N,K,64>.
 // OUT 4 (round 4): the BACKWARD TAPE of the inverse-free smoother (mk_dk.hip) instead of a covariance record -- per
 // (step, series) one entry of n + 4 doubles in the OBSERVABLE basis xt = T x, T = [[I, G], [0, I]] (series states
 // replaced by the observables y_j = x_j + sum_k g_jk x_{N+k}, in which the observation rows are unit vectors):
@@ -42,7 +42,7 @@
 
 namespace mk {
 
-template <int N, int K, int H, int OUT, bool BOOK>
+template <int N, int K, int H, int OUT, bool BOOK, bool SYM = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) filter_split_kernel(FilterArgs a)
 {
     constexpr int n = N + K, M = 64 / H;
@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int GT = (N * K + 1) & ~1;         // loadings table of one model, even
     constexpr int KF = K * (K + 1) / 2;          // upper triangle of the factor block
     constexpr int KK2 = (K * K + 1) & ~1;
-    constexpr int NV = record_payload(n), RS = record_stride_c(n), PADN = RS - NV;
+    static_assert(!SYM || OUT == 1 || OUT == 3, "packed-symmetric layout applies to record outputs");
+    constexpr int NV = SYM ? record_payload_sym(n) : record_payload(n), RS = SYM ? record_stride_sym_c(n) : record_stride_c(n), PADN = RS - NV;
     constexpr bool RECF = (OUT == 1 || OUT == 3);
     constexpr bool TAPE = (OUT == 4);
     constexpr int SW = tape_side_c(K);           // side row of a tape entry: [ factor part (K) | s0 | s1 | s2 | 0 ]
@@ -128,22 +129,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int k = 1; k < K; ++k) xm = (kl == k) ? xf[k] : xm;
         r[N + kl] = xm;
         double *cov = r + n;
+        if constexpr (SYM) {
+            // packed upper triangle by rows (mk_prims.h: element (c, r), c <= r, at sym_row_offset(n, c) + r - c): lane l writes
+            // its P[l][c] to (c, l) for c <= l -- for a fixed c one contiguous run of the lanes l >= c --, its factor columns
+            // P[l][N+k] as the tail of row l; the factor block comes from the replicated copy
 #pragma unroll
-        for (int c = 0; c < n; ++c) cov[c * n + jr] = Pr[c];            // (c, l) <- P[l][c]: a contiguous run per model
-        if constexpr (K % 2 == 0 && N % 2 == 0) {                       // (l, N+k) <- P[l][N+k]: K contiguous doubles
+            for (int c = 0; c < N; ++c)
+                if (jr >= c) cov[sym_row_offset(n, c) + (jr - c)] = Pr[c];
+            const int rowl = jr * n - (jr * (jr - 1)) / 2 - jr;         // sym_row_offset(n, l) - l
 #pragma unroll
-            for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(cov + jr * n + N + k) = v2d{Pr[N + k], Pr[N + k + 1]};
+            for (int k = 0; k < K; ++k) cov[rowl + N + k] = Pr[N + k];
+            wave_lds_sync();                                            // the previous record's staging reads are done
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int k2 = k; k2 < K; ++k2) pfs[pf(k, k2)] = PFv[pf(k, k2)];
+            wave_lds_sync();
+            {   // rows N+k of the triangle are contiguous and in the order of pf(): element e of the replicated block
+                const int e = l < KF ? l : KF - 1;
+                cov[sym_row_offset(n, N) + e] = pfs[e];
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < K; ++k) cov[jr * n + N + k] = Pr[N + k];
+            for (int c = 0; c < n; ++c) cov[c * n + jr] = Pr[c];            // (c, l) <- P[l][c]: a contiguous run per model
+            if constexpr (K % 2 == 0 && N % 2 == 0) {                       // (l, N+k) <- P[l][N+k]: K contiguous doubles
+#pragma unroll
+                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(cov + jr * n + N + k) = v2d{Pr[N + k], Pr[N + k + 1]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) cov[jr * n + N + k] = Pr[N + k];
+            }
+            wave_lds_sync();                                                // the previous record's staging reads are done
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int k2 = 0; k2 < K; ++k2) pfs[k * K + k2] = PFv[k <= k2 ? pf(k, k2) : pf(k2, k)]; // same value from every lane
+            wave_lds_sync();
+            cov[(N + fl16 / K) * n + N + fl16 % K] = pfs[fl16];
         }
-        wave_lds_sync();                                                // the previous record's staging reads are done
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int k2 = 0; k2 < K; ++k2) pfs[k * K + k2] = PFv[k <= k2 ? pf(k, k2) : pf(k2, k)]; // same value from every lane
-        wave_lds_sync();
-        cov[(N + fl16 / K) * n + N + fl16 % K] = pfs[fl16];
 #pragma unroll
         for (int p = 0; p < (PADN + H - 1) / H; ++p) { // the record's pad: sigma, detf, zeros (whole cache lines)
             const int slot = l + p * H < PADN ? l + p * H : PADN - 1;
@@ -531,7 +554,12 @@ static hipError_t launch_split_nk(const FilterArgs &a, hipStream_t s)
         const unsigned grid = (unsigned)((a.B + M - 1) / M);
         const bool book = a.sigmas || a.detfs;
         const bool any = a.F || a.Pf || a.Xp || a.Pp;
-        if (a.sym) return hipErrorNotSupported;
+        if (a.sym) { // packed-symmetric records (round 4; before: filter_kernel<N,K,64>)
+            if (a.rs > 0 && a.Xp) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 1, true, true>), dim3(grid), dim3(64), 0, s, a);
+            else if (a.rs > 0 && any) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 3, true, true>), dim3(grid), dim3(64), 0, s, a);
+            else return hipErrorNotSupported;
+            return hipGetLastError();
+        }
         if (a.tape) { // the backward tape of mk_dk.hip in a.F (a.rs = N (n + 4) doubles per model-step)
             if (book) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, true>), dim3(grid), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, false>), dim3(grid), dim3(64), 0, s, a);

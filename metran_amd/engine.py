@@ -77,6 +77,8 @@ class BatchedKalman:
         self.offset = None
         self.R = self.T = self.N = self.K = None
         self._timing = False
+        for which, name in type(self).default_variants.items():
+            self.set_variant(which, name)
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -93,12 +95,17 @@ class BatchedKalman:
     # ------------------------------------------------------------------ kernel variants (A/B measurements)
     _VARIANTS = {"smoother16": (0, ("record", "blk")),
                  "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded")),
-                 "wide_filter": (2, ("split", "lane_per_state"))}
+                 "wide_filter": (2, ("auto", "lane_per_state", "split"))}
+    # variants every new engine starts with (name -> value); empty = the library's defaults.  The GPU test tier sets
+    # {"wide_filter": "split"} so that its small batches keep exercising the split kernels, which "auto" reserves for
+    # batches of more than two models per SIMD (tests/conftest.py; tests/test_hip_layouts.py checks "auto" itself)
+    default_variants = {}
 
     def set_variant(self, which, name):
         """Choose between two equivalent kernels of a shape class (``mk_set_kernel_variant``): ``"smoother16"``:
-        ``"record"`` (default) | ``"blk"``; ``"wide_smoother"``: ``"mfma"`` (default) | ``"v1"`` | ``"mfma_unfolded"``.  Both members of a pair
-        are tested against the oracle; there is no environment switch."""
+        ``"record"`` (default) | ``"blk"``; ``"wide_smoother"``: ``"mfma"`` (default) | ``"v1"`` | ``"mfma_unfolded"``; ``"wide_filter"``: ``"auto"`` (default: the split
+        layout for more than two models per SIMD, one state per lane below) | ``"lane_per_state"`` | ``"split"``.  Every
+        member is tested against the oracle; there is no environment switch."""
         sel, names = self._VARIANTS[which]
         check(self._L.mk_set_kernel_variant(self._ctx, sel, names.index(name)))
         return self

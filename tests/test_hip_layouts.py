@@ -164,3 +164,41 @@ def test_accumulating_kernel_timing():
     f1, s1 = kf.last_kernel_ms()
     assert 0.0 < f1 < 100.0 and 0.0 < s1 < 100.0
     kf.enable_timing(False)
+
+
+def test_wide_filter_auto_rule():
+    """MK_VARIANT_WIDE_FILTER = 0 ("auto", the library default): one state per lane up to two models per SIMD, the split
+    layout above; both equal the oracle, and "auto" is bit-for-bit one of the two forced variants on either side of the
+    threshold."""
+    import torch
+
+    from metran_amd.engine import BatchedKalman
+    from metran_amd.synthetic import make_dfm_batch_torch
+
+    N, K, T = 32, 4, 12
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    small = make_dfm_batch(5, N, K, T, seed=71, missing=0.3, first_step="random")
+    ref = oracle.dfm_batch(small["obs"], small["phi"], small["q"], small["loadings"], smooth=False)
+    res = {}
+    for name in ("auto", "lane_per_state", "split"):
+        kf = BatchedKalman()
+        kf.set_variant("wide_filter", name)
+        assert kf.get_variant("wide_filter") == name
+        kf.set_observations(small["obs"]).set_loadings(small["loadings"])
+        r = kf.filter(small["phi"], small["q"])
+        np.testing.assert_allclose(_np(r["Pf"]), ref["Pf"], atol=1e-10)
+        np.testing.assert_allclose(_np(r["mle"]), ref["mle"], rtol=1e-9)
+        res[name] = (r["F"].clone(), r["Pf"].clone(), r["mle"].clone())
+        kf.close()
+    assert all(torch.equal(a, b) for a, b in zip(res["auto"], res["lane_per_state"]))      # 5 models: one state per lane
+    B = 2 * simds + 64
+    big = make_dfm_batch_torch(B, N, K, T, seed=72, device=torch.device("cuda", 0), missing=0.3)
+    out = {}
+    for name in ("auto", "lane_per_state", "split"):
+        kf = BatchedKalman(layout="time_major")
+        kf.set_variant("wide_filter", name)
+        kf.set_observations(big["obs"]).set_loadings(big["loadings"])
+        out[name] = kf.loglik(big["phi"], big["q"]).clone()
+        kf.close()
+    assert torch.equal(out["auto"], out["split"])                                          # > 2 models per SIMD: split layout
+    assert float(((out["split"] - out["lane_per_state"]) / out["split"]).abs().max()) < 1e-12
