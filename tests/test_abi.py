@@ -152,3 +152,24 @@ def test_kernel_sources_read_no_environment_variable():
         text = open(os.path.join(src, f)).read()
         assert "getenv" not in text, f
     assert "MK_TUNE" not in open(os.path.join(src, "Makefile")).read()   # the default build does not define it
+
+
+def test_tape_geometry_without_a_gpu():
+    """MK_OUT_TAPE's sizes (ABI 5) are pure functions: N entries of N + K + 4 doubles per (model, step), served for the shapes
+    of the split filter (16 < N + K, N <= 32) that have a kernel; the numpy restatement unpacks the same geometry."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dk_ref
+    from metran_amd import _lib
+
+    L = _lib.lib()
+    assert L.mk_tape_stride(32, 4) == 32 * 40 == 1280 and L.mk_tape_stride(14, 3) == 14 * 21
+    assert L.mk_tape_supported(32, 4) == 1 and L.mk_tape_supported(14, 3) == 1
+    assert L.mk_tape_supported(8, 2) == 0            # n <= 16: the 16-lane kernels
+    assert L.mk_tape_supported(48, 3) == 0           # N > 32: not a shape of the split filter
+    blk = np.arange(14 * 21, dtype=float)
+    e = dk_ref.unpack_block(blk, 14, 3)
+    assert e.shape == (14, 21) and e[3, 0] == 3 * 21 and e[3, 14] == 3 * 21 + 14 and e[13, 20] == 14 * 21 - 1
