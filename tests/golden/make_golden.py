@@ -577,12 +577,46 @@ def edge_nan(i, y):
         y[5, 2] = 0.25  # single observation in the whole record
 
 
+def heywood_wide():
+    """A WIDE model (17 series, 1 factor: a shape of the tape path, 16 < n, N <= 32) with a series of communality exactly 1
+    (q = 0 for its specific state, metran.py:314-316) AND 35 % missing observations: the predicted covariance turns singular
+    along the record while the smoother still has something to do (heywood.npz is fully observed: its smoothed observables are
+    the observations).  Stored: the reference's projected smoothed means / variances (kalmansmoother + simulate) and the same
+    recursion in 60-digit arithmetic -- what the inverse-free backward pass is compared with (tests/test_dk_tape.py)."""
+    N, K, T = 17, 1, 240
+    y, alpha, load, phi, q = make_dfm(N, K, T, 6160, 0, 0.35, "observed")
+    load = load.copy()
+    load[4] = [1.0]
+    alpha = alpha.copy()
+    alpha[4] = 5.0   # phi = 0.82: the variance of that state (q = 0) has decayed to rounding level after ~100 steps
+    phi, q = phi_q_from_alpha(alpha, load)
+    assert q[4] == 0.0
+    kf = kfm.SPKalmanFilter(engine="numpy")
+    kf.filtermethod = kfm.seqkalmanfilter
+    kf.set_observations(pd.DataFrame(y))
+    Phi, Z = np.diag(phi), observation_matrix(load)
+    kf.set_matrices(Phi, np.diag(q), Z, np.zeros(N))
+    kf.run_filter()
+    S, Ps = kfm.kalmansmoother(kf.filtered_state_means, kf.filtered_state_covariances, kf.predicted_state_means,
+                               kf.predicted_state_covariances, Phi)
+    Fe, Pfe, Se, Pse = exact_filter_smoother(y, phi, q, load)
+    mineig = np.array([np.linalg.eigvalsh(kf.predicted_state_covariances[t])[0] for t in range(T)])
+    proj = lambda m, P: (m @ Z.T, np.einsum("jn,tnm,jm->tj", Z, P, Z))  # noqa: E731
+    m_ref, v_ref = proj(S, Ps)
+    m_ex, v_ex = proj(Se, Pse)
+    print("heywood_wide: min eig(Pp) %.1e..%.1e | reference vs exact: projected means %.1e variances %.1e" % (
+        mineig[1:].min(), mineig[1:].max(), np.abs(m_ref - m_ex).max(), np.abs(v_ref - v_ex).max()))
+    np.savez_compressed(os.path.join(HERE, "heywood_wide.npz"), obs=y, phi=phi, q=q, loadings=load, mle=np.float64(kf.get_mle()),
+                        sim_means=m_ref, sim_vars=v_ref, sim_means_exact=m_ex, sim_vars_exact=v_ex, mineig_Pp=mineig)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py heywood ...
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
     heywood()
+    heywood_wide()
     factor_analysis()
     factor_multi()
     g1_real()
