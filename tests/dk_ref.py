@@ -126,6 +126,53 @@ def dk_smooth(tape, phi, loadings, obsvar=None):
     return means, variances
 
 
+def dk_state_moments(obs, phi, q, loadings):
+    """Groundwork for the state outputs (``filter_smooth`` / ``MK_OUT_VAR_ONLY`` of wide models, today the RTS kernel): the
+    smoothed STATE means and covariances from the same backward recursion, ``x_s = x_f + Pf r``, ``V = Pf - Pf N Pf`` with the
+    filtered moments of the step and (r, N) before the step's updates, taken back to Metran's own basis (r = T'rt, N = T'Nt T).
+    One model; returns (S [T,n], Ps [T,n,n]).  Checked against the oracle in tests/test_dk_tape.py."""
+    Tn, N = obs.shape
+    K = loadings.shape[1]
+    n = N + K
+    Z = np.concatenate([np.eye(N), loadings], axis=1)
+    Tm = transform(loadings)
+    x, P = np.zeros(n), np.eye(n)
+    F, Pf = np.empty((Tn, n)), np.empty((Tn, n, n))
+    for t in range(Tn):  # the filter once more, keeping the filtered moments (kalmanfilter.py:318-390)
+        x = phi * x
+        P = P * np.outer(phi, phi) + np.diag(q)
+        for j in np.nonzero(np.isfinite(obs[t]))[0]:
+            z = Z[j]
+            d = P @ z
+            f = z @ d
+            k = d / f
+            x = x + k * (obs[t, j] - z @ x)
+            P = P - np.outer(k, k) * f
+        F[t], Pf[t] = x, P
+    tape = filter_tape(obs, phi, q, loadings)
+    Pht = transition(phi, loadings)
+    r, Nm = np.zeros(n), np.zeros((n, n))
+    S, Ps = np.empty((Tn, n)), np.empty((Tn, n, n))
+    for t in range(Tn - 1, -1, -1):
+        ro, No = Tm.T @ r, Tm.T @ Nm @ Tm
+        S[t] = F[t] + Pf[t] @ ro
+        Ps[t] = Pf[t] - Pf[t] @ No @ Pf[t]
+        seen = ~np.isnan(tape[t, :, n + 2])
+        for j in np.nonzero(seen)[0][::-1]:
+            e = tape[t, j]
+            k = e[:n]
+            w = Nm @ k
+            beta, alpha = k @ r, k @ w
+            r[j] += e[n] - beta
+            col = Nm[:, j] - w
+            col[j] = Nm[j, j] - 2.0 * w[j] + alpha + e[n + 1]
+            Nm[:, j] = col
+            Nm[j, :] = col
+        r = Pht.T @ r
+        Nm = Pht.T @ Nm @ Pht
+    return S, Ps
+
+
 def project(means, variances, scale=None, offset=None):
     """simulate() with the series' standard deviations and means folded in (metran.py:944-961, kalmanfilter.py:597-602)."""
     if scale is not None:
