@@ -151,6 +151,10 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         d = torch.where(bad[:, None], -pg, d)
         if not S:
             d = d / pg.abs().amax(1, keepdim=True).clamp_min(1e-300)  # first step: unit-scale move
+        # a parameter ON its bound with the gradient pushing into it stays there: the history pairs carry its gradient
+        # changes (y) though not its moves (s = 0), so the two-loop product can hand it a component pointing INTO the
+        # feasible side -- uphill, and invisible to the Armijo test below, whose slope is the projected gradient's
+        d = torch.where((x <= lo) & (g > 0), torch.zeros_like(d), d)
         d = torch.where(active[:, None], d, torch.zeros_like(d))
         # Armijo back-tracking on the projected path, one trial per searching model per launch
         step = torch.ones(R, **f64)

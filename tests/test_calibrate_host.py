@@ -1,0 +1,214 @@
+"""CPU: the HOST logic of the batched calibration driver (metran_amd/calibrate.py -- SURVEY.md section 8f, row f1) with the
+device engine replaced by an oracle-backed stand-in that offers the same methods (tests may use the oracle; the product
+never does): the bound-projected L-BFGS update, the Armijo search with one trial per launch, the several-trials-per-launch
+search of a small differenced flight, the compaction of the flight onto the still-active records, the switch from the
+adjoint to differenced gradients, the adjoint's forward / backward bookkeeping.  The optimum is checked against scipy's
+L-BFGS-B (the reference's optimiser, metran/solver.py:248-255) on the same objective.  The GPU tier runs the same driver
+on the real engine (tests/test_hip_solver.py, tests/test_bench_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import minimize
+
+import adjoint_ref
+import oracle
+from metran_amd.calibrate import calibrate_batch
+from metran_amd.params import phi_q_from_alpha
+from metran_amd.synthetic import make_dfm_batch
+
+
+class OracleEngine:
+    """The slice of ``BatchedKalman`` that ``calibrate_batch`` touches, on the CPU, values from the C oracle
+    (``oracle_dfm_batch``) and gradients from the numpy adjoint restatement (tests/adjoint_ref.py)."""
+
+    def __init__(self, obs, loadings, adjoint=True, log=None):
+        self.obs_np, self.load_np = np.asarray(obs, float), np.asarray(loadings, float)
+        self.R, self.T, self.N = self.obs_np.shape
+        self.K = self.load_np.shape[2]
+        self.device = torch.device("cpu")
+        self._adjoint = adjoint
+        self._pending = None
+        self.log = log if log is not None else []       # (what, instances) per launch, shared with the subsets
+
+    n = property(lambda self: self.N + self.K)
+
+    def _dev(self, a, shape=None, name="array"):
+        a = torch.as_tensor(np.asarray(a, float) if not isinstance(a, torch.Tensor) else a, dtype=torch.float64)
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError("%s must be %s" % (name, tuple(shape)))
+        return a
+
+    def has_adjoint(self):
+        return self._adjoint
+
+    def record_stride(self):
+        return self.n * (self.n + 1)
+
+    def subset(self, index):
+        idx = np.asarray(index)
+        return OracleEngine(self.obs_np[idx], self.load_np[idx], self._adjoint, self.log)
+
+    def _records(self, B):
+        assert B % self.R == 0
+        return np.arange(B) % self.R                    # instance s*R + r reads record r
+
+    def params_from_alpha(self, alpha, dt=1.0):
+        a = alpha.numpy()
+        phi, q = phi_q_from_alpha(a, self.load_np[self._records(a.shape[0])], dt)
+        return torch.from_numpy(phi.copy()), torch.from_numpy(q.copy())
+
+    def loglik(self, phi, q, warmup=1):
+        rec = self._records(phi.shape[0])
+        self.log.append(("loglik", int(phi.shape[0])))
+        res = oracle.dfm_batch(self.obs_np[rec], phi.numpy(), q.numpy(), self.load_np[rec], warmup=warmup, smooth=False,
+                               outputs="mle")
+        return torch.from_numpy(res["mle"].copy())
+
+    def _grad(self, alpha, dt, warmup):
+        a = alpha.numpy()
+        rec = self._records(a.shape[0])
+        f, g = np.empty(a.shape[0]), np.empty_like(a)
+        for b, r in enumerate(rec):
+            G = self.load_np[r]
+            phi, q = phi_q_from_alpha(a[b], G, dt)
+            f[b], gphi, gq = adjoint_ref.gradient(self.obs_np[r], phi, q, G, warmup=warmup)
+            scale = np.concatenate([1.0 - np.sum(G * G, axis=1), np.ones(self.K)])
+            dphi = phi * dt / a[b] ** 2                  # phi = exp(-dt / alpha), q = (1 - phi^2) * scale
+            g[b] = (gphi - 2.0 * phi * scale * gq) * dphi
+        return torch.from_numpy(f), torch.from_numpy(g)
+
+    def loglik_grad_alpha(self, alpha, dt=1.0, warmup=1):
+        self.log.append(("forward+backward", int(alpha.shape[0])))
+        return self._grad(alpha, dt, warmup)
+
+    def loglik_forward_alpha(self, alpha, dt=1.0, warmup=1):
+        self.log.append(("forward", int(alpha.shape[0])))
+        phi, q = self.params_from_alpha(alpha, dt)
+        self._pending = (alpha.clone(), dt, warmup)
+        rec = self._records(alpha.shape[0])
+        res = oracle.dfm_batch(self.obs_np[rec], phi.numpy(), q.numpy(), self.load_np[rec], warmup=warmup, smooth=False,
+                               outputs="mle")
+        return torch.from_numpy(res["mle"].copy())
+
+    def loglik_backward_alpha(self):
+        assert self._pending is not None, "backward without a forward pass"
+        alpha, dt, warmup = self._pending
+        self._pending = None                             # one backward pass per forward pass, like the engine
+        self.log.append(("backward", int(alpha.shape[0])))
+        return self._grad(alpha, dt, warmup)[1]
+
+
+def scipy_optimum(eng, r, alpha0=10.0, pmin=1e-5):
+    def fun(a):
+        f, g = eng._grad(torch.from_numpy(np.tile(a, (eng.R, 1))), 1.0, 1)
+        return float(f[r]), g[r].numpy()
+
+    # (the whole batch is evaluated for one model's value: fine at these sizes)
+    lo = np.broadcast_to(np.asarray(pmin, float), (eng.R, eng.n))[r] if not np.isscalar(pmin) else np.full(eng.n, pmin)
+    return minimize(fun, np.maximum(np.full(eng.n, alpha0), lo), jac=True, method="l-bfgs-b",
+                    bounds=[(l, None) for l in lo], options=dict(ftol=2.220446049250313e-09, gtol=1e-5))
+
+
+@pytest.fixture(scope="module")
+def models():
+    d = make_dfm_batch(5, 3, 1, 160, seed=21, missing=0.2)
+    return d["obs"], d["loadings"]
+
+
+@pytest.fixture(scope="module")
+def optima(models):
+    eng = OracleEngine(*models)
+    return [scipy_optimum(eng, r) for r in range(eng.R)]
+
+
+def check_against_scipy(res, optima):
+    assert bool(res.converged.all())
+    for r, ref in enumerate(optima):
+        assert float(res.obj[r]) <= ref.fun + 1e-6 * max(1.0, abs(ref.fun)), (r, float(res.obj[r]), ref.fun)
+        assert abs(float(res.obj[r]) - ref.fun) <= 2e-5 * max(1.0, abs(ref.fun))
+    assert np.all(np.asarray(res.aic) == 2 * res.alpha.shape[1] + np.asarray(res.obj))
+
+
+def test_adjoint_iteration_reaches_scipys_optimum(models, optima):
+    eng = OracleEngine(*models)
+    res = calibrate_batch(eng, gradient="adjoint", compact=0)
+    check_against_scipy(res, optima)
+    # bookkeeping: every trial point is ONE recording forward launch over the R models in flight, every iteration ends in
+    # ONE backward launch; the first gradient is the only forward+backward pair
+    kinds = [k for k, _ in eng.log]
+    assert kinds[0] == "forward+backward" and kinds.count("forward+backward") == 1
+    assert res.nit - 1 <= kinds.count("backward") <= res.nit
+    assert all(b == eng.R for _, b in eng.log)
+    assert res.launches == 2 + kinds.count("forward") + kinds.count("backward")
+    assert res.nfev == eng.R * (1 + kinds.count("forward"))
+    # every backward pass directly follows the forward pass whose records it walks
+    for i, k in enumerate(kinds):
+        if k == "backward":
+            assert kinds[i - 1] == "forward"
+
+
+def test_compaction_leaves_every_models_iterates_unchanged(models):
+    """``compact``: the flight is gathered onto the still-active records (``subset``); the docstring's promise is that every
+    model sees exactly the iterates it would have seen in the full flight."""
+    full = OracleEngine(*models)
+    a = calibrate_batch(full, gradient="adjoint", compact=0)
+    comp = OracleEngine(*models)
+    b = calibrate_batch(comp, gradient="adjoint", compact=0.9, compact_min=2)
+    assert min(n for _, n in comp.log) < comp.R         # it did compact
+    assert torch.equal(a.alpha, b.alpha) and torch.equal(a.obj, b.obj) and torch.equal(a.grad, b.grad)
+    assert torch.equal(a.converged, b.converged)
+    assert b.nfev < a.nfev
+
+
+def test_differenced_small_flight_takes_several_trials_per_launch(models, optima):
+    """gradient="fd" on a flight with (n+1) R <= 4096 instances: every launch carries S_tr = 4 step lengths x (n+1)
+    difference points x R models, and an accepted trial needs no further launch for its gradient."""
+    eng = OracleEngine(*models, adjoint=False)
+    res = calibrate_batch(eng, gradient="auto", compact=0)
+    check_against_scipy(res, optima)
+    n, R = eng.n, eng.R
+    assert eng.log[0] == ("loglik", (n + 1) * R)
+    assert all(k == "loglik" and b == 4 * (n + 1) * R for k, b in eng.log[1:])
+    assert res.launches == len(eng.log) and res.nfev == sum(b for _, b in eng.log)
+    # the differenced gradient the result carries is the forward difference at the result
+    f, g = res.obj.numpy(), res.grad.numpy()
+    for j in range(n):
+        x = res.alpha.numpy().copy()
+        x[:, j] += 1e-8
+        phi, q = phi_q_from_alpha(x, models[1])
+        fj = oracle.dfm_batch(models[0], phi, q, models[1], smooth=False, outputs="mle")["mle"]
+        np.testing.assert_allclose((fj - f) / 1e-8, g[:, j], atol=1e-12)
+
+
+def test_switch_to_differences_below_a_flight_size(models, optima):
+    eng = OracleEngine(*models)
+    res = calibrate_batch(eng, gradient="adjoint", compact=0, fd_below=10 ** 6)
+    check_against_scipy(res, optima)
+    kinds = [k for k, _ in eng.log]
+    assert kinds[0] == "forward+backward" and set(kinds[1:]) == {"loglik"}   # the first gradient is exact, the rest differenced
+
+
+def test_active_bounds(models):
+    """Lower bounds above the unconstrained optimum of some parameters: the projected iteration stops ON the bound with the
+    gradient pointing into it, at scipy's bounded optimum."""
+    eng = OracleEngine(*models)
+    pmin = np.full((eng.R, eng.n), 1e-5)
+    pmin[:, 0] = 25.0
+    pmin[1, 2] = 40.0
+    res = calibrate_batch(eng, pmin=pmin, alpha0=30.0, gradient="adjoint", compact=0)
+    assert bool(res.converged.all())
+    x, g = res.alpha.numpy(), res.grad.numpy()
+    assert np.all(x >= pmin)
+    for r in range(eng.R):
+        ref = scipy_optimum(eng, r, alpha0=30.0, pmin=pmin)
+        assert abs(float(res.obj[r]) - ref.fun) <= 2e-5 * max(1.0, abs(ref.fun)), (r, float(res.obj[r]), ref.fun)
+        on = ref.x <= pmin[r] + 1e-12
+        assert np.array_equal(x[r] <= pmin[r], on), (r, x[r], ref.x)
+        assert np.all(g[r][on] > 0)
+    assert float(res.pgnorm.max()) < 1e-3
+    assert np.any(x <= pmin)
+
+
+def test_unknown_gradient_mode(models):
+    with pytest.raises(ValueError):
+        calibrate_batch(OracleEngine(*models), gradient="central")
