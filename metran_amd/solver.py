@@ -295,16 +295,19 @@ class HipSolve:
 
     @staticmethod
     def _nearPSD(A, epsilon=0.0):
-        """Nearest positive semi-definite matrix in the sense of ``BaseSolver._nearPSD``
-        (metran/solver.py:167-192): clip the eigenvalues at ``epsilon`` and rescale the rows so that the
-        diagonal is preserved where that is possible."""
+        """``BaseSolver._nearPSD`` (metran/solver.py:167-192) AS IT EVALUATES on ndarrays: the eigenvalues are clipped at
+        ``epsilon`` and the rows rescaled by ``t_i = 1 / sum_k V_ik^2 w_k``, but the reference's ``T @ vec * diag(sqrt(val))``
+        multiplies ELEMENT-wise by a diagonal matrix (the expression dates from ``np.matrix``), so only the diagonal of the
+        scaled eigenvector matrix survives and the result is the diagonal matrix ``diag(t_i V_ii^2 w_i)`` -- which is what a
+        drop-in has to return (tests/golden/solver_covariance.npz holds the reference's own outputs).  ``np.linalg.eig``
+        as there: the pairing of row i with eigenpair i follows LAPACK's order."""
         A = np.asarray(A, dtype=np.float64)
-        w, V = np.linalg.eigh(0.5 * (A + A.T))
+        w, V = np.linalg.eig(A)
         w = np.maximum(w, epsilon)
         with np.errstate(divide="ignore", invalid="ignore"):
             t = 1.0 / ((V * V) @ w)
-            B = (np.sqrt(t)[:, None] * V) * np.sqrt(w)[None, :]
-        return B @ B.T
+            b = np.sqrt(t) * np.diag(V) * np.sqrt(w)
+        return np.diag(b * b)
 
     @staticmethod
     def _get_correlations(pcov):

@@ -32,6 +32,7 @@ import metran.kalmanfilter as kfm  # noqa: E402
 
 from metran_amd.params import observation_matrix, phi_q_from_alpha  # noqa: E402
 from metran_amd.synthetic import make_dfm  # noqa: E402
+from analytic_objective import solver_objective  # noqa: E402
 
 
 def run_reference(obs, phi, q, loadings, r=None, warmup=1, engine="numba-source"):
@@ -195,6 +196,48 @@ def g1_solve():
         pcov=mt.fit.pcov.values.astype(float), names=np.array(list(mt.parameters.index)),
         initial=mt.parameters["initial"].values.astype(float), pmin=mt.parameters["pmin"].values.astype(float))
     print("g1_solve", mt.fit.obj_func, mt.fit.nfev)
+
+
+def solver_covariance():
+    """The reference's covariance helpers (metran/solver.py:65-192) run as they are on inputs that need no model:
+    ``BaseSolver._get_covariance`` (nested forward differences, the positive-diagonal test and its repair step) on an analytic
+    objective -- once at a minimum-like point, once with a fixed (non-varying) parameter in the callback, once on an objective
+    whose Hessian is indefinite so that the repair runs --, ``_nearPSD`` on symmetric matrices (two indefinite ones among
+    them) and ``_get_correlations``."""
+    from pandas import DataFrame
+    from metran.solver import BaseSolver
+
+    out = {}
+    sol = BaseSolver(mt=None)
+    full = lambda p, callback: float(solver_objective(callback(p))[0])
+    ident = lambda p: p
+    x0 = np.array([5.2, 11.5, 7.3, 19.0])
+    out["x0"] = x0.copy()
+    out["cov_full"] = sol._get_covariance(x0.copy(), full, ident)
+    # parameter 1 fixed at 12.5: the callback scatters the three varying values into the full vector (_array_todict, :290-305)
+    vary = np.array([True, False, True, True])
+    initial = np.array([0.0, 12.5, 0.0, 0.0])
+
+    def todict(p):
+        par = initial.copy()
+        par[vary] = p
+        return par
+
+    out["vary"], out["initial"] = vary, initial
+    out["cov_fixed"] = sol._get_covariance(x0[vary].copy(), full, todict)
+    # _nearPSD / _get_correlations
+    rng = np.random.default_rng(5)
+    mats = []
+    for k in range(4):
+        M = rng.standard_normal((4, 4))
+        M = 0.5 * (M + M.T) + (3.0, 3.0, 0.0, 1.2)[k] * np.eye(4)   # two positive definite, two indefinite
+        mats.append(M)
+    out["psd_in"] = np.stack(mats)
+    out["psd_out"] = np.stack([BaseSolver._nearPSD(M.copy()) for M in mats])
+    names = ["a", "b", "c", "d"]
+    out["pcor"] = BaseSolver._get_correlations(DataFrame(out["cov_full"], index=names, columns=names)).values.astype(float)
+    np.savez_compressed(os.path.join(HERE, "solver_covariance.npz"), **out)
+    print("solver_covariance: stderr", np.sqrt(np.diag(out["cov_full"])), "| nearPSD of an indefinite matrix:\n", out["psd_out"][2])
 
 
 def g2_seeded():
@@ -621,6 +664,7 @@ if __name__ == "__main__":
     factor_multi()
     g1_real()
     g1_solve()
+    solver_covariance()
     g2_seeded()
     # C2 shape (8 series / 2 factors), small T: every array, every step
     synthetic_case("c2_small.npz", 8, 2, 48, seed=2000, models=[0, 1, 2])
