@@ -23,7 +23,7 @@ __all__ = ["calibrate_batch", "calibrate_sharded", "calibrate_shared", "Calibrat
 
 
 class CalibrationResult(dict):
-    """``alpha [R,P]``, ``obj [R]`` (-2 log L), ``grad [R,P]``, ``converged [R]`` (bool), ``nit``,
+    """``alpha [R,P]``, ``obj [R]`` (-2 log L), ``grad [R,P]``, ``converged [R]`` (bool; False too where the objective is not finite), ``nit``,
     ``nfev`` (filter instances evaluated in total), ``launches``, ``aic [R]`` (= 2P + obj, solver.py:280)."""
 
     __getattr__ = dict.__getitem__
@@ -258,7 +258,10 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     kf, R, x, f, g, active = kf0, R0, X_all, F_all, G_all, active_all
     lo = torch.full((R, n), float(pmin), **f64) if np.isscalar(pmin) else kf._dev(pmin, (R, n), "pmin")
     pg = proj_grad(x, g)
-    res = CalibrationResult(alpha=x, obj=f, grad=g, converged=~active, nit=nit, nfev=nfev, launches=launches,
+    # a model whose objective is not a number (communalities above 1 give negative transition variances, say) leaves the
+    # flight at once -- NaN compares false with gtol -- but it has not converged (scipy: ABNORMAL_TERMINATION, success False)
+    finite = torch.isfinite(f) & torch.isfinite(g).all(1)
+    res = CalibrationResult(alpha=x, obj=f, grad=g, converged=~active & finite, nit=nit, nfev=nfev, launches=launches,
                             aic=2 * n + f, pgnorm=pg.abs().amax(1))
     if stderr:
         # the Hessian is differenced from the exact (adjoint) gradient whatever gradient the ITERATION used

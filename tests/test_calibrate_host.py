@@ -128,6 +128,46 @@ def test_active_bounds(models):
     assert np.any(x <= pmin)
 
 
+def test_a_model_without_a_finite_objective_is_not_converged(models):
+    """Communalities above 1 (negative transition variances): the objective is NaN from the first evaluation.  The model drops
+    out of the flight at once, keeps its start point, and is NOT reported converged; its neighbours are unaffected."""
+    obs, load = models
+    bad = load.copy()
+    bad[1] = 1.3
+    res = calibrate_batch(OracleEngine(obs, bad), gradient="adjoint", compact=0)
+    good = calibrate_batch(OracleEngine(obs, load), gradient="adjoint", compact=0)
+    assert not bool(res.converged[1]) and not np.isfinite(float(res.obj[1])) and torch.equal(res.alpha[1], torch.full((4,), 10.0, dtype=torch.float64))
+    keep = [0, 2, 3, 4]
+    assert bool(res.converged[keep].all()) and torch.equal(res.alpha[keep], good.alpha[keep])
+
+
+def test_iteration_limit_and_standard_errors(models):
+    """``maxiter`` reached: nobody is converged, the iterates are the first ones of the full run; ``stderr=True`` differences
+    the exact gradient into a Hessian -- against a central-difference Hessian of the oracle's objective."""
+    obs, load = models
+    short = calibrate_batch(OracleEngine(obs, load), gradient="adjoint", compact=0, maxiter=3)
+    assert short.nit == 3 and not bool(short.converged.any())
+    eng = OracleEngine(obs, load)
+    res = calibrate_batch(eng, gradient="adjoint", compact=0, stderr=True)
+    assert bool(res.converged.all()) and bool((res.obj < short.obj).all())
+    assert eng.log[-1] == ("forward+backward", (eng.n + 1) * eng.R)      # the Hessian's n + 1 gradients: one launch pair
+    r = 2
+
+    def f(a):
+        phi, q = phi_q_from_alpha(a[None], load[r][None])
+        return float(oracle.dfm_batch(obs[r][None], phi, q, load[r][None], smooth=False, outputs="mle")["mle"][0])
+
+    x, h = res.alpha[r].numpy(), 1e-3
+    H = np.empty((4, 4))
+    for i in range(4):
+        for j in range(4):
+            ei, ej = np.eye(4)[i] * h * x[i], np.eye(4)[j] * h * x[j]
+            H[i, j] = (f(x + ei + ej) - f(x + ei - ej) - f(x - ei + ej) + f(x - ei - ej)) / (4 * h * h * x[i] * x[j])
+    want = np.sqrt(np.diag(np.linalg.pinv(H)))
+    np.testing.assert_allclose(res.stderr[r].numpy(), want, rtol=2e-2)
+    assert res.pcov.shape == (5, 4, 4)
+
+
 def test_unknown_gradient_mode(models):
     with pytest.raises(ValueError):
         calibrate_batch(OracleEngine(*models), gradient="central")

@@ -196,3 +196,52 @@ def test_sharded_and_shared_calibration_world2(tmp_path):
     x = c0[1:-1]
     assert abs(c0[0] - total(x)) <= 1e-9 * abs(c0[0])       # the reported optimum is the summed objective there
     assert c0[0] < total(np.full(N + K, 10.0)) - 1e-3        # and it improved on the start
+
+
+def _worker_calibrate_sharded(rank, world, port, out_dir):
+    """``calibrate_sharded`` ITSELF on 2 CPU ranks: every rank builds an engine over its slice of the models (the oracle-backed
+    stand-in of tests/oracle_engine.py where the GPU box has ``BatchedKalman``), runs ``calibrate_batch`` on it, and the
+    per-model results come back in model order on every rank."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from metran_amd.calibrate import calibrate_sharded
+    from metran_amd.distributed import init_from_env
+    from metran_amd.synthetic import make_dfm_batch
+    from oracle_engine import OracleEngine
+
+    init_from_env(backend="gloo")
+    Bc = 5                                              # shards of 3 and 2
+    built = []
+
+    def build_engine(lo, hi):
+        built.append((lo, hi))
+        d = make_dfm_batch(hi - lo, 3, 1, 120, seed=SEED + 11, missing=0.2, start=lo)   # this rank's records only
+        return OracleEngine(d["obs"], d["loadings"])
+
+    res = calibrate_sharded(Bc, build_engine, gradient="adjoint", compact=0, stderr=False)
+    assert built == [((0, 3), (3, 5))[rank]] and res.shard == built[0]
+    assert res.alpha.shape == (Bc, 4) and res.converged.dtype == torch.bool and res.aic.shape == (Bc,)
+    np.save(os.path.join(out_dir, "s%d.npy" % rank),
+            np.c_[res.alpha.numpy(), res.obj.numpy(), res.pgnorm.numpy(), res.converged.numpy().astype(float)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_calibrate_sharded_world2_equals_the_single_process_run(tmp_path):
+    world = 2
+    mp.spawn(_worker_calibrate_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    s0, s1 = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
+    np.testing.assert_array_equal(s0, s1)               # every rank holds every model's result
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from metran_amd.calibrate import calibrate_batch
+    from metran_amd.synthetic import make_dfm_batch
+    from oracle_engine import OracleEngine
+
+    d = make_dfm_batch(5, 3, 1, 120, seed=SEED + 11, missing=0.2)
+    one = calibrate_batch(OracleEngine(d["obs"], d["loadings"]), gradient="adjoint", compact=0)
+    assert bool(one.converged.all()) and np.all(s0[:, 6] == 1.0)
+    # per-model parameters: a model's iterates do not depend on which flight it rides in
+    np.testing.assert_allclose(s0[:, :4], one.alpha.numpy(), rtol=1e-9)
+    np.testing.assert_allclose(s0[:, 4], one.obj.numpy(), rtol=1e-12)
