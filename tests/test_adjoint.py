@@ -30,6 +30,59 @@ def test_numpy_adjoint_matches_central_differences_of_the_oracle():
                 assert abs(g[i] - fd) <= 2e-6 * max(1.0, abs(fd)), (seed, i, g[i], fd)
 
 
+def test_numpy_adjoint_property():
+    """Property test (hypothesis, derandomised) of the backward pass's restatement -- the thing the GPU kernels are compared
+    with: any small shape and missingness pattern (whole steps empty, the first among them), warm-up 0..3 (the compressed
+    warm-up index of get_mle, kalmanfilter.py:550-567), a given initial state and covariance, observation variances: the gradient
+    w.r.t. phi and q equals central differences of the forward recursion, whose value is the oracle's where the oracle takes
+    the same arguments."""
+    from hypothesis import given, settings, strategies as st
+
+    @st.composite
+    def case(draw):
+        N, K, T = draw(st.integers(1, 4)), draw(st.integers(1, 2)), draw(st.integers(1, 10))
+        rng = np.random.default_rng(draw(st.integers(0, 2 ** 31 - 1)))
+        n = N + K
+        G = rng.uniform(0.2, 0.6, (N, K)) / np.sqrt(K)
+        phi = np.exp(-1.0 / rng.uniform(0.7, 40.0, n))
+        q = (1.0 - phi ** 2) * np.r_[1.0 - (G ** 2).sum(1), np.ones(K)]
+        y = rng.standard_normal((T, N))
+        y[rng.random((T, N)) < draw(st.sampled_from([0.0, 0.3, 0.8]))] = np.nan
+        if draw(st.booleans()):
+            y[rng.random(T) < 0.4] = np.nan
+        if draw(st.booleans()):
+            y[0] = np.nan
+        x0 = P0 = R = None
+        if draw(st.booleans()):
+            x0 = rng.standard_normal(n)
+            A = rng.standard_normal((n, n))
+            P0 = A @ A.T / n + 0.1 * np.eye(n)
+        if draw(st.booleans()):
+            R = rng.uniform(0.0, 0.4, N) * (rng.random(N) < 0.6)
+        return y, phi, q, G, draw(st.integers(0, 3)), x0, P0, R
+
+    @settings(max_examples=150, deadline=None, derandomize=True)
+    @given(case())
+    def check(c):
+        y, phi, q, G, warmup, x0, P0, R = c
+        mle, gphi, gq = adjoint_ref.gradient(y, phi, q, G, warmup=warmup, x0=x0, P0=P0, R=R)
+        if x0 is None:
+            ref = oracle.dfm_batch(y[None], phi[None], q[None], G[None], obsvar=None if R is None else R[None], warmup=warmup,
+                                   smooth=False, outputs="mle")["mle"][0]
+            assert abs(mle - ref) <= 1e-10 * max(1.0, abs(ref))
+        f = lambda ph, qq: adjoint_ref.forward(y, ph, qq, G, warmup, x0, P0, R)[0]  # noqa: E731
+        for i in range(len(phi)):
+            for vec, g in ((phi, gphi), (q, gq)):
+                h = 1e-5 * max(abs(vec[i]), 1e-2)
+                up, dn = vec.copy(), vec.copy()
+                up[i] += h
+                dn[i] -= h
+                fd = ((f(up, q) - f(dn, q)) if vec is phi else (f(phi, up) - f(phi, dn))) / (2 * h)
+                assert abs(g[i] - fd) <= 1e-5 * max(1.0, abs(fd)), (i, vec is phi, g[i], fd)
+
+    check()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["model_major", "time_major"])
 @pytest.mark.parametrize("N,K,T,B,missing,first", [(8, 2, 120, 37, 0.0, "full"), (8, 2, 90, 21, 0.3, "random"),
