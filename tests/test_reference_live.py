@@ -41,6 +41,68 @@ def test_oracle_vs_reference_random(metran):
         assert abs(r["mle"][0] - kf.get_mle()) <= 1e-12 * abs(kf.get_mle())
 
 
+def test_oracle_vs_reference_property(metran):
+    """Hypothesis (derandomised): any small shape, observation variances, whole steps / the first step / whole series without an
+    observation, warm-up 0..3: the oracle's filter is the reference's ``seqkalmanfilter`` bit for bit, its smoother, -2 log L,
+    ``simulate`` and ``decompose`` to rounding (the smoother's inverse: scaled by min(q), see test_dk_tape's property test)."""
+    import pandas as pd
+    from hypothesis import given, settings, strategies as st
+
+    import oracle
+    from metran_amd.params import observation_matrix
+
+    kfm = metran.kalmanfilter
+
+    @st.composite
+    def case(draw):
+        N, K, T = draw(st.integers(2, 6)), draw(st.integers(1, 3)), draw(st.integers(2, 16))
+        rng = np.random.default_rng(draw(st.integers(0, 2 ** 31 - 1)))
+        load = rng.uniform(0.2, 0.7, (N, K)) / np.sqrt(K)
+        phi = np.exp(-1.0 / rng.uniform(0.5, 200.0, N + K))
+        q = (1.0 - phi ** 2) * np.r_[1.0 - (load ** 2).sum(1), np.ones(K)]
+        y = rng.standard_normal((T, N))
+        y[rng.random((T, N)) < draw(st.sampled_from([0.0, 0.3, 0.85]))] = np.nan
+        if draw(st.booleans()):
+            y[rng.random(T) < 0.4] = np.nan
+        if draw(st.booleans()):
+            y[0] = np.nan
+        if draw(st.booleans()):
+            y[:, rng.integers(N)] = np.nan
+        R = rng.uniform(0.0, 0.4, N) * (rng.random(N) < 0.6) if draw(st.booleans()) else np.zeros(N)
+        return y, phi, q, load, R, draw(st.integers(0, 3))
+
+    @settings(max_examples=60, deadline=None, derandomize=True)
+    @given(case())
+    def check(c):
+        y, phi, q, load, R, warmup = c
+        N = y.shape[1]
+        kf = kfm.SPKalmanFilter(engine="numpy")
+        kf.filtermethod = kfm.seqkalmanfilter
+        kf.set_observations(pd.DataFrame(y))
+        Z = observation_matrix(load)
+        kf.set_matrices(np.diag(phi), np.diag(q), Z, R)
+        kf.run_smoother()
+        r = oracle.dfm_batch(y[None], phi[None], q[None], load[None], obsvar=R[None], warmup=warmup)
+        np.testing.assert_array_equal(r["F"][0], kf.filtered_state_means)
+        np.testing.assert_array_equal(r["Pf"][0], kf.filtered_state_covariances)
+        np.testing.assert_array_equal(r["Pp"][0], kf.predicted_state_covariances)
+        tol = 1e-11 + 1e-15 / float(q.min())
+        np.testing.assert_allclose(r["S"][0], kf.smoothed_state_means, atol=tol)
+        np.testing.assert_allclose(r["Ps"][0], kf.smoothed_state_covariances, atol=tol)
+        want = kf.get_mle(warmup=warmup)
+        assert abs(r["mle"][0] - want) <= 1e-12 * max(1.0, abs(want))
+        sm, sv = kf.simulate(Z)
+        om, ov = oracle.simulate(Z, r["S"][0], r["Ps"][0])
+        np.testing.assert_allclose(om, np.asarray(sm), atol=tol)
+        np.testing.assert_allclose(ov, np.asarray(sv), atol=tol)
+        sdf, cdf = kf.decompose(Z)
+        osdf, ocdf = oracle.decompose(Z, r["S"][0])
+        np.testing.assert_allclose(osdf, np.asarray(sdf), atol=tol)
+        np.testing.assert_allclose(ocdf, np.asarray(cdf), atol=tol)
+
+    check()
+
+
 def test_install_patches_the_plug_points(metran):
     """The three globals that INTEGRATION.md section 2 replaces exist and are what
     SPKalmanFilter binds (kalmanfilter.py:501-504, :685)."""
