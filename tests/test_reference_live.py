@@ -142,6 +142,45 @@ def test_observation_packing_property(metran):
     check()
 
 
+def test_solver_plug_point_through_the_real_class(metran):
+    """``Metran.solve(solver=...)`` of the unmodified reference class with ``HipSolve`` (its engine replaced by the oracle-backed
+    stand-in -- no GPU here; the GPU tier does the same with the real engine on examples/data) against the class's own
+    ``ScipySolve`` on a fresh synthetic data set for which the reference's factor analysis finds TWO factors: same number of
+    objective evaluations, same optimum, and ``fit_report`` renders from the attributes the solver leaves."""
+    import pandas as pd
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+
+    from metran_amd.solver import BatchObjective, HipSolve, _obs_from, _state_order
+    from metran_amd.synthetic import make_dfm
+
+    y, *_ = make_dfm(4, 1, 200, 77, 0, 0.2, "observed")
+    idx = pd.date_range("2001-01-01", periods=200, freq="D")
+    series = [pd.Series(y[:, j] * (1 + j) + 3 * j, index=idx, name="w%d" % j).dropna() for j in range(4)]
+    ref = metran.Metran(series, name="syn")
+    ref.solve(report=False, engine="numpy")
+    assert ref.nfactors == 2
+
+    class Solve(HipSolve):
+        def _objective(self):
+            if self._obj is None:
+                self._obj = BatchObjective(_obs_from(self.mt), self.mt.factors, order=_state_order(self.mt), dt=1.0,
+                                           engine=OracleEngine())
+            return self._obj
+
+    mt = metran.Metran(series, name="syn")
+    mt.solve(solver=Solve, report=False, engine="numpy")
+    assert mt.fit.nfev == ref.fit.nfev and mt.fit.nfev % 7 == 0          # P + 1 = 7 instances per gradient launch
+    assert mt.fit.launches == mt.fit.nfev // 7
+    assert abs(mt.fit.obj_func - ref.fit.obj_func) <= 1e-7 * abs(ref.fit.obj_func)
+    np.testing.assert_allclose(mt.parameters["optimal"].values.astype(float), ref.parameters["optimal"].values.astype(float),
+                               rtol=2e-3)
+    assert abs(mt.fit.aic - ref.fit.aic) <= 1e-6 * abs(ref.fit.aic)
+    report = mt.fit_report()
+    assert "nfev" in report and "Solve" in report
+
+
 def test_install_patches_the_plug_points(metran):
     """The three globals that INTEGRATION.md section 2 replaces exist and are what
     SPKalmanFilter binds (kalmanfilter.py:501-504, :685)."""
