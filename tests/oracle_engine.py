@@ -102,3 +102,71 @@ class OracleEngine:
         self._pending = None                             # one backward pass per forward pass, like the engine
         self.log.append(("backward", int(alpha.shape[0])))
         return self._grad(alpha, dt, warmup)[1]
+
+
+class OracleFilterEngine:
+    """The slice of ``BatchedKalman`` that the drop-in layer touches (``metran_amd.kalmanfilter``: ``seqkalmanfilter_hip``,
+    ``kalmansmoother_hip``, the ``SPKalmanFilter`` mirror), for ONE record: ``set_observations`` / ``set_loadings`` / ``filter``
+    / ``smooth`` / ``filter_smooth`` / ``simulate`` / ``decompose`` answered by the C oracle's per-model entry points.
+    ``uploads`` counts ``set_observations`` calls with host data (the upload cache's business)."""
+
+    def __init__(self):
+        self.obs = None
+        self.uploads = 0
+        self.calls = []
+
+    def set_observations(self, obs):
+        if isinstance(obs, torch.Tensor):                # "already resident": the mirror hands back what it got from us
+            self.obs = obs
+            return self
+        self.uploads += 1
+        self.obs = torch.from_numpy(np.array(obs, dtype=np.float64))
+        self.R, self.T, self.N = self.obs.shape
+        assert self.R == 1
+        return self
+
+    def set_loadings(self, loadings, obsvar=None):
+        self.loadings = np.asarray(loadings, float)[0]
+        self.obsvar = np.zeros(self.N) if obsvar is None else np.asarray(obsvar, float)[0]
+        self.K = self.loadings.shape[1]
+        return self
+
+    def _Z(self):
+        return np.concatenate([np.eye(self.N), self.loadings], axis=1)
+
+    def filter(self, phi, q, warmup=1, x0=None, P0=None):
+        self.calls.append("filter")
+        n = self.N + self.K
+        o, oi, oc = oracle.set_observations(self.obs[0].numpy())
+        x0 = np.zeros(n) if x0 is None else np.asarray(x0, float)[0]
+        P0 = np.eye(n) if P0 is None else np.asarray(P0, float)[0]
+        sg, df, sc, F, Pf, Xp, Pp = oracle.seqkalmanfilter(o, np.diag(phi[0]), np.diag(q[0]), self._Z(), self.obsvar, oi, oc, x0, P0)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None]  # noqa: E731
+        mle = oracle.get_mle(sg[:sc], df[:sc], oc, warmup)
+        bad = not np.all(np.isfinite(df[:sc]))
+        return {"sigmas": t(sg), "detfs": t(df), "sigmacount": torch.tensor([sc]), "F": t(F), "Pf": t(Pf), "Xp": t(Xp), "Pp": t(Pp),
+                "mle": torch.tensor([mle]), "status": torch.tensor([1 if bad else 0], dtype=torch.int32)}
+
+    def smooth(self, phi, q, F, Pf):
+        self.calls.append("smooth")
+        F = (F[0].numpy() if isinstance(F, torch.Tensor) else np.asarray(F)[0])
+        Pf = (Pf[0].numpy() if isinstance(Pf, torch.Tensor) else np.asarray(Pf)[0])
+        ph, qq = np.asarray(phi, float)[0], np.asarray(q, float)[0]
+        Xp = np.vstack([np.zeros((1, F.shape[1])), F[:-1] * ph])                       # predicted moments from the filtered ones
+        Pp = np.concatenate([np.eye(F.shape[1])[None], Pf[:-1] * np.outer(ph, ph) + np.diag(qq)])
+        S, Ps = oracle.kalmansmoother(F, Pf, Xp, Pp, np.diag(ph))
+        return {"S": torch.from_numpy(S)[None], "Ps": torch.from_numpy(Ps)[None], "status": torch.zeros(1, dtype=torch.int32)}
+
+    def filter_smooth(self, phi, q, warmup=1):
+        r = self.filter(phi, q, warmup)
+        S, Ps = oracle.kalmansmoother(r["F"][0].numpy(), r["Pf"][0].numpy(), r["Xp"][0].numpy(), r["Pp"][0].numpy(), np.diag(phi[0]))
+        r["S"], r["Ps"] = torch.from_numpy(S)[None], torch.from_numpy(Ps)[None]
+        return r
+
+    def simulate(self, Z, means, covariances):
+        sm, sv = oracle.simulate(Z, means[0], covariances[0])
+        return torch.from_numpy(sm)[None], torch.from_numpy(sv)[None]
+
+    def decompose(self, Z, means):
+        sdf, cdf = oracle.decompose(Z, means[0])
+        return torch.from_numpy(sdf)[None], torch.from_numpy(cdf)[None]

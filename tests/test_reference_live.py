@@ -181,6 +181,64 @@ def test_solver_plug_point_through_the_real_class(metran):
     assert "nfev" in report and "Solve" in report
 
 
+def test_engine_plug_point_through_the_real_class(metran):
+    """``kalmanfilter.install`` on the CPU: the three globals of the reference module replaced by the drop-in functions, their
+    device engine by the oracle-backed stand-in (tests/oracle_engine.py) -- the HOST side of the engine plug point (diagonal
+    extraction, the NaN-encoded record, the upload cache keyed on content, the smoother's reuse of the preceding filter call)
+    under the unmodified ``Metran`` class on examples/data: ``solve`` + ``get_simulation`` + a mask / unmask cycle."""
+    import pandas as pd
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import metran_amd.kalmanfilter as hk
+    from oracle_engine import OracleFilterEngine
+
+    d = os.path.join(_refshim.REFERENCE_ROOT, "examples", "data")
+    series = []
+    for i in range(1, 6):
+        s = pd.read_csv(os.path.join(d, "B21B021400%d_res.csv" % i), index_col=0, parse_dates=True).squeeze()
+        s.name = "B21B021400%d" % i
+        series.append(s)
+    ref = metran.Metran(series, name="B21B0214")
+    ref.solve(report=False, engine="numpy")
+    popt = ref.parameters["optimal"]
+    sim_ref = ref.get_simulation("B21B0214005", p=popt, alpha=0.05)
+    mask = (0 * ref.get_observations()).astype(bool)
+    mask.loc["1997-8-28", "B21B0214005"] = True
+    ref.mask_observations(mask)
+    masked_ref = ref.get_simulation("B21B0214005", p=popt, alpha=0.05)
+    masked_mle = ref.get_mle(popt)
+    ref.unmask_observations()
+
+    eng = OracleFilterEngine()
+    saved = (hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER)
+    hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = eng, None, None
+    hk.install(metran)
+    try:
+        mt = metran.Metran(series, name="B21B0214")
+        mt.solve(report=False, engine="numpy")
+        assert mt.fit.nfev == ref.fit.nfev == 77 and abs(mt.fit.obj_func - 2332.3270694) < 1e-6
+        assert eng.uploads == 1                          # ~80 filter calls, one upload: same content, same record
+        # (the band is mean -+ z sqrt(variance): where a series is observed its smoothed variance is rounding noise around 0,
+        #  1e-15, and the square root turns that into 1e-8 on the bounds -- hence 5e-7 here, 1e-9 on the means)
+        sim = mt.get_simulation("B21B0214005", p=popt, alpha=0.05)
+        np.testing.assert_allclose(sim["mean"].values, sim_ref["mean"].values, atol=1e-9)
+        np.testing.assert_allclose(sim.values, sim_ref.values, atol=5e-7)
+        assert eng.calls[-2:] == ["filter", "smooth"] and eng.uploads == 1
+        mt.mask_observations(mask)                       # new content at (possibly) recycled addresses: must be uploaded
+        masked = mt.get_simulation("B21B0214005", p=popt, alpha=0.05)
+        assert eng.uploads == 2
+        np.testing.assert_allclose(masked.values, masked_ref.values, atol=5e-7)
+        assert abs(mt.get_mle(popt) - masked_mle) <= 1e-10 * abs(masked_mle) and eng.uploads == 2
+        mt.unmask_observations()
+        back = mt.get_simulation("B21B0214005", p=popt, alpha=0.05)
+        assert eng.uploads == 3
+        np.testing.assert_allclose(back.values, sim_ref.values, atol=5e-7)
+    finally:
+        hk.uninstall(metran)
+        hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = saved
+    assert metran.kalmanfilter.seqkalmanfilter is not hk.seqkalmanfilter_hip
+
+
 def test_install_patches_the_plug_points(metran):
     """The three globals that INTEGRATION.md section 2 replaces exist and are what
     SPKalmanFilter binds (kalmanfilter.py:501-504, :685)."""
