@@ -145,7 +145,7 @@ class OracleFilterEngine:
         mle = oracle.get_mle(sg[:sc], df[:sc], oc, warmup)
         bad = not np.all(np.isfinite(df[:sc]))
         return {"sigmas": t(sg), "detfs": t(df), "sigmacount": torch.tensor([sc]), "F": t(F), "Pf": t(Pf), "Xp": t(Xp), "Pp": t(Pp),
-                "mle": torch.tensor([mle]), "status": torch.tensor([1 if bad else 0], dtype=torch.int32)}
+                "mle": torch.tensor([mle], dtype=torch.float64), "status": torch.tensor([1 if bad else 0], dtype=torch.int32)}
 
     def smooth(self, phi, q, F, Pf):
         self.calls.append("smooth")

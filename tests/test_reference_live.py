@@ -239,6 +239,60 @@ def test_engine_plug_point_through_the_real_class(metran):
     assert metran.kalmanfilter.seqkalmanfilter is not hk.seqkalmanfilter_hip
 
 
+def test_mirror_class_against_the_reference_class(metran):
+    """``metran_amd.kalmanfilter.SPKalmanFilter`` (the mirror a user constructs directly) over the stand-in engine against the
+    reference class, attribute by attribute, on models with empty steps and observation variances: ``run_filter`` (with and
+    without initial moments), ``run_smoother``, ``get_mle`` at several warm-ups, ``simulate`` / ``decompose`` by both methods."""
+    import pandas as pd
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import metran_amd.kalmanfilter as hk
+    from oracle_engine import OracleFilterEngine
+
+    from metran_amd.params import observation_matrix
+    from metran_amd.synthetic import make_dfm
+
+    saved = (hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER)
+    try:
+        for seed, (N, K, T, miss, first) in enumerate([(5, 2, 60, 0.4, "empty"), (3, 1, 30, 0.0, "observed"), (6, 1, 45, 0.7, "random")]):
+            y, _, load, phi, q = make_dfm(N, K, T, 300 + seed, 0, miss, first)
+            R = np.random.default_rng(seed).uniform(0.0, 0.2, N) * (seed != 1)
+            Z = observation_matrix(load)
+            frame = pd.DataFrame(y, index=pd.date_range("2000-01-01", periods=T, freq="D"))
+            ref = metran.kalmanfilter.SPKalmanFilter(engine="numpy")
+            hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = OracleFilterEngine(), None, None
+            mir = hk.SPKalmanFilter(engine="hip")
+            for kf in (ref, mir):
+                kf.set_observations(frame)
+                kf.set_matrices(np.diag(phi), np.diag(q), Z, R)
+            x0 = np.linspace(-0.5, 0.5, N + K)
+            P0 = np.eye(N + K) * 0.7 + 0.1
+            for init in ((None, None), (x0, P0)):
+                ref.run_filter(*init)
+                mir.run_filter(*init)
+                for a in ("filtered_state_means", "filtered_state_covariances", "predicted_state_means",
+                          "predicted_state_covariances", "sigmas", "detfs"):
+                    np.testing.assert_allclose(getattr(mir, a), getattr(ref, a), rtol=0, atol=1e-13, err_msg=a)
+                for w in (0, 1, 2, 5):
+                    assert abs(mir.get_mle(warmup=w) - ref.get_mle(warmup=w)) <= 1e-12 * max(1.0, abs(ref.get_mle(warmup=w)))
+            ref.run_smoother()
+            mir.run_smoother()
+            np.testing.assert_allclose(mir.smoothed_state_means, ref.smoothed_state_means, atol=1e-11)
+            np.testing.assert_allclose(mir.smoothed_state_covariances, ref.smoothed_state_covariances, atol=1e-11)
+            assert mir.nstate == ref.nstate and (mir.oseries_index == ref.oseries_index).all()
+            for method in ("filter", "smoother"):
+                a, b = mir.simulate(Z, method=method), ref.simulate(Z, method=method)
+                np.testing.assert_allclose(np.asarray(a[0]), np.asarray(b[0]), atol=1e-11)
+                np.testing.assert_allclose(np.asarray(a[1]), np.asarray(b[1]), atol=1e-11)
+                a, b = mir.decompose(Z, method=method), ref.decompose(Z, method=method)
+                np.testing.assert_allclose(np.asarray(a[0]), np.asarray(b[0]), atol=1e-11)
+                np.testing.assert_allclose(np.asarray(a[1]), np.asarray(b[1]), atol=1e-11)
+            with pytest.raises(Exception, match="Unknown engine"):
+                mir.run_filter(engine="numba")
+    finally:
+        hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = saved
+
+
 def test_install_patches_the_plug_points(metran):
     """The three globals that INTEGRATION.md section 2 replaces exist and are what
     SPKalmanFilter binds (kalmanfilter.py:501-504, :685)."""
