@@ -522,6 +522,66 @@ def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=5, warmu
     return out
 
 
+def secondary_state_variances(local_rank, rank, dev, layout, sync, B=4096, N=32, K=4, T=2000, missing=0.3, steps=5, warmup=2,
+                              n_check=24, projection_path="auto"):
+    """configs[3]'s batch through ``smooth_state_variances``: the smoothed STATE means and variances
+    [B,T,n] that ``Metran.get_state_means / get_state_variances / get_state`` consume (metran.py:655-756), on the state-tape
+    path (``MK_OUT_TAPE | MK_OUT_VAR_ONLY``: filter_split_kernel writing N + K entries per step, smoother_dk_kernel<..,STATE>)
+    -- or, with ``projection_path="records"``, on filtered records + the RTS kernel, the path it replaces.  Kernel ms from
+    hipEvents, models/s from the wall clock of the timed region, SURVEY 8d's full-output accounting next to the bar, and the
+    error against the oracle (reference kalmansmoother, kalmanfilter.py:403-476) on ``n_check`` models spread over the batch."""
+    import numpy as np
+    import torch
+
+    import oracle
+    from metran_amd.engine import BatchedKalman
+    from metran_amd.synthetic import make_dfm_batch_torch
+
+    d = make_dfm_batch_torch(B, N, K, T, seed=2000 + rank, device=dev, missing=missing)
+    kf = BatchedKalman(local_rank, layout=layout)
+    kf.projection_path = projection_path
+    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+    try:
+        state_tape = kf.state_tape_path()
+        bufs = kf.alloc_state_variances(B)
+
+        class W:  # what timed_run drives
+            pass
+        w = W()
+        w.kf = kf
+        w.step = lambda: kf.smooth_state_variances(d["phi"], d["q"], buffers=bufs)
+        elapsed, f_avg, s_avg = timed_run(w, steps, warmup, sync)
+        n = N + K
+        b_fs = 8 * T * (N + 4 * (n + n * n))
+        rate = B * steps / elapsed
+        idx = sample_models(B, n_check)
+        t0 = time.perf_counter()
+        ref = oracle.dfm_batch(d["obs"][idx].cpu().numpy(), d["phi"][idx].cpu().numpy(), d["q"][idx].cpu().numpy(),
+                               d["loadings"][idx].cpu().numpy())
+        out = {"workload": "batch=%d synthetic %d-series/%d-factor DFMs, %d %% missing, T=%d, fp64: smoothed state means + variances "
+                           "[B,T,n] (MK_OUT_VAR_ONLY), %s" % (B, N, K, round(100 * missing), T,
+                                                             "filter writing the STATE tape + inverse-free backward pass" if state_tape
+                                                             else "filter (filtered record) + RTS smoother"),
+               "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "models_per_s": rate,
+               "filter_ms": f_avg, "smoother_ms": s_avg, "state_tape": bool(state_tape),
+               "survey_8d_full_output_accounting": {
+                   "bytes_per_model": b_fs, "frac_of_peak": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3) / HBM_PEAK_GBS,
+                   "north_star_bar": {"frac_of_peak": 0.40, "models_per_s": 0.40 * HBM_PEAK_GBS * 1e9 / b_fs}},
+               "moved_GB": {"filter": B * 8 * T * (N + (N + K) * (n + 4)) / 1e9 if state_tape else B * 8 * T * (N + n + n * n) / 1e9,
+                            "smoother": B * 8 * T * ((N + K) * (n + 4) + 2 * n) / 1e9 if state_tape else B * 8 * T * (n + n * n + 2 * n) / 1e9},
+               "parity": {"models_compared": int(len(idx)),
+                          "loglik_max_rel_err": float(np.max(np.abs(bufs["mle"][idx].cpu().numpy() - ref["mle"]) / np.abs(ref["mle"]))),
+                          "state_means_max_abs_err": float(np.max(np.abs(bufs["S"][idx].cpu().numpy() - ref["S"]))),
+                          "state_vars_max_abs_err": float(np.max(np.abs(bufs["var"][idx].cpu().numpy()
+                                                                        - np.diagonal(ref["Ps"], axis1=2, axis2=3)))),
+                          "checker": "oracle/kalman_oracle.c, %.1f s on the host" % (time.perf_counter() - t0)}}
+        return out
+    finally:
+        kf.close()
+        del d
+        torch.cuda.empty_cache()
+
+
 def measure_transfers(dev, B, T, N, K, ms_per_step):
     """Opt-in (``--transfers``): what a caller that starts and ends on the HOST pays on top of the HBM-resident pass
     (never ``value``): the observation upload and the download of the results over the host link,
@@ -748,7 +808,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: c2 (BASELINE configs[1], 4096 models per GPU) -- except with --gpus 8, where it is c3 = configs[2]'s "
+                         "per-GPU share (65536 models over 8 GPUs = 8192 per GPU), so that the driver's 8-GPU run lands on the "
+                         "BASELINE configuration without a flag")
     ap.add_argument("--batch", type=int, default=None, help="models per GPU (default: the configuration's)")
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--packed-sym", action="store_true",
@@ -766,6 +829,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU (gloo): launch, barrier, max-over-ranks, one JSON line with value null")
     args = ap.parse_args()
+    config_defaulted = args.config is None
+    if config_defaulted:
+        args.config = "c3" if args.gpus == 8 else "c2"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -869,6 +935,10 @@ def main():
         ms_per_step = 1e3 * elapsed / steps
         models_per_s = world * B * units * steps / elapsed
         workload = w.describe() if w is not None else "dry run of %s" % BASELINE_NAME[args.config]
+        if config_defaulted and args.gpus == 8:
+            workload += (" [default of --gpus 8: configs[2] = 65536 models over 8 GPUs; the 1/2/4-GPU lines of the same sweep "
+                         "default to configs[1]'s 4096 models per GPU -- per-GPU kernel rates of the two are equal within 2 %, "
+                         "profiles/r04/bench_c3.json]")
         res = {
             "metric": "Kalman filter+smoother steps/sec (batched DFMs)",
             "value": None if args.dry_run else models_per_s * T,
@@ -927,7 +997,8 @@ def main():
                 res["secondary"][name] = secondary_workload(name, local_rank, rank, dev, args.layout, sync)
             except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure here
                 res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
-        for name, fn in (("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
+        for name, fn in (("c4_state_variances", lambda: secondary_state_variances(local_rank, rank, dev, args.layout, sync)),
+                         ("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
                          ("f4_factor_analysis_32x4", lambda: secondary_factor_analysis(dev, N=32, K=4, reps=2, scipy_subset=256)),
                          ("f1_calibration", lambda: secondary_calibration(local_rank, dev)),
                          ("c1_dropin", secondary_dropin)):

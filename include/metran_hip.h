@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define MK_API __attribute__((visibility("default")))
-#define MK_ABI_VERSION 5
+#define MK_ABI_VERSION 6
 
 typedef enum mk_status {
     MK_OK = 0,
@@ -146,7 +146,16 @@ typedef struct mk_outputs {
                                 sequential filter, kalmanfilter.py:341-378 walked backwards) then produces the same
                                 projected smoothed means / variances as kalmansmoother + simulate (:403-476,
                                 :569-603) without the pseudo-inverse of :455.  d_Pf, d_Xp, d_Pp, d_S, d_Ps must be
-                                NULL; d_sigmas / d_detfs, if given, are DENSE [B,T] arrays.                      */
+                                NULL; d_sigmas / d_detfs, if given, are DENSE [B,T] arrays.
+                              MK_OUT_TAPE | MK_OUT_VAR_ONLY   (ABI 6; mk_filter_smooth, d_obsvar = NULL) the STATE tape:
+                                record_stride = mk_state_tape_stride(N, K) = (N + K)(n + 4) doubles per (model, step) --
+                                the N series entries above followed by K entries [ T Pf e_{N+k} (n) | x_f[N+k] |
+                                Pf[N+k][N+k] | NaN | 0 ], the factor columns of the filtered covariance in the observable
+                                basis.  The same backward pass then also writes the smoothed state MEANS to d_S [B,T,n]
+                                and VARIANCES to d_Ps [B,T,n] (kalmansmoother's S and diag(Ps), :461-474; what
+                                get_state_means / get_state_variances / get_state consume, metran.py:655-756) with no
+                                filtered record, no LDL^T of the predicted covariance and no n x n product.
+                                d_sim_means / d_sim_vars are optional; d_Pf, d_Xp, d_Pp must be NULL.             */
 } mk_outputs;
 #define MK_OUT_PACKED_SYM 1
 #define MK_OUT_VAR_ONLY 2
@@ -193,6 +202,8 @@ MK_API int64_t mk_record_stride_sym(int64_t n);
  * tape path serves a shape (16 < N + K, N <= 32: the shapes of the split filter, mk_split.hip / mk_dk.hip). */
 MK_API int64_t mk_tape_stride(int64_t N, int64_t K);
 MK_API int mk_tape_supported(int64_t N, int64_t K);
+/* ... of the STATE tape (MK_OUT_TAPE | MK_OUT_VAR_ONLY): (N + K)(N + K + 4); served for the same shapes. */
+MK_API int64_t mk_state_tape_stride(int64_t N, int64_t K);
 /* Writes up to `cap` supported (N,K) pairs into shapes[2*i], shapes[2*i+1]; returns the count. */
 MK_API int mk_supported_shapes(int64_t *shapes, int cap);
 

@@ -86,6 +86,7 @@ API = {
     "mk_record_stride_sym": (c_int64, [c_int64]),
     "mk_tape_stride": (c_int64, [c_int64, c_int64]),
     "mk_tape_supported": (c_int, [c_int64, c_int64]),
+    "mk_state_tape_stride": (c_int64, [c_int64, c_int64]),
     "mk_supported_shapes": (c_int, [c_i64p, c_int]),
     "mk_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "mk_free": (c_int, [c_void_p, c_void_p]),
@@ -125,7 +126,7 @@ API = {
     "mk_kernel_ms_totals": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
 }
 
-ABI_VERSION = 5  # MK_ABI_VERSION of include/metran_hip.h
+ABI_VERSION = 6  # MK_ABI_VERSION of include/metran_hip.h
 _lib = None
 
 

@@ -8,7 +8,7 @@ number comes from the HIP kernels:
     FactorAnalysisBatch      ->  mk_fa_*                     (Metran.get_factors for all models)
     calibrate_batch          ->  mk_loglik_grad / mk_loglik  (Metran.solve for all models in lock-step)
     simulate_smoothed        ->  filter + projecting smoother (get_simulated_means / _variances)
-    filter_smooth            ->  state means / variances / decomposition
+    smooth_state_variances   ->  state means / variances / decomposition
 
 Results of the last filter / smoother run are cached per parameter set, like ``Metran._run_kalman`` does
 (metran.py:963-989): asking for another series, the variances after the means, or the decomposition after the
@@ -155,7 +155,9 @@ class MetranBatch:
             self.kf.set_scaling(self._std, self._mean)
             out = self.kf.simulate_smoothed(phi, q)
         elif kind == "smoother":
-            out = self.kf.filter_smooth(phi, q, outputs=("F", "Pf", "S", "Ps"))
+            # state means + variances only (MK_OUT_VAR_ONLY): what the accessors below consume; the smoothed covariances
+            # [R,T,n,n] are never written (wide models: the state tape, BatchedKalman.state_tape_path)
+            out = self.kf.smooth_state_variances(phi, q)
         elif kind == "filter":
             out = self.kf.filter(phi, q, outputs=("F", "Pf"))
         else:
@@ -270,7 +272,7 @@ class MetranBatch:
 
         out = self._run(self._method(method), alpha)
         L = int(self.batch.lengths[r])
-        var = torch.diagonal(out["Ps" if method == "smoother" else "Pf"][r, :L], dim1=1, dim2=2)
+        var = out["var"][r, :L] if method == "smoother" else torch.diagonal(out["Pf"][r, :L], dim1=1, dim2=2)
         return DataFrame(var.cpu().numpy(), index=self.batch.index[r], columns=self._state_columns(r))
 
     def get_state(self, r, i, alpha=None, ci=0.05, method="smoother"):

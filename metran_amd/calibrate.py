@@ -44,7 +44,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     last one after 140), and a lock-step launch costs the same whether a model still moves or not; whenever the active
     models are fewer than ``compact`` x the models in flight (and more than ``compact_min`` are in flight), the active
     records are gathered into a smaller engine (``BatchedKalman.subset``) and the iteration continues on those.
-    Every model sees exactly the iterates it would have seen without it.  0 disables.
+    Every model sees exactly the iterates it would have seen without it: the sub-engine inherits the parent's kernel
+    choices (``BatchedKalman.subset`` pins a batch-size-dependent "auto" to what it resolved to for the parent).  0 disables.
     ``fd_below``: with the adjoint gradient, switch to forward differences once (n+1) x the models in flight fit in
     ``fd_below`` instances (0 = never).  A handful of stragglers is latency-bound: one objective launch over (n+1) R
     instances takes as long as one over R, the forward + backward pair of the adjoint 4-5 times as long; the price is
@@ -270,19 +271,46 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
             raise ValueError("stderr=True differences the adjoint gradient, which this shape (N=%d, K=%d) does not have"
                              % (kf.N, kf.K))
         d = 1e-5 * x.abs().clamp_min(0.1)                                   # [R,n] step per parameter
-        pts = x[None].repeat(n + 1, 1, 1)                                   # [n+1,R,n]
-        idx = torch.arange(n, device=dev)
-        pts[1 + idx, :, idx] += d.transpose(0, 1)
-        _, gg = kf.loglik_grad_alpha(pts.reshape((n + 1) * R, n), dt=dt, warmup=warmup)
-        gg = gg.reshape(n + 1, R, n)
+        # the n + 1 gradient evaluations ride as batch -- as many point sets per launch pair as the recording forward pass
+        # has workspace for (R*T*record_stride(n) doubles per set: a wide flight that needed the memory check above for ONE
+        # set cannot hold n + 1 of them; round-4 advice: it used to run out of memory after the whole calibration)
+        sets = _grad_sets_that_fit(kf, R, n + 1)
+        gg = torch.empty((n + 1, R, n), **f64)
+        stderr_launches = 0
+        for s0 in range(0, n + 1, sets):
+            s1 = min(n + 1, s0 + sets)
+            pts = x[None].repeat(s1 - s0, 1, 1)                             # [sets,R,n]: set 0 is x itself, set 1 + j steps x_j
+            for s_ in range(max(s0, 1), s1):
+                pts[s_ - s0, :, s_ - 1] += d[:, s_ - 1]
+            _, gch = kf.loglik_grad_alpha(pts.reshape((s1 - s0) * R, n), dt=dt, warmup=warmup)
+            gg[s0:s1] = gch.reshape(s1 - s0, R, n)
+            stderr_launches += 2
         hess = ((gg[1:] - gg[0:1]) / d.transpose(0, 1)[:, :, None]).permute(1, 0, 2)   # [R, j, :] = d grad / d x_j
         hess = 0.5 * (hess + hess.transpose(1, 2))
         pcov = torch.linalg.pinv(hess)
         res["pcov"] = pcov
         res["stderr"] = torch.sqrt(torch.diagonal(pcov, dim1=1, dim2=2))
         res["nfev"] = nfev + (n + 1) * R
-        res["launches"] = launches + 2
+        res["launches"] = launches + stderr_launches
     return res
+
+
+def _grad_sets_that_fit(kf, R, want):
+    """How many parameter sets of R instances one ``loglik_grad_alpha`` launch pair can take (<= ``want``): its recording
+    forward pass needs R*T*record_stride(n) doubles per set.  Raises when not even one fits."""
+    import torch
+
+    per_set = 8.0 * R * kf.T * kf.record_stride()
+    have = getattr(kf, "_grad_work", None)
+    have = 8.0 * have.numel() if have is not None else 0.0
+    dev = kf.device
+    free = float(torch.cuda.mem_get_info(dev)[0]) if getattr(dev, "type", "cpu") == "cuda" else float("inf")
+    room = max(have, 0.8 * free)  # a larger workspace replaces the current one (engine._grad_work is reallocated)
+    sets = int(min(want, room // per_set)) if per_set > 0 else want
+    if sets < 1:
+        raise MemoryError("stderr=True needs %.1f GB for the recording forward pass of the adjoint gradient (%d models, T=%d, "
+                          "n=%d); %.1f GB are free -- calibrate in smaller flights" % (per_set / 1e9, R, kf.T, kf.n, free / 1e9))
+    return sets
 
 
 

@@ -297,24 +297,37 @@ MK_API int mk_shape_supported(int64_t N, int64_t K)
 MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
 MK_API int64_t mk_record_stride_sym(int64_t n) { return mk::record_stride_sym((int)n); }
 MK_API int64_t mk_tape_stride(int64_t N, int64_t K) { return mk::tape_stride_c((int)N, (int)K); }
+MK_API int64_t mk_state_tape_stride(int64_t N, int64_t K) { return mk::state_tape_stride_c((int)N, (int)K); }
 MK_API int mk_tape_supported(int64_t N, int64_t K)
 {
     return (N + K > 16 && N <= 32 && K <= 16 && N + K + 1 <= 64 && mk_shape_supported(N, K)) ? 1 : 0;
 }
-// MK_OUT_TAPE (mk_outputs.flags): 0 = not asked for, 1 = asked for and consistent, < 0 = an inconsistent description
+// MK_OUT_TAPE (mk_outputs.flags): 0 = not asked for, 1 = asked for and consistent, 2 = the STATE tape (with MK_OUT_VAR_ONLY:
+// d_S / d_Ps are the smoothed state means / variances [B,T,n]), < 0 = an inconsistent description
 static int tape_outputs(const mk_problem *p, const mk_outputs *o)
 {
     if (!(o->flags & MK_OUT_TAPE)) return 0;
-    if (o->flags & (MK_OUT_PACKED_SYM | MK_OUT_VAR_ONLY))
-        return fail(MK_ERR_INVALID, "MK_OUT_TAPE excludes MK_OUT_PACKED_SYM and MK_OUT_VAR_ONLY");
+    if (o->flags & MK_OUT_PACKED_SYM) return fail(MK_ERR_INVALID, "MK_OUT_TAPE excludes MK_OUT_PACKED_SYM");
     if (!mk_tape_supported(p->N, p->K))
         return fail(MK_ERR_SHAPE, "MK_OUT_TAPE serves 16 < N + K, N <= 32 (got N=%lld, K=%lld)", (long long)p->N, (long long)p->K);
+    if (!p->d_loadings) return fail(MK_ERR_INVALID, "MK_OUT_TAPE needs d_loadings");
+    if (o->flags & MK_OUT_VAR_ONLY) {
+        if (!o->d_F || o->d_Pf || o->d_Xp || o->d_Pp || !o->d_S || !o->d_Ps)
+            return fail(MK_ERR_INVALID, "MK_OUT_TAPE | MK_OUT_VAR_ONLY: d_F is the state tape, d_S / d_Ps the smoothed state means / "
+                                        "variances [B,T,n]; d_Pf / d_Xp / d_Pp must be NULL");
+        if (o->record_stride != mk_state_tape_stride(p->N, p->K))
+            return fail(MK_ERR_INVALID, "MK_OUT_TAPE | MK_OUT_VAR_ONLY: record_stride must be mk_state_tape_stride(N, K) = %lld doubles",
+                        (long long)mk_state_tape_stride(p->N, p->K));
+        if (p->d_obsvar)
+            return fail(MK_ERR_INVALID, "MK_OUT_TAPE | MK_OUT_VAR_ONLY serves zero observation variances (d_obsvar = NULL, Metran's R); "
+                                        "use filtered records + MK_OUT_VAR_ONLY otherwise");
+        return 2;
+    }
     if (!o->d_F || o->d_Pf || o->d_Xp || o->d_Pp || o->d_S || o->d_Ps)
         return fail(MK_ERR_INVALID, "MK_OUT_TAPE: d_F is the tape, d_Pf / d_Xp / d_Pp / d_S / d_Ps must be NULL");
     if (o->record_stride != mk_tape_stride(p->N, p->K))
         return fail(MK_ERR_INVALID, "MK_OUT_TAPE: record_stride must be mk_tape_stride(N, K) = %lld doubles",
                     (long long)mk_tape_stride(p->N, p->K));
-    if (!p->d_loadings) return fail(MK_ERR_INVALID, "MK_OUT_TAPE needs d_loadings");
     return 1;
 }
 
@@ -492,7 +505,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (tape < 0) return tape;
     if (!o->d_F || (!o->d_Pf && !tape))
         return fail(MK_ERR_INVALID, "the smoother reads d_F and d_Pf (filtered moments); both must be non-NULL");
-    if (tape && !(o->d_sim_means || o->d_sim_vars))
+    if (tape == 1 && !(o->d_sim_means || o->d_sim_vars))
         return fail(MK_ERR_INVALID, "MK_OUT_TAPE: nothing to write, give d_sim_means / d_sim_vars");
     mk::SmootherArgs a;
     a.tape = tape;
@@ -543,6 +556,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.q = p->d_q;
     a.F = o->d_F;
     a.Pf = o->d_Pf;
+    if (tape == 2 && !p->d_loadings) return fail(MK_ERR_INVALID, "the state tape needs d_loadings");
     a.S = var ? nullptr : o->d_S;
     a.Ps = var ? nullptr : o->d_Ps;
     if (var) {
@@ -628,7 +642,7 @@ MK_API int mk_filter_smooth(mk_context *ctx, const mk_problem *p, const mk_outpu
     MK_CTX(ctx);
     if (int rc = check_problem(p)) return rc;
     if (!o) return fail(MK_ERR_INVALID, "null mk_outputs");
-    if ((o->flags & MK_OUT_VAR_ONLY) && (o->d_Xp || o->d_Pp))
+    if ((o->flags & MK_OUT_VAR_ONLY) && !(o->flags & MK_OUT_TAPE) && (o->d_Xp || o->d_Pp))
         return fail(MK_ERR_INVALID, "MK_OUT_VAR_ONLY: d_Xp / d_Pp must be NULL (the filter writes the filtered record only)");
     if (int rc = do_filter(ctx, p, o)) return rc;
     return do_smooth(ctx, p, o);

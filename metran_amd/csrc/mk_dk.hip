@@ -44,10 +44,19 @@ typedef __attribute__((address_space(1))) const void global_cvoid_t;
 // an observed series are  z x = y - v R/f  and  P z' = k R,  so its smoothed observable is  y - R (v/f - beta)  with variance
 // R (1 - R/f) - R^2 alpha  -- the update's own beta and alpha; R = 0 (Metran: metran.py:382-384) gives (y, 0) and the
 // instantiation without the four extra operations per entry.
-template <int N, int K, bool HASR>
+// STATE (round 5; MK_OUT_TAPE | MK_OUT_VAR_ONLY, R = 0): the block carries K more entries, the factor columns of T Pf T'
+// (state_tape_stride_c), and the kernel also writes the smoothed STATE means and variances [., n] of Metran's own basis --
+// what kalmansmoother's S and diag(Ps) hold (kalmanfilter.py:461-474; consumers: metran.py:655-756) -- without the RTS chain:
+//     xt_s = xt_f + Pt r,  Vt = Pt - Pt N Pt  at the END of the step (Pt = T Pf T' has zero rows / columns at the observed series),
+//     x_a = xt_a - g_a . xt_F,   V_aa = Vt_aa - 2 g_a . Vt[a, F] + g_a' Vt_FF g_a,   x_{N+k} = xt_{N+k},   V_{N+k} = Vt_FF[k][k].
+// Beyond the projection's work: K products w_k = N pt_{N+k} (the r row yields r . pt_{N+k}), and one product of the step's
+// entries against them -- lane a reads ITS entry pt_a from the LDS block, w_k arrive DPP-replicated: c_a[k] = pt_a . w_k is
+// Vt[a][N+k] = Pt[a][N+k] - c_a[k] for an unobserved series a and Vt_FF[k'][k] at lane N + k'.  tests/dk_ref.py::dk_smooth_state.
+template <int N, int K, bool HASR, bool STATE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
 {
-    constexpr int n = N + K, SW = tape_side_c(K), RS = tape_stride_c(N, K);
+    static_assert(!(STATE && HASR), "the state outputs are served for R = 0 (Metran's observation variance, metran.py:382-384)");
+    constexpr int n = N + K, SW = tape_side_c(K), RS = STATE ? state_tape_stride_c(N, K) : tape_stride_c(N, K);
     constexpr int XS = tape_xs_c(N, K), SS = tape_ss_c(N, K), SO = tape_so_c(N, K); // tape block addressing (mk_internal.h)
     static_assert(n > 16 && n + 1 <= 64 && K <= 16 && N >= 2, "one model per wavefront: rows 0..n-1 of N and the r row");
     constexpr int NB = (N + 15) / 16;          // DPP-replicated registers holding the series entries of a vector
@@ -72,7 +81,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const long T = a.T;
 
     // wave-private LDS
-    __shared__ __attribute__((aligned(16))) double lds[TBD + NP + NP + K * NP + K * K * QS + ((K * K + 1) & ~1)];
+    constexpr int GLT = STATE ? ((N * K + 1) & ~1) : 0; // STATE: loadings table [N][K]
+    __shared__ __attribute__((aligned(16))) double lds[TBD + NP + NP + K * NP + K * K * QS + ((K * K + 1) & ~1) + GLT];
     double *tapeb = lds;                       // the step's tape block: N entries [ series part (N) | side row (SW) ]
     double *sideb = tapeb + SO;
     double *phim = tapeb + TBD;                // diag(Phi) [n]
@@ -80,6 +90,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *fbuf = tbuf + NP;                  // [K][NP] factor columns on their way to the factor rows
     double *qbuf = fbuf + K * NP;              // [K*K][QS] products of the factor block
     double *ffb = qbuf + K * K * QS;           // [K*K] factor block sums
+    [[maybe_unused]] double *gtab = ffb + ((K * K + 1) & ~1); // STATE: loadings [N][K]
 
     const double phi_own = lane < n ? a.phi[inst * n + lane] : 1.0; // row scaling of the transition (none for the r row)
     if (lane < n) phim[lane] = phi_own;
@@ -101,6 +112,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     [[maybe_unused]] const double rvar = HASR ? a.obsvar[rec * N + js] : 0.0;
     const double scale = a.scale ? a.scale[rec * N + js] : 1.0;
     const double offset = a.offset ? a.offset[rec * N + js] : 0.0;
+    if constexpr (STATE) { // the loadings of this lane's series wait in LDS (registers are what this kernel is short of)
+#pragma unroll
+        for (int k = 0; k < K; ++k) gtab[js * K + k] = a.loadings[(rec * N + js) * K + k];
+        wave_lds_sync();
+    }
 
     double Nr[n];
 #pragma unroll
@@ -181,6 +197,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *omean = a.sim_means ? a.sim_means + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
     double *ovar = a.sim_vars ? a.sim_vars + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
     const long ostep = a.ts * N;
+    [[maybe_unused]] const int sl = lane < n ? lane : n - 1; // STATE: the state this lane writes (lanes >= n replicate n - 1)
+    [[maybe_unused]] double *osm = (STATE && a.state_means) ? a.state_means + (inst * a.bs + (T - 1) * a.ts) * n + sl : nullptr;
+    [[maybe_unused]] double *osv = (STATE && a.state_vars) ? a.state_vars + (inst * a.bs + (T - 1) * a.ts) * n + sl : nullptr;
+    [[maybe_unused]] const long sstep = a.ts * n;
 
     fetch_block(tb);
     for (long t = T - 1; t >= 0; --t) {
@@ -203,6 +223,98 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const bool unobs = (s2 != s2);
         const unsigned obsm = (unsigned)__ballot(lane < N && !unobs) & NM; // series observed at this step
         Ent ea, eb;
+
+        // ---- STATE: the factor columns of Vt and the smoothed factor means, with (r, N) before the step's updates and BEFORE the
+        // unobserved pass overwrites its entries' LDS slots
+        [[maybe_unused]] double st_madd = 0.0, st_vadd = 0.0; // what the state outputs add to the projection's (mean, var)
+        if constexpr (STATE) {
+            {   // w_k = N pt_{N+k} in the natural layout (lane a: w_k[a]; the r row: r . pt_{N+k}) -> fbuf[k][.]
+                Ent ef[2];
+                load_ent(N, ef[0]);
+                sfor<0, K>(MK_LAMBDA(kk) {
+                    constexpr int k = decltype(kk)::value;
+                    if constexpr (k + 1 < K) load_ent(N + k + 1, ef[(k + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double w = matvec(ef[k & 1]);
+                    fbuf[k * NP + ra] = w;
+                });
+            }
+            wave_lds_sync();
+            // c[k] = (this lane's entry) . w_k: the entry's n doubles are contiguous in the block (series part, factor part),
+            // w_k DPP-replicated (lane 16 q + i holds w_k[16 m + i])
+            const double *er = tapeb + sl * XS;
+            double cacc[K], WBk[K][NB], WFk[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                cacc[k] = 0.0;
+#pragma unroll
+                for (int m = 0; m < NB; ++m) WBk[k][m] = fbuf[k * NP + xoff_b[m]];
+                WFk[k] = fbuf[k * NP + N + (i16 < K ? i16 : K - 1)];
+            }
+            constexpr int CH = 8; // columns per piece: the row is read a piece ahead of its multiply-adds
+            sfor<0, (n + CH - 1) / CH>(MK_LAMBDA(pp) {
+                constexpr int c0 = CH * decltype(pp)::value, c1 = c0 + CH < n ? c0 + CH : n;
+                double rowp[CH];
+                if constexpr (PAIRS) {
+#pragma unroll
+                    for (int c = c0; c < c1; c += 2) {
+                        const v2d t2 = *reinterpret_cast<const v2d *>(er + c);
+                        rowp[c - c0] = t2.x;
+                        rowp[c - c0 + 1] = t2.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = c0; c < c1; ++c) rowp[c - c0] = er[c];
+                }
+                sfor<c0, c1>(MK_LAMBDA(cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (c < N) {
+                        if constexpr (K == 4)
+                            G16::fmac4x<c % 16>(cacc[0], cacc[1], cacc[2], cacc[3], WBk[0][c / 16], WBk[1][c / 16], WBk[2][c / 16],
+                                                 WBk[3][c / 16], rowp[c - c0]);
+                        else
+                            sfor<0, K>(MK_LAMBDA(k2) { G16::fmac<c % 16>(cacc[decltype(k2)::value], WBk[decltype(k2)::value][c / 16], rowp[c - c0]); });
+                    } else {
+                        if constexpr (K == 4)
+                            G16::fmac4x<c - N>(cacc[0], cacc[1], cacc[2], cacc[3], WFk[0], WFk[1], WFk[2], WFk[3], rowp[c - c0]);
+                        else
+                            sfor<0, K>(MK_LAMBDA(k2) { G16::fmac<c - N>(cacc[decltype(k2)::value], WFk[decltype(k2)::value], rowp[c - c0]); });
+                    }
+                });
+            });
+            // Vt[a][N+k] = Pt[a][N+k] - c[k]  (Pt[a][N+k] is the factor part of entry a); zero where the series was observed
+            double vaf[K];
+            const bool live = frow || (lane < N && unobs);
+#pragma unroll
+            for (int k = 0; k < K; ++k) vaf[k] = live ? er[N + k] - cacc[k] : 0.0;
+            const double xf_own = er[n] + fbuf[(frow ? lane - N : 0) * NP + n]; // lane N + k: x_f[N+k] + r . pt_{N+k}
+            wave_lds_sync();                                                    // fbuf has been read
+            if (frow) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) ffb[(lane - N) * K + k] = vaf[k];   // row k' = lane - N of Vt_FF
+                tbuf[lane - N] = xf_own;
+            }
+            wave_lds_sync();
+            double gl[K];
+            if constexpr (K % 2 == 0) load_row<K>(gtab + js * K, gl);
+            else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) gl[k] = gtab[js * K + k];
+            }
+            double quad = 0.0, cross = 0.0, gx = 0.0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                gx = fma(gl[k], tbuf[k], gx);
+                cross = fma(gl[k], vaf[k], cross);
+                double rowq = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < K; ++k2) rowq = fma(gl[k2], ffb[k * K + k2], rowq);
+                quad = fma(gl[k], rowq, quad);
+            }
+            const int kf = frow ? lane - N : 0;
+            st_madd = frow ? tbuf[kf] : -gx;                              // factor rows: the smoothed factor mean itself
+            st_vadd = frow ? ffb[kf * K + kf] : fma(-2.0, cross, quad);   // ... and Vt_FF[k][k]
+        }
 
         // ---- series not observed at this step: mean = s0 + pt.r, var = s1 - pt'N pt with (r, N) before the step's updates.
         // The products x_a w_a go back into the entry's own (consumed) LDS slots, beta into its constant-0 slot; lane u sums
@@ -248,6 +360,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             mean = s0 + rowf[SW - 1];
             var = s1 - (q0 + q1);
+        }
+        if constexpr (STATE) { // smoothed state means / variances of Metran's basis (kalmanfilter.py:461-474: S, diag(Ps));
+            // R = 0: the projection's (mean, var) are final here, before the observed pass
+            if (osm) *osm = (frow ? 0.0 : mean) + st_madd;
+            if (osv) *osv = (frow ? 0.0 : var) + st_vadd;
         }
         // ---- observed series, last first: the scalar updates of the filter walked backwards
         unsigned om = obsm;
@@ -307,6 +424,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (omean) *omean = fma(scale, mean, offset);
             if (ovar) *ovar = v < 0.0 ? 0.0 : v;  // kalmanfilter.py:601-602 (np.maximum keeps a NaN)
         }
+
         // every entry of the step has been consumed: next step's block on its way while the transition runs
         tb -= tstep;
         if (t > 0) {
@@ -377,6 +495,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         if (omean) omean -= ostep;
         if (ovar) ovar -= ostep;
+        if constexpr (STATE) {
+            if (osm) osm -= sstep;
+            if (osv) osv -= sstep;
+        }
     }
 }
 
@@ -385,6 +507,11 @@ template <int N, int K>
 static hipError_t launch_dk_nk(const SmootherArgs &a, hipStream_t s)
 {
     if constexpr (N + K > 16 && N <= 32 && N + K + 1 <= 64 && K <= 16) {
+        if (a.tape == 2) { // the STATE tape: smoothed state means / variances (and, if asked for, the projection)
+            if (a.rs != state_tape_stride_c(N, K) || a.obsvar) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((smoother_dk_kernel<N, K, false, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+            return hipGetLastError();
+        }
         if (a.rs != tape_stride_c(N, K)) return hipErrorInvalidValue;
         if (a.obsvar) hipLaunchKernelGGL((smoother_dk_kernel<N, K, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((smoother_dk_kernel<N, K, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);

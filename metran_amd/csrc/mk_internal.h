@@ -30,6 +30,10 @@ constexpr int tape_xs_c(int N, int K) { return N + tape_side_c(K); }
 constexpr int tape_ss_c(int N, int K) { return tape_xs_c(N, K); }
 constexpr int tape_so_c(int N, int K) { return N; }
 constexpr int tape_stride_c(int N, int K) { return N * tape_xs_c(N, K); }
+// STATE tape (MK_OUT_TAPE | MK_OUT_VAR_ONLY, round 5): K more entries per block, the factor columns of the filtered
+// covariance in the observable basis -- entry N + k = [ T Pf e_{N+k} (n) | x_f[N+k] | Pf[N+k][N+k] | NaN | 0 ] -- from which the
+// backward pass also gets the smoothed STATE means and variances (mk_dk.hip, STATE = true)
+constexpr int state_tape_stride_c(int N, int K) { return (N + K) * tape_xs_c(N, K); }
 
 struct FilterArgs {
     long B, R, T, warmup;
@@ -44,7 +48,8 @@ struct FilterArgs {
     double *F, *Pf, *Xp, *Pp;
     unsigned *status;
     long variant;        // wide models: 0 = split layout when B > 2 x #SIMDs, else filter_kernel<N,K,64> (one state per lane); 1 = one state per lane always; 2 = split always
-    long tape;           // 1: F is the backward tape of the inverse-free smoother (MK_OUT_TAPE; rs = tape_stride(N, K))
+    long tape;           // 1: F is the backward tape of the inverse-free smoother (MK_OUT_TAPE; rs = tape_stride(N, K));
+                         // 2: the STATE tape (MK_OUT_TAPE | MK_OUT_VAR_ONLY; rs = state_tape_stride(N, K))
 };
 
 // Timing experiments that skip phases of a kernel (and so produce wrong numbers) exist only in builds made with
@@ -71,7 +76,8 @@ struct SmootherArgs {
     unsigned *status;
     long variant;        // bit 0: n <= 15 records -> smoother_blk_kernel; bit 1: n > 16 -> smoother_wave_kernel (round 1); bit 2: n > 16 -> the MFMA kernel without the lane fold; bits 3 / 4: (-DMK_EXPERIMENTAL_BLK4 builds only) n > 16, n % 4 == 0 -> the 4x4x4 MFMA block path with / without the lane fold;
                          // set by the C ABI from mk_set_kernel_variant.  Every variant is a tested, equivalent kernel.
-    long tape;           // 1: F is the backward tape (MK_OUT_TAPE, rs = tape_stride(N, K)): smoother_dk_kernel (mk_dk.hip)
+    long tape;           // 1: F is the backward tape (MK_OUT_TAPE, rs = tape_stride(N, K)): smoother_dk_kernel (mk_dk.hip);
+                         // 2: the STATE tape (rs = state_tape_stride(N, K)): state_means / state_vars [., n] are written too
     const double *obsvar; // tape path: observation variances [R,N] or NULL = zeros
 };
 

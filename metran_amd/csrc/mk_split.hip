@@ -145,8 +145,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int k2 = k; k2 < K; ++k2) pfs[pf(k, k2)] = PFv[pf(k, k2)];
             wave_lds_sync();
-            {   // rows N+k of the triangle are contiguous and in the order of pf(): element e of the replicated block
-                const int e = l < KF ? l : KF - 1;
+            // rows N+k of the triangle are contiguous and in the order of pf(): element e of the replicated block, one
+            // element per lane and pass (KF > H for K >= 6 at H = 16, K >= 8 at H = 32: run-time-specialised shapes)
+#pragma unroll
+            for (int p = 0; p < (KF + H - 1) / H; ++p) {
+                const int e = l + p * H < KF ? l + p * H : KF - 1;
                 cov[sym_row_offset(n, N) + e] = pfs[e];
             }
         } else {
@@ -165,7 +168,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int k2 = 0; k2 < K; ++k2) pfs[k * K + k2] = PFv[k <= k2 ? pf(k, k2) : pf(k2, k)]; // same value from every lane
             wave_lds_sync();
-            cov[(N + fl16 / K) * n + N + fl16 % K] = pfs[fl16];
+#pragma unroll
+            for (int p = 0; p < (K * K + H - 1) / H; ++p) { // one element per lane and pass (K * K > H for K >= 5 at H = 16)
+                const int e = fl16 + p * H < K * K ? fl16 + p * H : K * K - 1;
+                cov[(N + e / K) * n + N + e % K] = pfs[e];
+            }
         }
 #pragma unroll
         for (int p = 0; p < (PADN + H - 1) / H; ++p) { // the record's pad: sigma, detf, zeros (whole cache lines)
@@ -455,7 +462,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 unsigned uany = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) uany |= urem[g];
-                if (uany && !MK_TUNE_SKIP(a, 2)) {
+                const bool stape = a.tape == 2; // STATE tape: K more entries per step, the factor columns of T Pf T'
+                if ((uany || stape) && !MK_TUNE_SKIP(a, 2)) {
                     double Q[K], yh = x;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
@@ -465,6 +473,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         for (int k2 = 0; k2 < K; ++k2) sq = fma(gam[k2], PF[k <= k2 ? pf(k, k2) : pf(k2, k)], sq);
                         Q[k] = sq;
                     }
+                    if (stape) {
+                        // entry N + k = [ Q[.][k] (series part) | PF[.][k] | x_f[N+k] | PF[k][k] | NaN | 0 ]: column N + k of T Pf T'
+                        // (T' e_{N+k} = e_{N+k}), the filtered factor mean and its variance.  One 8 N-byte run per model for
+                        // the series part; the side row is replicated in every lane, lane 0 of the group writes it.
+                        const double qnan = __builtin_nan("");
+                        sfor<0, K>(MK_LAMBDA(kk) {
+                            constexpr int k = decltype(kk)::value;
+                            trec[(N + k) * XS + jr] = Q[k];
+                            if (l == 0) {
+                                double *sd = trec + SO + (N + k) * SS;
+#pragma unroll
+                                for (int k2 = 0; k2 < K; ++k2) sd[k2] = PF[k2 <= k ? pf(k2, k) : pf(k, k2)];
+                                sd[SW - 4] = xk[k];
+                                sd[SW - 3] = PF[pf(k, k)];
+                                sd[SW - 2] = qnan;
+                                sd[SW - 1] = 0.0;
+                            }
+                        });
+                    }
+                    if (uany) {
                     wave_lds_sync(); // the previous step's table reads are done
                     if constexpr (K % 2 == 0) {
 #pragma unroll
@@ -524,6 +552,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             }
                         }
                     });
+                    } // uany
                 }
                 trec += tstep;
             }

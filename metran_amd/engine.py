@@ -110,6 +110,16 @@ class BatchedKalman:
         check(self._L.mk_set_kernel_variant(self._ctx, sel, names.index(name)))
         return self
 
+    def resolved_wide_filter(self, B):
+        """The wide-filter kernel ``"auto"`` picks for B instances (``mk_kernels.hip`` dispatch_filter: the split layout above
+        two wavefronts per SIMD, one state per lane below)."""
+        v = self.get_variant("wide_filter")
+        if v != "auto":
+            return v
+        torch = _torch()
+        simds = 4 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        return "split" if B > 2 * simds else "lane_per_state"
+
     def get_variant(self, which):
         sel, names = self._VARIANTS[which]
         v = ctypes.c_int(-1)
@@ -283,6 +293,14 @@ class BatchedKalman:
         index = torch.as_tensor(index, dtype=torch.long, device=self.device)
         sub = BatchedKalman(self.device.index, layout="time_major" if self.time_major else "model_major",
                             packed_sym=self.packed_sym)
+        # the sub-engine runs the SAME kernels as its parent: the user's variants and projection path carry over, and
+        # "auto" (a rule on the batch size) is pinned to what it resolves to for the parent's record count -- so a model
+        # sees bit-identical results whether or not calibrate_batch compacted the flight around it
+        sub.projection_path = self.projection_path
+        for which in self._VARIANTS:
+            sub.set_variant(which, self.get_variant(which))
+        if self.get_variant("wide_filter") == "auto" and self.R is not None:
+            sub.set_variant("wide_filter", self.resolved_wide_filter(self.R))
         sub.set_observations(self.obs[index])
         sub.set_loadings(self.loadings[index], None if self.obsvar is None else self.obsvar[index])
         if self.scale is not None:
@@ -599,21 +617,43 @@ class BatchedKalman:
         check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
         return res
 
+    def state_tape_path(self):
+        """True when ``smooth_state_variances`` runs over the STATE tape (``MK_OUT_TAPE | MK_OUT_VAR_ONLY``: the tape of
+        ``tape_path`` plus K factor entries per step; ``mk_dk.hip`` STATE = true): the shapes of ``tape_path`` with zero
+        observation variances (Metran's, metran.py:382-384)."""
+        return self.tape_path() and self.obsvar is None
+
+    def alloc_state_variances(self, B, projection=False):
+        """Buffers of ``smooth_state_variances`` for B instances (pass them back as ``buffers=``).  ``projection``: on the
+        state-tape path the same backward pass can write the projected moments ``sim_means / sim_vars [B,T,N]`` as well."""
+        torch = _torch()
+        res = {"mle": torch.empty(B, dtype=torch.float64, device=self.device),
+               "status": torch.zeros(B, dtype=torch.int32, device=self.device),
+               "sigmacount": torch.empty(B, dtype=torch.int64, device=self.device), "_rs": self.record_stride(),
+               "_var_only": True}
+        if self.state_tape_path():
+            res["_rs"] = int(self._L.mk_state_tape_stride(self.N, self.K))
+            res["_tape"] = True
+            res["F"] = res["_rec_filt"] = self._empty_bt(B, self.T, res["_rs"])  # d_F = the state tape
+            if projection:
+                res["sim_means"] = self._empty_bt(B, self.T, self.N)
+                res["sim_vars"] = self._empty_bt(B, self.T, self.N)
+        else:
+            if projection:
+                raise MetranHipError("projection=True needs the state-tape path (state_tape_path())")
+            res["_rec_filt"], res["F"], res["Pf"], res["sigmas"], res["detfs"] = self._alloc_records(B)
+        res["S"] = self._empty_bt(B, self.T, self.n)
+        res["var"] = self._empty_bt(B, self.T, self.n)
+        return res
+
     def smooth_state_variances(self, phi, q, warmup=1, x0=None, P0=None, buffers=None):
         """``Metran.get_state_means`` / ``get_state_variances`` (metran.py:655-711, method="smoother") for B instances
-        without materialising the smoothed covariances (``MK_OUT_VAR_ONLY``): the filter writes the filtered records,
-        the smoother reads them and writes the smoothed state means ``S [B,T,n]`` and variances ``var [B,T,n]``."""
-        torch = _torch()
+        without materialising the smoothed covariances (``MK_OUT_VAR_ONLY``): smoothed state means ``S [B,T,n]`` and
+        variances ``var [B,T,n]``.  n <= 16 and the shapes without a tape: the filter writes the filtered records, the
+        RTS smoother reads them.  Wide models on the tape path (``state_tape_path``): the filter writes the STATE tape and
+        the inverse-free backward pass turns it into the same moments -- no filtered record, no LDL^T chain."""
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
-        res = buffers
-        if res is None:
-            res = {"mle": torch.empty(B, dtype=torch.float64, device=self.device),
-                   "status": torch.zeros(B, dtype=torch.int32, device=self.device),
-                   "sigmacount": torch.empty(B, dtype=torch.int64, device=self.device), "_rs": self.record_stride(),
-                   "_var_only": True}
-            res["_rec_filt"], res["F"], res["Pf"], res["sigmas"], res["detfs"] = self._alloc_records(B)
-            res["S"] = self._empty_bt(B, self.T, self.n)
-            res["var"] = self._empty_bt(B, self.T, self.n)
+        res = buffers if buffers is not None else self.alloc_state_variances(B)
         o = self._outputs_struct(dict(res, Ps=res["var"]))
         self._bind_stream()
         check(self._L.mk_filter_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))

@@ -5,6 +5,12 @@ statically checked for the hazards hipcc does not pad around inline asm (``scrip
 results with one side inside an asm block) and registered with the library (``mk_register_shape_module``).
 Built modules are cached by a hash of the sources under ``$METRAN_HIP_CACHE`` (default
 ``~/.cache/metran_amd``).  Set ``METRAN_HIP_JIT=0`` to forbid compilation (unsupported shapes raise).
+
+Prebuilding (no hipcc needed at first use).  ``python -m metran_amd.jit 2-12x1-3 20x2 ...`` compiles the listed shapes
+ahead of time into ``metran_amd/_shape_cache/`` next to the library (several hipcc processes in parallel); modules found
+there are used before the per-user cache is consulted, so a deployment -- or a GPU box without a compiler -- that ships
+the directory never compiles at run time.  The modules are keyed by the same source hash: after a kernel edit they are
+simply not found any more, and ``python -m metran_amd.jit --prune`` removes the stale files.
 """
 import hashlib
 import logging
@@ -55,13 +61,29 @@ def _source_hash():
     return h.hexdigest()[:16]
 
 
+PREBUILT_DIR = os.path.join(_HERE, "_shape_cache")  # shipped next to libmetran_hip.so (git-ignored *.so, travels with the tree)
+
+
+def _module_name(N, K):
+    return "mk_shape_%d_%d_%s.so" % (N, K, _source_hash())
+
+
 def module_path(N, K):
-    return os.path.join(cache_dir(), "mk_shape_%d_%d_%s.so" % (N, K, _source_hash()))
+    return os.path.join(cache_dir(), _module_name(N, K))
 
 
-def build_shape_module(N, K):
-    """Compile, hazard-check and cache the shape module for (N, K); returns its path."""
-    out = module_path(N, K)
+def prebuilt_path(N, K):
+    return os.path.join(PREBUILT_DIR, _module_name(N, K))
+
+
+def build_shape_module(N, K, out=None):
+    """Compile, hazard-check and cache the shape module for (N, K); returns its path.  A module prebuilt into
+    ``metran_amd/_shape_cache`` (``python -m metran_amd.jit``) is returned as it is."""
+    if out is None:
+        pre = prebuilt_path(N, K)
+        if os.path.exists(pre):
+            return pre
+        out = module_path(N, K)
     if os.path.exists(out):
         return out
     if os.environ.get("METRAN_HIP_JIT", "1") == "0":
@@ -94,7 +116,7 @@ def build_shape_module(N, K):
             raise MetranHipError("link failed for shape (%d,%d):\n%s" % (N, K, r.stderr[-2000:]))
         # publish atomically: every rank of a multi-GPU job builds the same shape at the same moment, and a
         # reader must never dlopen a half-written file (temp file INSIDE the cache directory + rename)
-        fd, stage = tempfile.mkstemp(prefix=".mk_shape_", suffix=".so", dir=cache_dir())
+        fd, stage = tempfile.mkstemp(prefix=".mk_shape_", suffix=".so", dir=os.path.dirname(out))
         os.close(fd)
         shutil.copyfile(so, stage)
         os.chmod(stage, 0o755)
@@ -114,3 +136,77 @@ def ensure_shape(N, K):
     if not L.mk_shape_supported(N, K):
         raise MetranHipError("shape module %s did not register (N=%d, K=%d)" % (path, N, K))
     return True
+
+
+def parse_shapes(specs):
+    """``["2-12x1-3", "20x2"]`` -> [(2,1), (2,2), ..., (12,3), (20,2)] (N or a range of N, "x", K or a range of K)."""
+    out = []
+    for spec in specs:
+        a, b = spec.lower().split("x")
+        rng = lambda t: range(int(t.split("-")[0]), int(t.split("-")[-1]) + 1)  # noqa: E731
+        out += [(N, K) for N in rng(a) for K in rng(b)]
+    return out
+
+
+def prebuild(shapes, jobs=None, verbose=True):
+    """Compile shape modules into ``metran_amd/_shape_cache`` (skips ahead-of-time shapes and what is already there).
+    Needs hipcc, not a GPU.  Returns the list of module paths."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(PREBUILT_DIR, exist_ok=True)
+    L = _lib.lib()
+    todo = [(N, K) for (N, K) in dict.fromkeys(shapes) if not _aot(L, N, K) and N + K <= 64]
+    jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 2)))
+
+    def one(shape):
+        path = build_shape_module(shape[0], shape[1], out=prebuilt_path(*shape))
+        if verbose:
+            print("%s  (%d,%d)" % (os.path.relpath(path, _ROOT), shape[0], shape[1]), flush=True)
+        return path
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:  # the work is in hipcc child processes
+        return list(ex.map(one, todo))
+
+
+def _aot(L, N, K):
+    import ctypes
+
+    shapes = (ctypes.c_int64 * 512)()
+    cnt = L.mk_supported_shapes(shapes, 256)
+    aot = {(int(shapes[2 * i]), int(shapes[2 * i + 1])) for i in range(min(cnt, 256))}
+    return (N, K) in aot
+
+
+def prune():
+    """Remove prebuilt modules whose source hash is not the current one."""
+    gone = []
+    if os.path.isdir(PREBUILT_DIR):
+        tag = "_%s.so" % _source_hash()
+        for f in os.listdir(PREBUILT_DIR):
+            if f.startswith("mk_shape_") and f.endswith(".so") and not f.endswith(tag):
+                os.remove(os.path.join(PREBUILT_DIR, f))
+                gone.append(f)
+    return gone
+
+
+# the shapes the GPU test tier specialises at run time (tests/test_hip_parity.py, test_adjoint.py, test_hip_layouts.py,
+# test_dk_tape.py, test_gpu_property.py, the golden fixtures): `python -m metran_amd.jit --tests` prebuilds them on the build
+# machine so that the GPU box spends its minutes on kernels, not on hipcc
+TEST_SHAPES = [(7, 2), (11, 3), (14, 2), (20, 2), (16, 2), (32, 1), (48, 3), (17, 1), (17, 3), (20, 4), (11, 6), (12, 3), (9, 2)]
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser(description="prebuild run-time shape modules into metran_amd/_shape_cache")
+    ap.add_argument("shapes", nargs="*", help="e.g. 2-12x1-3 20x2")
+    ap.add_argument("--tests", action="store_true", help="the shapes the GPU test tier uses")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--prune", action="store_true", help="remove modules built from other sources")
+    a = ap.parse_args()
+    if a.prune:
+        for f in prune():
+            print("removed", f)
+    want = parse_shapes(a.shapes) + (TEST_SHAPES if a.tests else [])
+    if want:
+        prebuild(want, jobs=a.jobs)

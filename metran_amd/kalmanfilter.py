@@ -36,7 +36,7 @@ _LAST_UPLOAD = None  # (key, device record) of the observation arrays seqkalmanf
 
 
 def _content_hash(*arrays):
-    """64-bit (xxhash, when importable) or 128-bit (blake2b) digest of the arrays' dtypes, shapes and bytes."""
+    """128-bit digest (xxh3_128 when xxhash is importable, else blake2b) of the arrays' dtypes, shapes and bytes."""
     try:
         import xxhash
 
@@ -48,7 +48,8 @@ def _content_hash(*arrays):
     for a in arrays:
         a = np.ascontiguousarray(a)
         h.update(("%s%s" % (a.dtype.str, a.shape)).encode())
-        h.update(memoryview(a).cast("B"))
+        if a.size:  # (a memoryview with a zero in its shape cannot be cast)
+            h.update(memoryview(a).cast("B"))
     return h.digest()
 
 

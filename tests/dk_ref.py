@@ -45,8 +45,10 @@ def transform(loadings):
     return T
 
 
-def filter_tape(obs, phi, q, loadings, obsvar=None, x0=None, P0=None):
-    """One model.  obs [T,N] (NaN = missing).  Returns tape [T, N, n+4]."""
+def filter_tape(obs, phi, q, loadings, obsvar=None, x0=None, P0=None, state=False):
+    """One model.  obs [T,N] (NaN = missing).  Returns tape [T, N, n+4]; with ``state`` (the STATE tape, MK_OUT_TAPE |
+    MK_OUT_VAR_ONLY) [T, N + K, n+4]: K more entries per step, the factor columns of the filtered covariance in the observable
+    basis,  entry N+k = [ T Pf e_{N+k} (n) | x_f[N+k] | Pf[N+k][N+k] | NaN | 0 ]."""
     Tn, N = obs.shape
     K = loadings.shape[1]
     n = N + K
@@ -55,7 +57,7 @@ def filter_tape(obs, phi, q, loadings, obsvar=None, x0=None, P0=None):
     R = np.zeros(N) if obsvar is None else np.asarray(obsvar, float)
     x = np.zeros(n) if x0 is None else np.array(x0, float)
     P = np.eye(n) if P0 is None else np.array(P0, float)
-    tape = np.zeros((Tn, N, n + 4))
+    tape = np.zeros((Tn, N + K if state else N, n + 4))
     for t in range(Tn):
         x = phi * x
         P = P * np.outer(phi, phi) + np.diag(q)
@@ -77,6 +79,11 @@ def filter_tape(obs, phi, q, loadings, obsvar=None, x0=None, P0=None):
             e = tape[t, u]
             e[:n] = Tm @ d
             e[n:] = (z @ x, z @ d, np.nan, 0.0)
+        if state:
+            for k in range(K):
+                e = tape[t, N + k]
+                e[:n] = Tm @ P[:, N + k]
+                e[n:] = (x[N + k], P[N + k, N + k], np.nan, 0.0)
     return tape
 
 
@@ -124,6 +131,61 @@ def dk_smooth(tape, phi, loadings, obsvar=None):
         r = Pht.T @ r
         Nm = Pht.T @ Nm @ Pht
     return means, variances
+
+
+def dk_smooth_state(tape, phi, loadings):
+    """The STATE outputs from the state tape (filter_tape(..., state=True); R = 0): smoothed state means [T,n] and
+    variances [T,n] in Metran's own basis, next to the projected (means [T,N], variances [T,N]) of dk_smooth -- what
+    smoother_dk_kernel<N,K,false,true> computes (mk_dk.hip).  At the END of a step, with (r, N) before the step's updates,
+        xt_s = xt_f + Pt r,   Vt = Pt - Pt N Pt          (observable basis, Pt = T Pf T')
+    and Pt has zero rows / columns at the series observed at the step (R = 0: the observable IS the observation).  What the
+    state variances need of Vt: its diagonal over the unobserved series (dk_smooth's variances), the K factor columns
+    Vt[., N+k] = Pt[., N+k] - Pt N Pt[., N+k] -- K more products w_k = N pt_{N+k} and then, for every entry a of the step
+    (unobserved series and factors), the K dot products pt_a . w_k -- and nothing else:
+        x_a = xt_a - g_a . xt_F,   V_aa = Vt_aa - 2 g_a . Vt[a, F] + g_a' Vt_FF g_a,   x_{N+k} = xt_{N+k},  V = Vt_FF[k][k]."""
+    Tn, NE, ES = tape.shape
+    n = ES - 4
+    N, K = loadings.shape
+    assert NE == N + K
+    Pht = transition(phi, loadings)
+    r = np.zeros(n)
+    Nm = np.zeros((n, n))
+    S, var = np.empty((Tn, n)), np.empty((Tn, n))
+    means, variances = np.empty((Tn, N)), np.empty((Tn, N))
+    for t in range(Tn - 1, -1, -1):
+        seen = ~np.isnan(tape[t, :N, n + 2])
+        W = np.stack([Nm @ tape[t, N + k, :n] for k in range(K)], axis=1)          # [n, K]  w_k = N pt_{N+k}
+        xf = np.array([tape[t, N + k, n] + tape[t, N + k, :n] @ r for k in range(K)])   # smoothed factor means
+        Vff = np.array([[tape[t, N + k, N + l] - tape[t, N + k, :n] @ W[:, l] for l in range(K)] for k in range(K)])
+        Vff = 0.5 * (Vff + Vff.T)
+        for a in range(N):
+            g = loadings[a]
+            e = tape[t, a]
+            if seen[a]:
+                xt, vaa, vaf = e[n + 2], 0.0, np.zeros(K)
+            else:
+                p = e[:n]
+                xt = e[n] + p @ r
+                vaa = e[n + 1] - p @ Nm @ p
+                vaf = e[N:n] - p @ W                                               # Vt[a, N+k]
+            means[t, a], variances[t, a] = xt, vaa
+            S[t, a] = xt - g @ xf
+            var[t, a] = vaa - 2.0 * g @ vaf + g @ Vff @ g
+        S[t, N:] = xf
+        var[t, N:] = np.diag(Vff)
+        for j in np.nonzero(seen)[0][::-1]:
+            e = tape[t, j]
+            k = e[:n]
+            w = Nm @ k
+            beta, alpha = k @ r, k @ w
+            r[j] += e[n] - beta
+            col = Nm[:, j] - w
+            col[j] = Nm[j, j] - 2.0 * w[j] + alpha + e[n + 1]
+            Nm[:, j] = col
+            Nm[j, :] = col
+        r = Pht.T @ r
+        Nm = Pht.T @ Nm @ Pht
+    return S, var, means, variances
 
 
 def dk_state_moments(obs, phi, q, loadings):

@@ -82,7 +82,9 @@ def test_no_gpu_calls_fail_loudly_not_silently(lib):
 
     with pytest.raises(MetranHipError):
         BatchedKalman()
-    assert lib.mk_abi_version() == 5
+    from metran_amd import _lib as binding
+
+    assert lib.mk_abi_version() == binding.ABI_VERSION == 6
     assert lib.mk_shape_supported(8, 2) == 1 and lib.mk_shape_supported(32, 4) == 1
     assert lib.mk_shape_supported(7, 7) == 0
 
@@ -170,6 +172,8 @@ def test_tape_geometry_without_a_gpu():
     assert L.mk_tape_supported(32, 4) == 1 and L.mk_tape_supported(14, 3) == 1
     assert L.mk_tape_supported(8, 2) == 0            # n <= 16: the 16-lane kernels
     assert L.mk_tape_supported(48, 3) == 0           # N > 32: not a shape of the split filter
+    # the STATE tape (ABI 6, MK_OUT_TAPE | MK_OUT_VAR_ONLY): K more entries per block
+    assert L.mk_state_tape_stride(32, 4) == 36 * 40 and L.mk_state_tape_stride(14, 3) == 17 * 21
     blk = np.arange(14 * 21, dtype=float)
     e = dk_ref.unpack_block(blk, 14, 3)
     assert e.shape == (14, 21) and e[3, 0] == 3 * 21 and e[3, 14] == 3 * 21 + 14 and e[13, 20] == 14 * 21 - 1

@@ -10,6 +10,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# smooth_state_variances at configs[3]'s shape, models/s: the path it replaces (filtered records + the RTS kernel) ran at
+# 31.7 k (profiles/r04/rts_c4_kernel_stats.csv); the floor is that number -- the state tape must never be slower
+STATE_VARIANCES_FLOOR = 31700.0
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +48,11 @@ def test_secondary_configs3_throughput_floor(line):
     assert "32-series/4-factor" in s["workload"] and "T=2000" in s["workload"]
     assert s["roofline"]["bound"] == "fp64" and s["roofline"]["unit"] == "TFLOP/s" and s["roofline"]["peak"] == 78.6
     assert "tape" in s["workload"]               # the inverse-free path (round 4) is what the default run measures
-    assert s["models_per_s"] >= 32000.0, s       # floor (round 2: 24.6 k, round 3: 28.4-31.7 k on records + RTS; round 4 tape path: 35.9-37.6 k)
+    # the floor IS the north-star bar in SURVEY 8d's full-output accounting (0.40 x 8 TB/s / 85.76 MB per model = 37 313 models/s;
+    # a floor of 32 k would have stayed green with configs[3] back under it)
+    bar = s["roofline"]["survey_8d_full_output_accounting"]["north_star_bar"]["models_per_s"]
+    assert 37300.0 < bar < 37330.0
+    assert s["models_per_s"] >= bar, s
     assert 0.0 < s["roofline"]["frac"] < 1.0
     # error figures against the oracle ride in the line
     par = s["parity"]
@@ -55,6 +62,18 @@ def test_secondary_configs3_throughput_floor(line):
     # HBM traffic of its kernels measured in the run
     for k in s["roofline"]["kernels"].values():
         assert k.get("traffic_source", "").startswith("measured in this run"), k
+
+
+def test_secondary_state_variances_of_wide_models(line):
+    """smooth_state_variances on configs[3]'s batch in the driver's line -- on the state tape, parity
+    figures against the oracle riding along."""
+    s = line["secondary"]["c4_state_variances"]
+    assert "error" not in s, s
+    assert s["state_tape"] and "STATE tape" in s["workload"] and "T=2000" in s["workload"]
+    par = s["parity"]
+    assert par["models_compared"] >= 24 and par["loglik_max_rel_err"] < 1e-9, par
+    assert par["state_means_max_abs_err"] < 1e-9 and par["state_vars_max_abs_err"] < 1e-9, par
+    assert s["models_per_s"] >= STATE_VARIANCES_FLOOR, s
 
 
 def test_secondary_configs4_solver_loop(line):

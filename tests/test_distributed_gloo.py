@@ -127,6 +127,24 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res["config"]["name"] == "c2" and res["config"]["batch_per_gpu"] == 4096
 
 
+def test_bench_eight_ranks_default_to_configs2(tmp_path):
+    """``bench.py --gpus 8`` without ``--config`` is configs[2]'s per-GPU share (8192 models: 65536 over 8 GPUs), so the
+    driver's 8-GPU line lands on the BASELINE configuration; fewer ranks stay on configs[1] (checked above).  Dry run (gloo)."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "1",
+                          "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8
+    assert res["config"]["name"] == "c3" and res["config"]["batch_per_gpu"] == 8192 and res["config"]["total_batch"] == 65536
+    assert "configs[2]" in res["config"]["workload"]
+
+
 def _worker_calibrate(rank, world, port, out_dir):
     """Multi-GPU calibration paths on 2 CPU ranks: ``run_sharded`` (per-model parameters:
     slice, local work, rank-order gather -- what ``calibrate_sharded`` wraps around ``calibrate_batch``) and

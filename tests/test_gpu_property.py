@@ -1,0 +1,171 @@
+"""GPU tier: the HIP kernels under the property sweep the CPU restatements got.
+
+tests/hard_models.py draws >= 300 seeded models over every ahead-of-time shape plus two run-time-specialised ones:
+missingness from none to 95 %, empty first / last steps, never-observed series, a single observation, persistence up to
+1 - 1e-9, communalities up to 0.999, observation variances, non-default initial moments, records of one step.  Every model
+goes through every entry point that serves its shape, each against the oracle (C restatement of the reference,
+kalmanfilter.py:236-476, 550-603) or, for the gradient, the numpy adjoint restatement:
+
+  filter_smooth            all six state arrays, sigmas / detfs / sigmacount, -2 log L
+  simulate_smoothed        both projection routes (tape where it exists, filtered records + RTS)
+  smooth_state_variances   both routes (state tape where it exists, records + RTS)
+  loglik                   dense (one record per instance) and sparse (several parameter sets on ONE record, n <= 16)
+  loglik_grad              adjoint kernels against tests/adjoint_ref.py
+
+Tolerances (fp64): -2 log L 1e-9 relative (north-star bar); filtered / predicted moments 1e-10 on the scale of the moments;
+smoothed moments hard_models.smoother_tolerance (1e-9 + the reference algorithm's own eps * cond(Pp));
+gradient 1e-7 relative to its largest component (tests/test_adjoint.py's bar)."""
+import numpy as np
+import pytest
+
+import adjoint_ref
+import hard_models
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def jit_cache(tmp_path_factory):
+    import os
+
+    old = os.environ.get("METRAN_HIP_CACHE")
+    if old is None:
+        os.environ["METRAN_HIP_CACHE"] = str(tmp_path_factory.getbasetemp() / "mkjit")
+    yield
+    if old is None:
+        os.environ.pop("METRAN_HIP_CACHE", None)
+
+
+def _engine(g, layout):
+    from metran_amd.engine import BatchedKalman
+
+    kf = BatchedKalman(0, layout=layout)
+    kf.set_observations(g["obs"]).set_loadings(g["loadings"], g["obsvar"])
+    return kf
+
+
+GROUPS = list(hard_models.groups())
+IDS = ["%dx%d_T%d_B%d" % key for key, _ in GROUPS]
+
+
+def test_sweep_size():
+    assert sum(key[3] for key, _ in GROUPS) >= 300
+    assert {(k[0], k[1]) for k, _ in GROUPS} >= set(hard_models.AOT_SHAPES) | set(hard_models.JIT_SHAPES)
+
+
+@pytest.mark.parametrize("key,g", GROUPS, ids=IDS)
+def test_filter_smooth_property(key, g, jit_cache):
+    N, K, T, B = key
+    layout = "time_major" if (N + T) % 2 else "model_major"
+    kf = _engine(g, layout)
+    r = kf.filter_smooth(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+    from metran_amd.engine import FLAG_NONPOSITIVE_F, FLAG_NOT_SPD
+
+    assert not (int(np.bitwise_or.reduce(_np(r["status"]))) & (FLAG_NONPOSITIVE_F | FLAG_NOT_SPD))
+    for b in range(B):
+        ref = hard_models.oracle_model(oracle, g, b)
+        sc = ref["sigmacount"]
+        what = "model %d (%s)" % (b, g["patterns"][b])
+        assert int(_np(r["sigmacount"])[b]) == sc, what
+        assert abs(_np(r["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+        np.testing.assert_allclose(_np(r["sigmas"])[b, :sc], ref["sigmas"][:sc], rtol=1e-9, atol=1e-10, err_msg=what)
+        np.testing.assert_allclose(_np(r["detfs"])[b, :sc], ref["detfs"][:sc], rtol=0, atol=1e-10, err_msg=what)
+        assert not _np(r["sigmas"])[b, sc:].any() and not _np(r["detfs"])[b, sc:].any(), what
+        scale = max(1.0, float(np.abs(ref["Pp"]).max()), float(np.abs(ref["F"]).max()))
+        for k in ("F", "Pf", "Xp", "Pp"):
+            np.testing.assert_allclose(_np(r[k])[b], ref[k], rtol=0, atol=1e-10 * scale, err_msg=what + " " + k)
+        tol = hard_models.smoother_tolerance(g, b, ref)
+        np.testing.assert_allclose(_np(r["S"])[b], ref["S"], rtol=0, atol=tol, err_msg=what + " S")
+        np.testing.assert_allclose(_np(r["Ps"])[b], ref["Ps"], rtol=0, atol=tol, err_msg=what + " Ps")
+    kf.close()
+
+
+@pytest.mark.parametrize("key,g", GROUPS, ids=IDS)
+def test_projection_and_state_variances_property(key, g, jit_cache):
+    N, K, T, B = key
+    rng = np.random.default_rng(N * 1000 + T)
+    scale, offset = rng.uniform(0.5, 2.0, (B, N)), rng.normal(size=(B, N))
+    kf = _engine(g, "time_major" if T % 2 else "model_major")
+    kf.set_scaling(scale, offset)
+    routes = ["auto", "records"] if kf.tape_path() else ["auto"]
+    refs = [hard_models.oracle_model(oracle, g, b) for b in range(B)]
+    for route in routes:
+        kf.projection_path = route
+        p = kf.simulate_smoothed(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+        s = kf.smooth_state_variances(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+        assert bool(p.get("_tape")) == (route == "auto" and len(routes) == 2)
+        assert bool(s.get("_tape")) == (route == "auto" and len(routes) == 2 and g["obsvar"] is None)
+        for b in range(B):
+            ref = refs[b]
+            what = "model %d (%s), route %s" % (b, g["patterns"][b], route)
+            tol = hard_models.smoother_tolerance(g, b, ref)
+            Z = ref["Z"] * scale[b][:, None]
+            m_ref = ref["S"] @ Z.T + offset[b]
+            v_ref = np.maximum(np.einsum("jn,tnm,jm->tj", Z, ref["Ps"], Z), 0.0)
+            sc2 = float(scale[b].max()) ** 2
+            np.testing.assert_allclose(_np(p["sim_means"])[b], m_ref, rtol=0, atol=2 * tol * sc2, err_msg=what + " sim_means")
+            np.testing.assert_allclose(_np(p["sim_vars"])[b], v_ref, rtol=0, atol=2 * tol * sc2, err_msg=what + " sim_vars")
+            np.testing.assert_allclose(_np(s["S"])[b], ref["S"], rtol=0, atol=tol, err_msg=what + " state means")
+            np.testing.assert_allclose(_np(s["var"])[b], np.diagonal(ref["Ps"], axis1=1, axis2=2), rtol=0, atol=tol,
+                                       err_msg=what + " state variances")
+            for out in (p, s):
+                assert abs(_np(out["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+    kf.close()
+
+
+@pytest.mark.parametrize("key,g", GROUPS, ids=IDS)
+def test_objective_and_gradient_property(key, g, jit_cache):
+    N, K, T, B = key
+    n = N + K
+    kf = _engine(g, "model_major")
+    refs = [hard_models.oracle_model(oracle, g, b, smooth=False) for b in range(B)]
+    want = np.array([r["mle"] for r in refs])
+    # dense objective, every warm-up the reference's indexing quirk distinguishes (compressed vs time index, :550-567)
+    mle = _np(kf.loglik(g["phi"], g["q"], x0=g["x0"], P0=g["P0"]))
+    np.testing.assert_allclose(mle, want, rtol=1e-9, atol=1e-9)
+    for warm in (0, 2):
+        got = _np(kf.loglik(g["phi"], g["q"], warmup=warm, x0=g["x0"], P0=g["P0"]))
+        for b in range(0, B, 3):
+            o, oi, oc = oracle.set_observations(g["obs"][b])
+            sc = refs[b]["sigmacount"]
+            ref = oracle.get_mle(refs[b]["sigmas"][:sc], refs[b]["detfs"][:sc], oc, warmup=warm)
+            assert abs(got[b] - ref) <= 1e-9 * max(1.0, abs(ref)), (b, warm, g["patterns"][b])
+    # adjoint gradient on a few models (the numpy restatement is a Python loop over the updates)
+    if kf.has_adjoint():
+        f, gphi, gq = kf.loglik_grad(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+        np.testing.assert_allclose(_np(f), want, rtol=1e-9, atol=1e-9)
+        for b in range(0, B, max(1, B // 3)):
+            if g["phi"][b].max() > 1.0 - 1e-6:
+                continue   # d/dq of a model with q ~ 1e-9 is ~1e9: covered by the objective itself
+            R = None if g["obsvar"] is None else g["obsvar"][b]
+            _, rphi, rq = adjoint_ref.gradient(g["obs"][b], g["phi"][b], g["q"][b], g["loadings"][b], 1,
+                                               None if g["x0"] is None else g["x0"][b], None if g["P0"] is None else g["P0"][b], R)
+            for got, ref, name in ((_np(gphi)[b], rphi, "gphi"), (_np(gq)[b], rq, "gq")):
+                assert np.abs(got - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (b, name, g["patterns"][b])
+    kf.close()
+    # sparse objective: S parameter sets on ONE record (what Metran.solve's finite differences are), n <= 16
+    if n <= 16:
+        from metran_amd.engine import BatchedKalman
+
+        for b in (0, B - 1):
+            kf = BatchedKalman(0)
+            kf.set_observations(g["obs"][b:b + 1]).set_loadings(g["loadings"][b:b + 1], None if g["obsvar"] is None else g["obsvar"][b:b + 1])
+            S = 5
+            rng = np.random.default_rng(b)
+            phi = np.clip(g["phi"][b][None] * (1.0 + 0.01 * rng.standard_normal((S, n))), 0.0, 1.0 - 1e-10)
+            q = g["q"][b][None] * (1.0 + 0.01 * rng.standard_normal((S, n)))
+            x0 = None if g["x0"] is None else np.repeat(g["x0"][b:b + 1], S, 0)
+            P0 = None if g["P0"] is None else np.repeat(g["P0"][b:b + 1], S, 0)
+            got = _np(kf.loglik(phi, q, x0=x0, P0=P0))
+            for s in range(S):
+                gs = dict(g, phi=phi[s][None], q=q[s][None], obs=g["obs"][b:b + 1], loadings=g["loadings"][b:b + 1],
+                          obsvar=None if g["obsvar"] is None else g["obsvar"][b:b + 1],
+                          x0=None if g["x0"] is None else g["x0"][b:b + 1], P0=None if g["P0"] is None else g["P0"][b:b + 1])
+                ref = hard_models.oracle_model(oracle, gs, 0, smooth=False)["mle"]
+                assert abs(got[s] - ref) <= 1e-9 * max(1.0, abs(ref)), (b, s, g["patterns"][b])
+            kf.close()

@@ -184,7 +184,10 @@ def test_full_size_properties(kf):
     r = kf.filter_smooth(d["phi"], d["q"], outputs=("F", "Pf", "S", "Ps"))
     torch.cuda.synchronize()
     assert not r["status"].any()
-    idx = [0, 1, 63, 64, 2047, 4095]
+    # 72 models: the first and last wavefronts whole (every DPP row and every position of a four-model wavefront), then an
+    # odd stride through the batch (6 of 4096 were compared before)
+    idx = sorted(set(list(range(16)) + list(range(B - 16, B)) + (np.linspace(16, B - 17, 40).astype(np.int64) | 1).tolist()))
+    assert len(idx) >= 64 and {i % 4 for i in idx} == {0, 1, 2, 3}
     sub = {k: _np(d[k][idx]) for k in ("obs", "phi", "q", "loadings")}
     ref = oracle.dfm_batch(sub["obs"], sub["phi"], sub["q"], sub["loadings"])
     assert rel_err(_np(r["mle"][idx]), ref["mle"]) < MLE_RTOL

@@ -1,0 +1,55 @@
+"""CPU tier: the sweep of tests/hard_models.py (the inputs of the GPU property tests) through the oracle and the numpy
+restatements -- every tolerance the GPU tier applies is first shown to hold between two independent CPU implementations of
+the same formulas, and the generator is shown to produce the input classes it promises."""
+import numpy as np
+
+import adjoint_ref
+import dk_ref
+import hard_models
+import oracle
+
+
+def test_generator_covers_the_promised_input_classes():
+    seen, nmodels, extremes, withR, withP0 = set(), 0, 0, 0, 0
+    for (N, K, T, B), g in hard_models.groups():
+        nmodels += B
+        seen |= set(g["patterns"])
+        extremes += int((g["phi"].max(1) > 1.0 - 1e-6).sum())
+        withR += B if g["obsvar"] is not None else 0
+        withP0 += B if g["P0"] is not None else 0
+        for b in range(B):
+            y = g["obs"][b]
+            if g["patterns"][b] in ("first", "both"):
+                assert np.isnan(y[0]).all()
+            if g["patterns"][b] in ("last", "both"):
+                assert np.isnan(y[-1]).all()
+            assert (g["q"][b] > 0).all() and (g["phi"][b] < 1).all()
+    assert nmodels >= 300 and seen == set(hard_models.PATTERNS)
+    assert extremes >= 30 and withR >= 40 and withP0 >= 40
+
+
+def test_sweep_restatements_equal_the_oracle():
+    """(1) the inverse-free recursion (projection and state outputs) against the oracle's smoother on every R = 0,
+    default-initial-moments model of the wide shapes; (2) the adjoint restatement's objective against the oracle's on a
+    sample of all models (observation variances, initial moments, empty first steps: the warm-up quirk)."""
+    checked_dk = checked_mle = 0
+    for (N, K, T, B), g in hard_models.groups():
+        for b in range(B):
+            if b % 4 == 0:
+                ref = hard_models.oracle_model(oracle, g, b, smooth=False)
+                R = None if g["obsvar"] is None else g["obsvar"][b]
+                mle = adjoint_ref.forward(g["obs"][b], g["phi"][b], g["q"][b], g["loadings"][b], 1,
+                                          None if g["x0"] is None else g["x0"][b], None if g["P0"] is None else g["P0"][b], R)[0]
+                assert abs(mle - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"]))
+                checked_mle += 1
+            if N + K > 16 and g["obsvar"] is None and g["P0"] is None and b % 2 == 0:
+                ref = hard_models.oracle_model(oracle, g, b)
+                tol = hard_models.smoother_tolerance(g, b, ref)
+                tape = dk_ref.filter_tape(g["obs"][b], g["phi"][b], g["q"][b], g["loadings"][b], state=True)
+                S, var, m, v = dk_ref.dk_smooth_state(tape, g["phi"][b], g["loadings"][b])
+                np.testing.assert_allclose(S, ref["S"], atol=tol)
+                np.testing.assert_allclose(var, np.diagonal(ref["Ps"], axis1=1, axis2=2), atol=tol)
+                np.testing.assert_allclose(m, ref["S"] @ ref["Z"].T, atol=tol)
+                np.testing.assert_allclose(v, np.einsum("jn,tnm,jm->tj", ref["Z"], ref["Ps"], ref["Z"]), atol=tol)
+                checked_dk += 1
+    assert checked_dk >= 10 and checked_mle >= 75
