@@ -47,7 +47,7 @@ extern "C" {
 typedef enum mk_status {
     MK_OK = 0,
     MK_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, ...) */
-    MK_ERR_SHAPE = -2,       /* (N,K) has no compiled kernel (see mk_shape_supported) */
+    MK_ERR_SHAPE = -2,       /* (N,K) is not served, or not in the asked-for mode (see mk_shape_supported) */
     MK_ERR_HIP = -3,         /* a HIP runtime call failed */
     MK_ERR_NO_DEVICE = -4,   /* no gfx950 device visible */
     MK_ERR_ALLOC = -5
@@ -187,8 +187,16 @@ MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value);
  * data derived from it (the observed-step list of the sparse objective, see mk_loglik) is rebuilt on the next call.
  * Not needed when a different buffer is passed. */
 MK_API int mk_observations_changed(mk_context *ctx);
-/* 1 if a kernel for (N,K) is compiled into the library. */
+/* 1 if the library serves (N,K): a SPECIALISED kernel (compiled ahead of time, or a registered shape module: N + K <= 64,
+ * fully unrolled over the state dimension -- the fast path) or, for every other shape with N + K <= mk_generic_max_states()
+ * (= 128), the SIZE-GENERIC kernels of mk_generic.hip (one model per workgroup, covariance in LDS; correct for any shape,
+ * tuned for none: the reference's loops are size-generic too, kalmanfilter.py:315-390, 453-474).  mk_shape_specialised tells
+ * which.  Generic shapes run mk_filter / mk_loglik / mk_smooth / mk_filter_smooth with dense arrays or full-square records,
+ * projection and MK_OUT_VAR_ONLY outputs; they have no packed-symmetric records, no tape and no adjoint gradient
+ * (MK_ERR_SHAPE). */
 MK_API int mk_shape_supported(int64_t N, int64_t K);
+MK_API int mk_shape_specialised(int64_t N, int64_t K);
+MK_API int64_t mk_generic_max_states(void);
 /* Register a run-time shape module: a shared object built from metran_amd/csrc/mk_kernels.hip with
  * -DMK_SHAPE_MODULE '-DMK_SHAPES(X)=X(N,K)' (hipcc --offload-arch=gfx950).  The kernels are fully
  * unrolled over the state dimension, so a model shape outside the ahead-of-time list gets its own
@@ -221,6 +229,16 @@ MK_API int mk_params_from_alpha(mk_context *ctx, int64_t B, int64_t R, int64_t N
                                 const double *d_alpha /* [B,n] */,
                                 const double *d_loadings /* [R,N,K] */, double dt,
                                 double *d_phi /* [B,n] */, double *d_q /* [B,n] */);
+
+/* kalmansmoother in its literal 5-argument form for B models (kalmanfilter.py:403-476: filtered_state_means [B,T,n],
+ * filtered_state_covariances [B,T,n,n], predicted_state_means, predicted_state_covariances, diag of transition_matrix [B,n])
+ * -> d_S [B,T,n], d_Ps [B,T,n,n] (either may be NULL).  The predicted moments are READ, not recomputed (:454-474 use
+ * predicted_state_covariances[t+1] and predicted_state_means[t+1] as handed in), so no transition covariance is needed and a
+ * caller's own predicted moments are honoured.  Size-generic kernel (mk_generic.hip), n <= mk_generic_max_states(); dense
+ * model-major arrays.  The fast path for moments that came out of mk_filter is mk_smooth / mk_filter_smooth. */
+MK_API int mk_smooth_dense(mk_context *ctx, int64_t B, int64_t T, int64_t n, const double *d_phi, const double *d_F,
+                           const double *d_Pf, const double *d_Xp, const double *d_Pp, double *d_S, double *d_Ps,
+                           uint32_t *d_status);
 
 /* seqkalmanfilter + get_mle for B instances (kalmanfilter.py:236-400, 550-567).
  * Uses d_mle, d_sigmas, d_detfs, d_sigmacount, d_F, d_Pf, d_Xp, d_Pp, d_status of `out`. */

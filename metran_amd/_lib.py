@@ -81,6 +81,8 @@ API = {
     "mk_sync": (c_int, [c_void_p]),
     "mk_observations_changed": (c_int, [c_void_p]),
     "mk_shape_supported": (c_int, [c_int64, c_int64]),
+    "mk_shape_specialised": (c_int, [c_int64, c_int64]),
+    "mk_generic_max_states": (c_int64, []),
     "mk_register_shape_module": (c_int, [c_char_p]),
     "mk_record_stride": (c_int64, [c_int64]),
     "mk_record_stride_sym": (c_int64, [c_int64]),
@@ -99,6 +101,8 @@ API = {
     "mk_loglik": (c_int, [c_void_p, POINTER(Problem), c_void_p]),
     "mk_smooth": (c_int, [c_void_p, POINTER(Problem), POINTER(Outputs)]),
     "mk_filter_smooth": (c_int, [c_void_p, POINTER(Problem), POINTER(Outputs)]),
+    "mk_smooth_dense": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
     "mk_simulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p]),
     "mk_decompose": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

@@ -11,6 +11,7 @@
 #include <vector>
 #include <new>
 
+#include "mk_generic.h"
 #include "mk_internal.h"
 
 struct mk_context {
@@ -28,6 +29,8 @@ struct mk_context {
     const double *tlist_obs;
     long tlist_T, tlist_N, tlist_ostep;
     int variant[MK_VARIANT_COUNT]; // mk_set_kernel_variant: which of two equivalent (tested) kernels serves a shape class
+    double *gws;       // workspace of the size-generic smoother (mk_generic.hip), grown on demand
+    size_t gws_cap;    // ... in doubles
 };
 
 static thread_local char g_err[512] = "";
@@ -117,10 +120,13 @@ bool aot_state_dim(int64_t n)
     }
     return false;
 }
+bool specialised(int64_t N, int64_t K) { return aot_shape(N, K) || find_module(N, K) != nullptr; }
+bool generic_shape(int64_t N, int64_t K) { return N >= 1 && K >= 1 && N + K <= MK_GENERIC_MAX_STATES; }
 hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s)
 {
     if (aot_shape(N, K)) return mk::launch_filter(N, K, a, s);
     if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_filter(&a, (void *)s);
+    if (generic_shape(N, K)) return mk::launch_filter_generic(N, K, a, s); // any shape, not specialised (mk_generic.hip)
     return hipErrorInvalidValue;
 }
 hipError_t dispatch_sparse(int N, int K, const mk::SparseArgs &a, hipStream_t s)
@@ -135,12 +141,42 @@ hipError_t dispatch_adjoint(int N, int K, const mk::AdjointArgs &a, hipStream_t 
     if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_adjoint(&a, (void *)s);
     return hipErrorInvalidValue;
 }
-hipError_t dispatch_smoother(int N, int K, const mk::SmootherArgs &a, hipStream_t s)
+// workspace of the generic smoother: grown on demand, stream-ordered reuse (every launch of a context is on its stream)
+hipError_t generic_workspace(mk_context *ctx, long B, int n, double **ws)
+{
+    const size_t need = mk::generic_smoother_ws_doubles(B, n);
+    if (ctx->gws_cap < need) {
+        if (ctx->gws) {
+            hipError_t e = hipStreamSynchronize(ctx->stream); // a launch still reading the old buffer
+            if (e != hipSuccess) return e;
+            e = hipFree(ctx->gws);
+            if (e != hipSuccess) return e;
+        }
+        ctx->gws = nullptr;
+        ctx->gws_cap = 0;
+        const hipError_t e = hipMalloc((void **)&ctx->gws, need * sizeof(double));
+        if (e != hipSuccess) return e;
+        ctx->gws_cap = need;
+    }
+    *ws = ctx->gws;
+    return hipSuccess;
+}
+hipError_t dispatch_smoother(mk_context *ctx, int N, int K, const mk::SmootherArgs &a, hipStream_t s)
 {
     // the plain smoother depends on n = N + K only; the projecting one needs the exact (N, K)
     const bool proj = a.sim_means || a.sim_vars;
     if (proj ? aot_shape(N, K) : aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
     if (const ShapeModule *m = find_module(N, K, !proj)) return (hipError_t)m->launch_smoother(&a, (void *)s);
+    if (generic_shape(N, K)) {
+        mk::GenericSmootherArgs g;
+        g.a = a;
+        g.N = N;
+        g.K = K;
+        g.Xp = g.Pp = nullptr;
+        const hipError_t e = generic_workspace(ctx, a.B, N + K, &g.ws);
+        if (e != hipSuccess) return e;
+        return mk::launch_smoother_generic(g, s);
+    }
     return hipErrorInvalidValue;
 }
 } // namespace
@@ -222,6 +258,8 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->tlist_cap = 0;
     ctx->tlist_obs = nullptr;
     ctx->tlist_T = ctx->tlist_N = ctx->tlist_ostep = 0;
+    ctx->gws = nullptr;
+    ctx->gws_cap = 0;
     for (int &v : ctx->variant) v = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
@@ -245,6 +283,7 @@ MK_API int mk_destroy(mk_context *ctx)
             (void)hipEventDestroy(pr.second);
         }
     if (ctx->tlist) (void)hipFree(ctx->tlist);
+    if (ctx->gws) (void)hipFree(ctx->gws);
     delete ctx;
     return MK_OK;
 }
@@ -291,8 +330,10 @@ MK_API int mk_sync(mk_context *ctx)
 
 MK_API int mk_shape_supported(int64_t N, int64_t K)
 {
-    return (aot_shape(N, K) || find_module(N, K)) ? 1 : 0;
+    return (specialised(N, K) || generic_shape(N, K)) ? 1 : 0;
 }
+MK_API int mk_shape_specialised(int64_t N, int64_t K) { return specialised(N, K) ? 1 : 0; }
+MK_API int64_t mk_generic_max_states(void) { return MK_GENERIC_MAX_STATES; }
 
 MK_API int64_t mk_record_stride(int64_t n) { return mk::record_stride((int)n); }
 MK_API int64_t mk_record_stride_sym(int64_t n) { return mk::record_stride_sym((int)n); }
@@ -300,7 +341,7 @@ MK_API int64_t mk_tape_stride(int64_t N, int64_t K) { return mk::tape_stride_c((
 MK_API int64_t mk_state_tape_stride(int64_t N, int64_t K) { return mk::state_tape_stride_c((int)N, (int)K); }
 MK_API int mk_tape_supported(int64_t N, int64_t K)
 {
-    return (N + K > 16 && N <= 32 && K <= 16 && N + K + 1 <= 64 && mk_shape_supported(N, K)) ? 1 : 0;
+    return (N + K > 16 && N <= 32 && K <= 16 && N + K + 1 <= 64 && specialised(N, K)) ? 1 : 0;
 }
 // MK_OUT_TAPE (mk_outputs.flags): 0 = not asked for, 1 = asked for and consistent, 2 = the STATE tape (with MK_OUT_VAR_ONLY:
 // d_S / d_Ps are the smoothed state means / variances [B,T,n]), < 0 = an inconsistent description
@@ -421,9 +462,9 @@ static int check_problem(const mk_problem *p)
     if (p->warmup < 0) return fail(MK_ERR_INVALID, "warmup must be >= 0");
     if (!mk_shape_supported(p->N, p->K))
         return fail(MK_ERR_SHAPE,
-                    "no kernel for (N=%lld series, K=%lld factors): build a shape module (metran_amd.jit.ensure_shape, "
-                    "mk_register_shape_module) or add X(%lld, %lld) to MK_SHAPES in metran_amd/csrc/mk_internal.h",
-                    (long long)p->N, (long long)p->K, (long long)p->N, (long long)p->K);
+                    "no kernel for (N=%lld series, K=%lld factors): the size-generic kernels serve N + K <= %d states, specialised "
+                    "ones (metran_amd.jit.ensure_shape / mk_register_shape_module / MK_SHAPES in mk_internal.h) N + K <= 64",
+                    (long long)p->N, (long long)p->K, MK_GENERIC_MAX_STATES);
     if (!p->d_phi || !p->d_q) return fail(MK_ERR_INVALID, "d_phi and d_q are required");
     return MK_OK;
 }
@@ -493,6 +534,9 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.Xp = o->d_Xp;
     a.Pp = o->d_Pp;
     a.status = o->d_status;
+    if (a.sym && !specialised(p->N, p->K))
+        return fail(MK_ERR_SHAPE, "packed-symmetric records exist for specialised shapes only (N=%lld, K=%lld runs the size-generic "
+                                  "kernels: mk_shape_specialised)", (long long)p->N, (long long)p->K);
     MK_HIP(timing_start(ctx, 0));
     MK_HIP(dispatch_filter((int)p->N, (int)p->K, a, ctx->stream));
     MK_HIP(timing_stop(ctx, 0));
@@ -565,7 +609,10 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     }
     a.status = o->d_status;
     MK_HIP(timing_start(ctx, 1));
-    MK_HIP(dispatch_smoother((int)p->N, (int)p->K, a, ctx->stream));
+    if ((sym || tape) && !specialised(p->N, p->K))
+        return fail(MK_ERR_SHAPE, "packed-symmetric records and the tape exist for specialised shapes only (N=%lld, K=%lld runs the "
+                                  "size-generic kernels: mk_shape_specialised)", (long long)p->N, (long long)p->K);
+    MK_HIP(dispatch_smoother(ctx, (int)p->N, (int)p->K, a, ctx->stream));
     MK_HIP(timing_stop(ctx, 1));
     return MK_OK;
 }
@@ -583,7 +630,7 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
     MK_CTX(ctx);
     if (int rc = check_problem(p)) return rc;
     if (!d_mle) return fail(MK_ERR_INVALID, "d_mle is required");
-    if (p->n_records == 1 && p->N + p->K <= 16 && p->d_obs && p->d_loadings ) {
+    if (p->n_records == 1 && p->N + p->K <= 16 && p->d_obs && p->d_loadings && specialised(p->N, p->K)) {
         // every instance shares the one record (the solver's finite-difference points): walk only its
         // observed steps, the runs of empty steps in closed form (loglik_sparse_kernel)
         if (ctx->tlist_cap < p->T + 1) {
@@ -635,6 +682,39 @@ MK_API int mk_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (int rc = check_problem(p)) return rc;
     if (!o) return fail(MK_ERR_INVALID, "null mk_outputs");
     return do_smooth(ctx, p, o);
+}
+
+MK_API int mk_smooth_dense(mk_context *ctx, int64_t B, int64_t T, int64_t n, const double *d_phi, const double *d_F,
+                           const double *d_Pf, const double *d_Xp, const double *d_Pp, double *d_S, double *d_Ps, uint32_t *d_status)
+{
+    MK_CTX(ctx);
+    if (B <= 0 || T <= 0 || n <= 0 || !d_phi || !d_F || !d_Pf || !d_Xp || !d_Pp || !(d_S || d_Ps))
+        return fail(MK_ERR_INVALID, "mk_smooth_dense: bad argument (all five inputs and one of d_S / d_Ps are required)");
+    if (n > MK_GENERIC_MAX_STATES)
+        return fail(MK_ERR_SHAPE, "mk_smooth_dense serves n <= %d states (got %lld)", MK_GENERIC_MAX_STATES, (long long)n);
+    mk::GenericSmootherArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a.B = B;
+    g.a.T = T;
+    g.a.bs = T; // dense [B,T,...] arrays, the reference's layout with a leading batch axis
+    g.a.ts = 1;
+    g.a.R = 1;
+    g.a.phi = d_phi;
+    g.a.q = nullptr; // not needed: the predicted covariances are the caller's
+    g.a.F = d_F;
+    g.a.Pf = d_Pf;
+    g.a.S = d_S;
+    g.a.Ps = d_Ps;
+    g.a.status = d_status;
+    g.N = (int)n; // no projection outputs: only n = N + K matters
+    g.K = 0;
+    g.Xp = d_Xp;
+    g.Pp = d_Pp;
+    MK_HIP(generic_workspace(ctx, B, (int)n, &g.ws));
+    MK_HIP(timing_start(ctx, 1));
+    MK_HIP(mk::launch_smoother_generic(g, ctx->stream));
+    MK_HIP(timing_stop(ctx, 1));
+    return MK_OK;
 }
 
 MK_API int mk_filter_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
@@ -693,6 +773,10 @@ MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *p, double *d
     if (!d_work || !d_sigmacount || ((phases & MK_GRAD_FORWARD) && !d_mle) || ((phases & MK_GRAD_BACKWARD) && (!d_gphi || !d_gq)))
         return fail(MK_ERR_INVALID, "mk_loglik_grad: d_work and d_sigmacount are required; d_mle by the forward pass, d_gphi and d_gq by the backward pass");
     const int64_t n = p->N + p->K;
+    if (!specialised(p->N, p->K))
+        return fail(MK_ERR_SHAPE, "the adjoint gradient exists for specialised shapes (N + K <= 64: ahead-of-time list or a shape "
+                                  "module); N=%lld, K=%lld runs the size-generic kernels, difference mk_loglik instead",
+                    (long long)p->N, (long long)p->K);
     // forward pass: filtered records only (+ per-step bookkeeping in the record pads), objective, step count
     mk_outputs o;
     memset(&o, 0, sizeof(o));

@@ -197,9 +197,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     double *omean = a.sim_means ? a.sim_means + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
     double *ovar = a.sim_vars ? a.sim_vars + (inst * a.bs + (T - 1) * a.ts) * N + js : nullptr;
     const long ostep = a.ts * N;
-    [[maybe_unused]] const int sl = lane < n ? lane : n - 1; // STATE: the state this lane writes (lanes >= n replicate n - 1)
-    [[maybe_unused]] double *osm = (STATE && a.state_means) ? a.state_means + (inst * a.bs + (T - 1) * a.ts) * n + sl : nullptr;
-    [[maybe_unused]] double *osv = (STATE && a.state_vars) ? a.state_vars + (inst * a.bs + (T - 1) * a.ts) * n + sl : nullptr;
+    [[maybe_unused]] const int sl = lane < n ? lane : n - 1; // STATE: the entry this lane reads (lanes >= n: any valid one)
+    // lane a < n writes state a; the lanes beyond hold the r row's replicas and write nothing (two exec-masked stores a step)
+    [[maybe_unused]] double *osm = (STATE && a.state_means && lane < n) ? a.state_means + (inst * a.bs + (T - 1) * a.ts) * n + lane : nullptr;
+    [[maybe_unused]] double *osv = (STATE && a.state_vars && lane < n) ? a.state_vars + (inst * a.bs + (T - 1) * a.ts) * n + lane : nullptr;
     [[maybe_unused]] const long sstep = a.ts * n;
 
     fetch_block(tb);

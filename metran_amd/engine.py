@@ -9,11 +9,14 @@ simulate / decompose`` (/root/reference/metran/kalmanfilter.py:520-778) and
 ``Metran._get_matrices`` (metran/metran.py:386-416).
 """
 import ctypes
+import logging
 
 import numpy as np
 
 from . import _lib
 from ._lib import MetranHipError, Outputs, Problem, check
+
+logger = logging.getLogger(__name__)
 
 __all__ = ["BatchedKalman", "MetranHipError", "FLAG_NONPOSITIVE_F", "FLAG_NOT_SPD", "FLAG_RANK_DEFICIENT"]
 
@@ -271,10 +274,7 @@ class BatchedKalman:
         if tuple(self.loadings.shape[:2]) != (self.R, self.N):
             raise ValueError("loadings must be [R=%d,N=%d,K], got %s" % (self.R, self.N, tuple(self.loadings.shape)))
         self.K = int(self.loadings.shape[2])
-        if not self._L.mk_shape_supported(self.N, self.K):
-            from . import jit
-
-            jit.ensure_shape(self.N, self.K)  # builds + registers a specialised kernel module (cached)
+        self._ensure_kernels()
         if obsvar is not None:
             if not isinstance(obsvar, torch.Tensor):
                 obsvar = np.asarray(obsvar, dtype=np.float64)
@@ -284,6 +284,35 @@ class BatchedKalman:
         else:
             self.obsvar = None
         return self
+
+    def _ensure_kernels(self):
+        """Kernels for this engine's (N, K).  A shape of the ahead-of-time list runs as it is; any other shape with
+        N + K <= 64 gets its own specialised module (``metran_amd/jit.py``: prebuilt under ``metran_amd/_shape_cache``, cached
+        per user, or compiled now by hipcc); where that is not possible -- no hipcc on the machine, ``METRAN_HIP_JIT=0``,
+        or N + K > 64 -- the size-generic kernels serve the shape (``mk_generic.hip``, N + K <= 128: correct for every
+        shape, an order of magnitude slower; no packed-symmetric records, tape or adjoint gradient)."""
+        if self._L.mk_shape_specialised(self.N, self.K):
+            return
+        why = None
+        if self.n <= 64:
+            from . import jit
+
+            try:
+                jit.ensure_shape(self.N, self.K)  # builds + registers a specialised kernel module (cached)
+                return
+            except MetranHipError as e:
+                why = str(e).splitlines()[0]
+        if not self._L.mk_shape_supported(self.N, self.K):
+            raise MetranHipError("a model of N=%d series and K=%d factors has %d states; the library serves N + K <= %d"
+                                 % (self.N, self.K, self.n, int(self._L.mk_generic_max_states())))
+        if self.packed_sym:
+            raise MetranHipError("packed-symmetric records need specialised kernels; (N=%d, K=%d) runs the size-generic ones%s"
+                                 % (self.N, self.K, " (%s)" % why if why else ""))
+        logger.info("(N=%d, K=%d) runs the size-generic kernels%s", self.N, self.K, ": " + why if why else " (N + K > 64)")
+
+    def specialised(self):
+        """True when this engine's shape runs the specialised (unrolled, one-state-per-lane) kernels, False for the size-generic ones."""
+        return bool(self._L.mk_shape_specialised(self.N, self.K))
 
     def subset(self, index):
         """A new engine holding the records ``index`` (1-D integer tensor / array of record numbers) of this one: the
@@ -446,7 +475,7 @@ class BatchedKalman:
     def has_adjoint(self):
         """Whether ``loglik_grad`` (``mk_loglik_grad``) serves this engine's shape: ``adjoint_kernel`` for n <= 16 (four
         models per wavefront), ``adjoint_wide_kernel`` for 16 < n <= 64 (one model per wavefront)."""
-        return self.N is not None and self.n <= 64
+        return self.N is not None and self.n <= 64 and self.specialised()
 
     def loglik_grad_alpha(self, alpha, dt=1.0, warmup=1):
         """``(mle [B], d mle / d alpha [B,n])`` for Metran's parametrisation (``params_from_alpha`` forward,
@@ -676,8 +705,10 @@ class BatchedKalman:
         phi = self._dev(phi, (B, n), "phi")
         q = self._dev(q, (B, n), "q")
         shape = [(N, K) for (N, K) in self.supported_shapes() if N + K == n]
+        if not shape and n >= 2 and self._L.mk_shape_supported(n - 1, 1):
+            shape = [(n - 1, 1)]  # no specialised kernel of this state dimension: the size-generic smoother (it depends on n only)
         if not shape:
-            raise MetranHipError("no HIP smoother kernel compiled for state dimension n=%d" % n)
+            raise MetranHipError("no HIP smoother kernel for state dimension n=%d" % n)
         N, K = shape[0]
         prob = Problem(B, 1, T, N, K, 1, None, self._p(phi), self._p(q), None, None, None, None, 0, None, None)
         torch = _torch()
@@ -689,6 +720,25 @@ class BatchedKalman:
         o = self._outputs_struct(res)
         self._bind_stream()
         check(self._L.mk_smooth(self._ctx, ctypes.byref(prob), ctypes.byref(o)))
+        return res
+
+    def smooth_dense(self, phi, F, Pf, Xp, Pp):
+        """``kalmansmoother`` in its literal 5-argument form (kalmanfilter.py:403-476) for B models: the predicted moments
+        ``Xp [B,T,n]``, ``Pp [B,T,n,n]`` are READ as handed in (:454-474), not recomputed from the filtered ones -- for
+        moments that did not come out of this engine's own filter.  ``mk_smooth_dense`` (size-generic kernel, n <= 128).
+        Returns a dict with ``S [B,T,n]``, ``Ps [B,T,n,n]``, ``status [B]``."""
+        torch = _torch()
+        F, Pf, Xp, Pp = (self._dev(a) for a in (F, Pf, Xp, Pp))
+        B, T, n = (int(s) for s in F.shape)
+        if tuple(Pf.shape) != (B, T, n, n) or tuple(Xp.shape) != (B, T, n) or tuple(Pp.shape) != (B, T, n, n):
+            raise ValueError("F, Xp must be [B,T,n] and Pf, Pp [B,T,n,n]")
+        phi = self._dev(phi, (B, n), "phi")
+        res = {"S": torch.empty((B, T, n), dtype=torch.float64, device=self.device),
+               "Ps": torch.empty((B, T, n, n), dtype=torch.float64, device=self.device),
+               "status": torch.zeros(B, dtype=torch.int32, device=self.device)}
+        self._bind_stream()
+        check(self._L.mk_smooth_dense(self._ctx, B, T, n, self._p(phi), self._p(F), self._p(Pf), self._p(Xp), self._p(Pp),
+                                      self._p(res["S"]), self._p(res["Ps"]), self._p(res["status"])))
         return res
 
     # ------------------------------------------------------------------ projection epilogues

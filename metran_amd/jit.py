@@ -28,9 +28,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 # every file a shape module is compiled from, directly or through an #include (mk_prims.h includes the GENERATED
 # mk_sweeps.h: regenerating the sweeps must invalidate cached modules too)
-_SOURCES = [os.path.join(_HERE, "csrc", "mk_kernels.hip"), os.path.join(_HERE, "csrc", "mk_wide.hip"),
-            os.path.join(_HERE, "csrc", "mk_split.hip"), os.path.join(_HERE, "csrc", "mk_dk.hip")] + sorted(
-    os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h")) + [
+_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("mk_kernels.hip", "mk_wide.hip", "mk_split.hip", "mk_dk.hip",
+                                                     "mk_internal.h", "mk_jump.h", "mk_prims.h", "mk_sweeps.h")] + [
     os.path.join(_ROOT, "include", "metran_hip.h")]
 
 
@@ -129,11 +128,11 @@ def build_shape_module(N, K, out=None):
 def ensure_shape(N, K):
     """Make kernels for (N, K) available in the loaded library (no-op for ahead-of-time shapes)."""
     L = _lib.lib()
-    if L.mk_shape_supported(N, K):
+    if L.mk_shape_specialised(N, K):
         return False
     path = build_shape_module(int(N), int(K))
     _lib.check(L.mk_register_shape_module(path.encode()))
-    if not L.mk_shape_supported(N, K):
+    if not L.mk_shape_specialised(N, K):
         raise MetranHipError("shape module %s did not register (N=%d, K=%d)" % (path, N, K))
     return True
 

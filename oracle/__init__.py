@@ -156,3 +156,48 @@ def dfm_batch(obs, phi, q, loadings, obsvar=None, warmup=1, smooth=True, outputs
 
 def num_threads(native=False):
     return int(load(native).oracle_num_threads())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The OPTIMISED CPU leg (oracle/kalman_fast.c): same recursions written for speed (diagonal Phi / Q and Z = [I | G]
+# exploited, Cholesky instead of pinv, -ffp-contract=fast); bench.py's ``cpu_baseline_optimised``.  Not the checker:
+# tests/test_oracle_golden.py checks IT against the checker.
+_FAST = {}
+
+
+def load_fast(native=False):
+    if native not in _FAST:
+        path = os.path.join(_HERE, "libkalman_fast_native.so" if native else "libkalman_fast.so")
+        if not os.path.exists(path):
+            build(native)
+        lib = ctypes.CDLL(path)
+        lib.fast_dfm_batch.restype = ctypes.c_int64
+        lib.fast_num_threads.restype = ctypes.c_int
+        _FAST[native] = lib
+    return _FAST[native]
+
+
+def fast_dfm_batch(obs, phi, q, loadings, warmup=1, outputs="all", native=False):
+    """B models through oracle/kalman_fast.c.  outputs: "all" (six state arrays) | "means" (projected smoothed means /
+    variances) | "mle".  Returns a dict (with ``bad`` = number of models the fast path cannot serve: a non-positive
+    innovation variance or a predicted covariance that is not positive definite)."""
+    obs, phi, q, loadings = _c(obs), _c(phi), _c(q), _c(loadings)
+    B, T, N = obs.shape
+    K = loadings.shape[2]
+    n = N + K
+    res = dict(mle=np.empty(B))
+    mode = {"mle": 0, "means": 1, "all": 2}[outputs]
+    if mode == 2:
+        res.update(F=np.empty((B, T, n)), Xp=np.empty((B, T, n)), S=np.empty((B, T, n)), Pf=np.empty((B, T, n, n)),
+                   Pp=np.empty((B, T, n, n)), Ps=np.empty((B, T, n, n)))
+    if mode == 1:
+        res.update(sim_means=np.empty((B, T, N)), sim_vars=np.empty((B, T, N)))
+    res["bad"] = int(load_fast(native).fast_dfm_batch(
+        i64(B), i64(T), i64(N), i64(K), _d(obs), _d(phi), _d(q), _d(loadings), i64(warmup), ctypes.c_int(mode), _d(res["mle"]),
+        _d(res.get("F")), _d(res.get("Pf")), _d(res.get("Xp")), _d(res.get("Pp")), _d(res.get("S")), _d(res.get("Ps")),
+        _d(res.get("sim_means")), _d(res.get("sim_vars"))))
+    return res
+
+
+def fast_num_threads(native=False):
+    return int(load_fast(native).fast_num_threads())

@@ -157,6 +157,12 @@ class OracleFilterEngine:
         S, Ps = oracle.kalmansmoother(F, Pf, Xp, Pp, np.diag(ph))
         return {"S": torch.from_numpy(S)[None], "Ps": torch.from_numpy(Ps)[None], "status": torch.zeros(1, dtype=torch.int32)}
 
+    def smooth_dense(self, phi, F, Pf, Xp, Pp):
+        self.calls.append("smooth_dense")
+        a = lambda v: (v[0].numpy() if isinstance(v, torch.Tensor) else np.asarray(v)[0])  # noqa: E731
+        S, Ps = oracle.kalmansmoother(a(F), a(Pf), a(Xp), a(Pp), np.diag(np.asarray(phi, float)[0]))
+        return {"S": torch.from_numpy(S)[None], "Ps": torch.from_numpy(Ps)[None], "status": torch.zeros(1, dtype=torch.int32)}
+
     def filter_smooth(self, phi, q, warmup=1):
         r = self.filter(phi, q, warmup)
         S, Ps = oracle.kalmansmoother(r["F"][0].numpy(), r["Pf"][0].numpy(), r["Xp"][0].numpy(), r["Pp"][0].numpy(), np.diag(phi[0]))

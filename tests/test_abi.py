@@ -86,7 +86,12 @@ def test_no_gpu_calls_fail_loudly_not_silently(lib):
 
     assert lib.mk_abi_version() == binding.ABI_VERSION == 6
     assert lib.mk_shape_supported(8, 2) == 1 and lib.mk_shape_supported(32, 4) == 1
-    assert lib.mk_shape_supported(7, 7) == 0
+    # (7, 7) has no specialised kernel here (not in the ahead-of-time list, no module registered) and runs the size-generic
+    # ones; beyond 128 states nothing serves a shape
+    assert lib.mk_shape_specialised(8, 2) == 1 and lib.mk_shape_specialised(7, 7) == 0
+    assert lib.mk_shape_supported(7, 7) == 1 and lib.mk_shape_supported(70, 3) == 1 and lib.mk_shape_supported(100, 28) == 1
+    assert lib.mk_shape_supported(100, 29) == 0 and lib.mk_generic_max_states() == 128
+    assert lib.mk_tape_supported(17, 3) == 0         # the tape needs a specialised module
 
 
 def test_graft_entry_build_passes():

@@ -74,7 +74,9 @@ def test_filter_smooth_property(key, g, jit_cache):
         assert int(_np(r["sigmacount"])[b]) == sc, what
         assert abs(_np(r["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
         np.testing.assert_allclose(_np(r["sigmas"])[b, :sc], ref["sigmas"][:sc], rtol=1e-9, atol=1e-10, err_msg=what)
-        np.testing.assert_allclose(_np(r["detfs"])[b, :sc], ref["detfs"][:sc], rtol=0, atol=1e-10, err_msg=what)
+        # log f of an innovation variance that is a ~q-sized difference of O(1) covariances carries eps / q of relative error in f
+        np.testing.assert_allclose(_np(r["detfs"])[b, :sc], ref["detfs"][:sc], rtol=0, atol=1e-10 + 1e-15 / float(g["q"][b].min()),
+                                   err_msg=what)
         assert not _np(r["sigmas"])[b, sc:].any() and not _np(r["detfs"])[b, sc:].any(), what
         scale = max(1.0, float(np.abs(ref["Pp"]).max()), float(np.abs(ref["F"]).max()))
         for k in ("F", "Pf", "Xp", "Pp"):

