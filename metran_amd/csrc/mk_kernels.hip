@@ -1600,7 +1600,13 @@ __global__ void __launch_bounds__(256) adjoint_kernel(AdjointArgs a)
     static_assert(G == 16 && n <= 16, "adjoint kernel: one model per 16-lane group");
     using Gp = Group<G>;
     constexpr int GPB = 256 / G;
-    constexpr bool HOIST = (N * K <= 32);
+    // Registers decide this kernel's speed (round 5): with more than 256 (VGPRs + AGPRs) a SIMD holds ONE wavefront of it, and
+    // a flight of 8192 models -- 2048 wavefronts on 1024 SIMDs -- runs as two rounds of a latency-bound kernel (round 4: 294
+    // registers, 4.85 ms against 1.72 ms for the recording forward pass).  What was hoisted for speed is therefore kept small:
+    // the loadings of series j reach the multiply-adds as DPP broadcasts of the lanes' own `gam` (no N x K table), element r
+    // of every observation row Z_j is one array zt[N], and the innovation / reciprocal variance of update j wait in lane j
+    // alone (two registers instead of 2 N) and are broadcast on the way back.
+    constexpr bool FUSED = Sweeps<n>::fused; // whole sums as ONE asm statement (mk_sweeps.h): no padding nops in dependent chains
     const int lane = threadIdx.x % G;
     long inst = (long)blockIdx.x * GPB + threadIdx.x / G;
     const bool live = inst < a.B;
@@ -1618,14 +1624,20 @@ __global__ void __launch_bounds__(256) adjoint_kernel(AdjointArgs a)
 #pragma unroll
     for (int k = 0; k < K; ++k) gam[k] = a.loadings[(rec * N + jr) * K + k];
     const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
-    double Gh[HOIST ? N : 1][K];
-    if constexpr (HOIST) {
-        sfor<0, N>(MK_LAMBDA(j) {
-            sfor<0, K>(MK_LAMBDA(k) {
-                Gh[decltype(j)::value][decltype(k)::value] = Gp::template bcast<decltype(j)::value>(gam[decltype(k)::value]);
-            });
+    double zt[N]; // element r of Z_j = e_j + sum_k loadings[j,k] e_{N+k}, j = 0 .. N-1
+    sfor<0, N>(MK_LAMBDA(jc) {
+        constexpr int j = decltype(jc)::value;
+        double z = (r == j) ? 1.0 : 0.0;
+        sfor<0, K>(MK_LAMBDA(k) {
+            constexpr int kk = decltype(k)::value;
+            const double g = Gp::template bcast<j>(gam[kk]);
+            z = (r == N + kk) ? g : z;
         });
-    }
+        zt[j] = z;
+    });
+    double ones[n];
+#pragma unroll
+    for (int c = 0; c < n; ++c) ones[c] = 1.0;
     const long sctot = a.sigmacount[inst]; // observed steps in total (written by the forward filter)
     long rem = 0;                          // observed steps already walked (from the end)
     const double one = 1.0;
@@ -1677,21 +1689,19 @@ __global__ void __launch_bounds__(256) adjoint_kernel(AdjointArgs a)
             asm volatile("" : "+v"(rv), "+v"(qv));
 #pragma unroll
             for (int c = 0; c < n; ++c) P[c] = fma(Pprev[c], pp[c], c == rv ? qv : 0.0);
-            double dS[N], rfS[N], vS[N];
+            double dS[N];
+            double vown = 0.0, rfown = 0.0; // lane j: innovation and reciprocal variance of ITS update
             sfor<0, N>(MK_LAMBDA(jc) {
                 constexpr int j = decltype(jc)::value;
-                dS[j] = rfS[j] = vS[j] = 0.0;
+                dS[j] = 0.0;
                 if ((vm >> j) & 1) {
                     double vl = y - x;
                     sfor<0, K>(MK_LAMBDA(k) { Gp::template fmac<N + decltype(k)::value, true>(vl, x, gam[decltype(k)::value]); });
                     const double v = Gp::template bcast<j>(vl);
                     double dr = P[j];
-                    sfor<0, K>(MK_LAMBDA(k) {
+                    sfor<0, K>(MK_LAMBDA(k) { // d_r = P[r][j] + sum_k P[r][N+k] loadings[j,k], the loadings broadcast from lane j
                         constexpr int kk = decltype(k)::value;
-                        double g;
-                        if constexpr (HOIST) g = Gh[j][kk];
-                        else g = Gp::template bcast<j>(gam[kk]);
-                        dr = fma(P[N + kk], g, dr);
+                        Gp::template fmac<j, false>(dr, gam[kk], P[N + kk]);
                     });
                     double fl = rvar + dr;
                     dpp_pin(dr);
@@ -1702,8 +1712,8 @@ __global__ void __launch_bounds__(256) adjoint_kernel(AdjointArgs a)
                     Gp::template axpy_col<0, n, true, n>(P, dr, kr);
                     x = fma(kr, v, x);
                     dS[j] = dr;
-                    rfS[j] = rf;
-                    vS[j] = v;
+                    vown = (r == j) ? v : vown;
+                    rfown = (r == j) ? rf : rfown;
                 }
             });
             // ---- reverse: adjoints back through the updates, last observation first ----
@@ -1711,42 +1721,51 @@ __global__ void __launch_bounds__(256) adjoint_kernel(AdjointArgs a)
                 constexpr int j = decltype(jc)::value;
                 if ((vm >> j) & 1) {
                     double dr = dS[j];
-                    const double rf = rfS[j], v = vS[j];
+                    const double rf = Gp::template bcast<j>(rfown), v = Gp::template bcast<j>(vown);
                     double pa = xb * dr;
                     dpp_guard1(pa, dr);
-                    double asum = 0.0, b0 = 0.0, b1 = 0.0;
-                    sfor<0, n>(MK_LAMBDA(cc) {
-                        constexpr int c = decltype(cc)::value;
-                        Gp::template fmac<c, false>(asum, pa, one);                    // a = sum_r xb_r d_r
-                        if constexpr (c % 2 == 0) Gp::template fmac<c, false>(b0, dr, Pb[c]); // b_r = sum_c Pb[r][c] d_c
-                        else Gp::template fmac<c, false>(b1, dr, Pb[c]);
-                    });
-                    const double b = b0 + b1;
+                    double asum, b;
+                    if constexpr (FUSED) { // a = sum_r xb_r d_r and b_r = sum_c Pb[r][c] d_c, one asm statement each (two chains inside)
+                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                        Sweeps<n>::mean(a0, a1, pa, ones);
+                        Sweeps<n>::mean(b0, b1, dr, Pb);
+                        asum = a0 + a1;
+                        b = b0 + b1;
+                    } else {
+                        double a0 = 0.0, b0 = 0.0, b1 = 0.0;
+                        sfor<0, n>(MK_LAMBDA(cc) {
+                            constexpr int c = decltype(cc)::value;
+                            Gp::template fmac<c, false>(a0, pa, one);
+                            if constexpr (c % 2 == 0) Gp::template fmac<c, false>(b0, dr, Pb[c]);
+                            else Gp::template fmac<c, false>(b1, dr, Pb[c]);
+                        });
+                        asum = a0;
+                        b = b0 + b1;
+                    }
                     double ps = dr * b;
                     dpp_guard1(ps, ps);
-                    double csum = 0.0;
-                    sfor<0, n>(MK_LAMBDA(cc) { Gp::template fmac<decltype(cc)::value, false>(csum, ps, one); });
+                    double csum;
+                    if constexpr (FUSED) {
+                        double c0 = 0.0, c1 = 0.0;
+                        Sweeps<n>::mean(c0, c1, ps, ones);
+                        csum = c0 + c1;
+                    } else {
+                        csum = 0.0;
+                        sfor<0, n>(MK_LAMBDA(cc) { Gp::template fmac<decltype(cc)::value, false>(csum, ps, one); });
+                    }
                     const double vrf = v * rf;
                     const double vbar = fma(2.0 * w, v, asum) * rf;
                     const double fbar = (fma(-w * v, vrf, w) - asum * vrf + csum * rf) * rf;
-                    double zr = (r == j) ? 1.0 : 0.0; // element r of Z_j = e_j + sum_k loadings[j,k] e_{N+k}
-                    sfor<0, K>(MK_LAMBDA(k) {
-                        constexpr int kk = decltype(k)::value;
-                        double g;
-                        if constexpr (HOIST) g = Gh[j][kk];
-                        else g = Gp::template bcast<j>(gam[kk]);
-                        zr = (r == N + kk) ? g : zr;
-                    });
+                    const double zr = zt[j]; // element r of Z_j
                     double dbar = fma(xb, vrf, fma(-2.0 * rf, b, fbar * zr));
                     xb = fma(-vbar, zr, xb);
-                    const double hd = 0.5 * dbar, hz = 0.5 * zr;
+                    double hd = 0.5 * dbar;
+                    const double hz = 0.5 * zr;
                     Pb[j] += hd;
-                    sfor<0, K>(MK_LAMBDA(k) {
+                    dpp_pin(hd);
+                    sfor<0, K>(MK_LAMBDA(k) { // Pb[r][N+k] += db_r loadings[j,k] / 2, the loadings broadcast from lane j
                         constexpr int kk = decltype(k)::value;
-                        double g;
-                        if constexpr (HOIST) g = Gh[j][kk];
-                        else g = Gp::template bcast<j>(gam[kk]);
-                        Pb[N + kk] = fma(hd, g, Pb[N + kk]);
+                        Gp::template fmac<j, false>(Pb[N + kk], gam[kk], hd);
                     });
                     dpp_guard1(dbar, dbar);
                     Gp::template axpy_col<0, n, false, n>(Pb, dbar, hz); // Pb[r][c] += z_r db_c / 2
