@@ -39,8 +39,12 @@ CONFIGS = {
     "c3": (8192, 8, 2, 1000, 0.0, "full"),
     "c4": (4096, 32, 4, 2000, 0.3, "project"),
     "c5": (8192, 8, 2, 1000, 0.0, "solver"),
+    # configs[3]'s batch with the smoothed STATE means / variances [B,T,n] as outputs (MK_OUT_VAR_ONLY; what get_state_means /
+    # get_state_variances consume, metran.py:655-756): the state-tape path (round 5), or --projection-path records for RTS
+    "c4s": (4096, 32, 4, 2000, 0.3, "state"),
 }
-BASELINE_NAME = {"c2": "configs[1]", "c3": "configs[2] (per-GPU share)", "c4": "configs[3]", "c5": "configs[4] (fp64)"}
+BASELINE_NAME = {"c2": "configs[1]", "c3": "configs[2] (per-GPU share)", "c4": "configs[3]", "c5": "configs[4] (fp64)",
+                 "c4s": "configs[3]'s batch, state outputs"}
 EVALS_PER_STEP = 50  # c5: "50 parameter evaluations x batch=8192"
 
 
@@ -60,6 +64,10 @@ def algorithmic_bytes(N, K, T, mode, sym=False, tape=False):
     c = n + (n * (n + 1) // 2 if sym else n * n)
     if mode == "full":      # read obs, write filtered + predicted | re-read filtered, write smoothed
         return {"filter": 8 * T * (N + 2 * c), "smoother": 8 * T * (2 * c)}
+    if mode == "state" and tape:    # read obs, write the STATE tape (N + K entries of n + 4) | re-read it, write 2n state moments
+        return {"filter": 8 * T * (N + (N + K) * (n + 4)), "smoother": 8 * T * ((N + K) * (n + 4) + 2 * n)}
+    if mode == "state":             # read obs, write filtered | re-read filtered, write 2n state moments
+        return {"filter": 8 * T * (N + c), "smoother": 8 * T * (c + 2 * n)}
     if mode == "project" and tape:  # read obs, write the tape (N entries of n + 4) | re-read it, write 2N projected moments
         return {"filter": 8 * T * (N + N * (n + 4)), "smoother": 8 * T * (N * (n + 4) + 2 * N)}
     if mode == "project":   # read obs, write filtered | re-read filtered, write 2N projected moments
@@ -162,6 +170,14 @@ def executed_flops_tape(N, K, T, missing):
             "smoother": T * (N * (2 * n * (n + 1) + 4 * n) + 2 * (n + 1) * N * K + 4 * n * n)}
 
 
+def executed_flops_state_tape(N, K, T, missing):
+    """... of the state-tape path: the projection tape's count plus, per step, K more products (n+1) x n and the K x n
+    products of every entry against them."""
+    n = N + K
+    base = executed_flops_tape(N, K, T, missing)
+    return {"filter": base["filter"] + T * 4 * K * n, "smoother": base["smoother"] + T * (K * 2 * n * (n + 1) + 2 * n * n * K)}
+
+
 def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, evals=1, live=None, tape=False):
     """The ``roofline`` object of the bench line for one workload: per-kernel algorithmic bytes / flops per launch over
     the hipEvent launch time, and the dominant kernel against the roof that bounds it -- HBM for the 16-lane
@@ -173,6 +189,7 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
         s_avg = 0.0
     wide = N + K > 16   # one model per wavefront: mk_wide.hip / mk_dk.hip
     sname = None if mode == "solver" else ("smoother_dk_kernel" if tape else "smoother_mfma_kernel" if wide else "smoother_record_kernel")
+    ex_fn = executed_flops_state_tape if mode == "state" else executed_flops_tape
 
     def entry(kind, ms):
         return {"ms": ms, "algorithmic_GB": ab[kind] * B / 1e9, "GBps": ab[kind] * B / 1e9 / (ms / 1e3),
@@ -183,7 +200,7 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
     if sname:
         kernels[sname] = entry("smoother", s_avg)
     if tape:  # the reference-algorithm count above is what SURVEY 8d prices; this is what the formulation executes
-        ex = executed_flops_tape(N, K, T, missing)
+        ex = ex_fn(N, K, T, missing)
         for kname, kind, ms in ((fname, "filter", f_avg), (sname, "smoother", s_avg)):
             kernels[kname]["executed_TFLOP"] = ex[kind] * B / 1e12
             kernels[kname]["executed_TFLOPps"] = ex[kind] * B / 1e12 / (ms / 1e3)
@@ -213,7 +230,7 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
                             % (kernels[dom]["algorithmic_TFLOP"] * 1e3 / max(kernels[dom]["algorithmic_GB"], 1e-30))
                             + ("; flops are SURVEY 8d's count of the REFERENCE algorithm (dense updates, RTS with an explicit "
                                "inverse) -- the tape path executes %.2f x of them (executed_TFLOP), so `frac` is work-equivalent "
-                               "throughput, not pipe utilisation" % (sum(executed_flops_tape(N, K, T, missing).values())
+                               "throughput, not pipe utilisation" % (sum(ex_fn(N, K, T, missing).values())
                                                                      / sum(fl.values())) if tape else "")}
     else:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -255,7 +272,7 @@ def cpu_baseline_port(host, mode, gpu_mle, target_seconds=12.0):
 
     def run(sl):
         return oracle.dfm_batch(host["obs"][sl], host["phi"][sl], host["q"][sl], host["loadings"][sl], native=native,
-                                smooth=smooth, outputs={"full": "all", "project": "means", "solver": "mle"}[mode])
+                                smooth=smooth, outputs={"full": "all", "project": "means", "state": "all", "solver": "mle"}[mode])
 
     probe = min(B, cores)
     t0 = time.perf_counter()
@@ -293,7 +310,7 @@ def cpu_baseline_optimised(host, mode, gpu_mle, target_seconds=8.0):
         pass
     cores = oracle.fast_num_threads(native)
     B, T = host["obs"].shape[0], host["obs"].shape[1]
-    outputs = {"full": "all", "project": "means", "solver": "mle"}[mode]
+    outputs = {"full": "all", "project": "means", "state": "all", "solver": "mle"}[mode]
 
     def run(sl):
         return oracle.fast_dfm_batch(host["obs"][sl], host["phi"][sl], host["q"][sl], host["loadings"][sl], outputs=outputs, native=native)
@@ -428,12 +445,14 @@ class Workload:
         self.kf = BatchedKalman(local_rank, layout=layout, packed_sym=self.packed_sym)
         self.kf.projection_path = projection_path
         self.kf.set_observations(self.d["obs"]).set_loadings(self.d["loadings"])
-        self.tape = mode == "project" and self.kf.tape_path()
+        self.tape = (mode == "project" and self.kf.tape_path()) or (mode == "state" and self.kf.state_tape_path())
         self.total = torch.zeros(1, dtype=torch.float64, device=dev)
         if mode == "full":
             self.bufs = self.kf._alloc_outputs(self.B, ["F", "Pf", "Xp", "Pp", "S", "Ps"])
         elif mode == "project":
             self.bufs = self.kf.alloc_projection(self.B)
+        elif mode == "state":
+            self.bufs = self.kf.alloc_state_variances(self.B)
         else:
             self.bufs = {"mle": torch.empty(self.B, dtype=torch.float64, device=dev)}
             # the 50 parameter sets of one step: alpha_k = alpha_0 (1 + 0.02 k), SURVEY 8d
@@ -449,6 +468,8 @@ class Workload:
             kf.filter_smooth(d["phi"], d["q"], buffers=self.bufs)
         elif self.mode == "project":
             kf.simulate_smoothed(d["phi"], d["q"], buffers=self.bufs)
+        elif self.mode == "state":
+            kf.smooth_state_variances(d["phi"], d["q"], buffers=self.bufs)
         else:
             for a in self.alphas:  # a2 + a3 + a6 per evaluation, as Metran.get_mle does (metran.py:605-622)
                 phi, q = kf.params_from_alpha(a)
@@ -470,6 +491,9 @@ class Workload:
                     "project": "%d %% missing, projection outputs (sim_means, sim_vars): %s" % (
                         round(100 * self.missing), "filter writing the backward tape + inverse-free backward pass (MK_OUT_TAPE)"
                         if getattr(self, "tape", False) else "filter (filtered record) + RTS smoother with the fused projection epilogue"),
+                    "state": "%d %% missing, smoothed state means + variances [B,T,n] (MK_OUT_VAR_ONLY): %s" % (
+                        round(100 * self.missing), "filter writing the STATE tape + inverse-free backward pass (MK_OUT_TAPE | MK_OUT_VAR_ONLY)"
+                        if getattr(self, "tape", False) else "filter (filtered record) + RTS smoother with the variance epilogue"),
                     "solver": "solver loop: %d objective evaluations (alpha -> phi,q -> filter -> -2 log L) per step" % EVALS_PER_STEP}[self.mode]))
 
     def close(self):
@@ -533,6 +557,13 @@ def parity_figures(w, n_mle=256, n_proj=32):
     ref = oracle.dfm_batch(host["obs"], host["phi"], host["q"], host["loadings"], smooth=False, outputs="mle")
     gpu = w.bufs["mle"][idx].cpu().numpy()
     out = {"loglik_max_rel_err": float(np.max(np.abs(gpu - ref["mle"]) / np.abs(ref["mle"]))), "loglik_models_compared": int(len(idx))}
+    if w.mode == "state":
+        sub = idx[np.linspace(0, len(idx) - 1, min(n_proj, len(idx))).astype(int)]
+        pos = np.searchsorted(idx, sub)
+        r2 = oracle.dfm_batch(host["obs"][pos], host["phi"][pos], host["q"][pos], host["loadings"][pos])
+        out["state_models_compared"] = int(len(sub))
+        out["state_means_max_abs_err"] = float(np.max(np.abs(w.bufs["S"][sub].cpu().numpy() - r2["S"])))
+        out["state_vars_max_abs_err"] = float(np.max(np.abs(w.bufs["var"][sub].cpu().numpy() - np.diagonal(r2["Ps"], axis1=2, axis2=3))))
     if w.mode == "project":
         sub = idx[np.linspace(0, len(idx) - 1, min(n_proj, len(idx))).astype(int)]
         pos = np.searchsorted(idx, sub)
@@ -561,6 +592,8 @@ def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=5, warmu
         out = {"workload": w.describe(), "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
                "models_per_s": models_per_s, "value": models_per_s * w.T, "unit": "model-timesteps/s",
                "filter_ms": f_avg, "smoother_ms": (s_avg if w.mode != "solver" else None)}
+        if w.mode == "state":
+            out["state_tape"] = bool(tape)
         if w.mode == "solver":
             out["objective_evaluations_per_s"] = models_per_s
         try:
@@ -574,66 +607,6 @@ def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=5, warmu
     lv = live_traffic(name, False) if (live and name == "c4") else None   # after the buffers are released
     out["roofline"] = build_roofline(name, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], f_avg, s_avg, False, live=lv, tape=tape)
     return out
-
-
-def secondary_state_variances(local_rank, rank, dev, layout, sync, B=4096, N=32, K=4, T=2000, missing=0.3, steps=5, warmup=2,
-                              n_check=24, projection_path="auto"):
-    """configs[3]'s batch through ``smooth_state_variances``: the smoothed STATE means and variances
-    [B,T,n] that ``Metran.get_state_means / get_state_variances / get_state`` consume (metran.py:655-756), on the state-tape
-    path (``MK_OUT_TAPE | MK_OUT_VAR_ONLY``: filter_split_kernel writing N + K entries per step, smoother_dk_kernel<..,STATE>)
-    -- or, with ``projection_path="records"``, on filtered records + the RTS kernel, the path it replaces.  Kernel ms from
-    hipEvents, models/s from the wall clock of the timed region, SURVEY 8d's full-output accounting next to the bar, and the
-    error against the oracle (reference kalmansmoother, kalmanfilter.py:403-476) on ``n_check`` models spread over the batch."""
-    import numpy as np
-    import torch
-
-    import oracle
-    from metran_amd.engine import BatchedKalman
-    from metran_amd.synthetic import make_dfm_batch_torch
-
-    d = make_dfm_batch_torch(B, N, K, T, seed=2000 + rank, device=dev, missing=missing)
-    kf = BatchedKalman(local_rank, layout=layout)
-    kf.projection_path = projection_path
-    kf.set_observations(d["obs"]).set_loadings(d["loadings"])
-    try:
-        state_tape = kf.state_tape_path()
-        bufs = kf.alloc_state_variances(B)
-
-        class W:  # what timed_run drives
-            pass
-        w = W()
-        w.kf = kf
-        w.step = lambda: kf.smooth_state_variances(d["phi"], d["q"], buffers=bufs)
-        elapsed, f_avg, s_avg = timed_run(w, steps, warmup, sync)
-        n = N + K
-        b_fs = 8 * T * (N + 4 * (n + n * n))
-        rate = B * steps / elapsed
-        idx = sample_models(B, n_check)
-        t0 = time.perf_counter()
-        ref = oracle.dfm_batch(d["obs"][idx].cpu().numpy(), d["phi"][idx].cpu().numpy(), d["q"][idx].cpu().numpy(),
-                               d["loadings"][idx].cpu().numpy())
-        out = {"workload": "batch=%d synthetic %d-series/%d-factor DFMs, %d %% missing, T=%d, fp64: smoothed state means + variances "
-                           "[B,T,n] (MK_OUT_VAR_ONLY), %s" % (B, N, K, round(100 * missing), T,
-                                                             "filter writing the STATE tape + inverse-free backward pass" if state_tape
-                                                             else "filter (filtered record) + RTS smoother"),
-               "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "models_per_s": rate,
-               "filter_ms": f_avg, "smoother_ms": s_avg, "state_tape": bool(state_tape),
-               "survey_8d_full_output_accounting": {
-                   "bytes_per_model": b_fs, "frac_of_peak": B * b_fs / 1e9 / ((f_avg + s_avg) / 1e3) / HBM_PEAK_GBS,
-                   "north_star_bar": {"frac_of_peak": 0.40, "models_per_s": 0.40 * HBM_PEAK_GBS * 1e9 / b_fs}},
-               "moved_GB": {"filter": B * 8 * T * (N + (N + K) * (n + 4)) / 1e9 if state_tape else B * 8 * T * (N + n + n * n) / 1e9,
-                            "smoother": B * 8 * T * ((N + K) * (n + 4) + 2 * n) / 1e9 if state_tape else B * 8 * T * (n + n * n + 2 * n) / 1e9},
-               "parity": {"models_compared": int(len(idx)),
-                          "loglik_max_rel_err": float(np.max(np.abs(bufs["mle"][idx].cpu().numpy() - ref["mle"]) / np.abs(ref["mle"]))),
-                          "state_means_max_abs_err": float(np.max(np.abs(bufs["S"][idx].cpu().numpy() - ref["S"]))),
-                          "state_vars_max_abs_err": float(np.max(np.abs(bufs["var"][idx].cpu().numpy()
-                                                                        - np.diagonal(ref["Ps"], axis1=2, axis2=3)))),
-                          "checker": "oracle/kalman_oracle.c, %.1f s on the host" % (time.perf_counter() - t0)}}
-        return out
-    finally:
-        kf.close()
-        del d
-        torch.cuda.empty_cache()
 
 
 def measure_transfers(dev, B, T, N, K, ms_per_step):
@@ -1056,7 +1029,7 @@ def main():
                 res["secondary"][name] = secondary_workload(name, local_rank, rank, dev, args.layout, sync)
             except Exception as e:  # noqa: BLE001 -- the headline line must survive a failure here
                 res["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
-        for name, fn in (("c4_state_variances", lambda: secondary_state_variances(local_rank, rank, dev, args.layout, sync)),
+        for name, fn in (("c4_state_variances", lambda: secondary_workload("c4s", local_rank, rank, dev, args.layout, sync)),
                          ("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
                          ("f4_factor_analysis_32x4", lambda: secondary_factor_analysis(dev, N=32, K=4, reps=2, scipy_subset=256)),
                          ("f1_calibration", lambda: secondary_calibration(local_rank, dev)),

@@ -71,8 +71,9 @@ def test_secondary_state_variances_of_wide_models(line):
     assert "error" not in s, s
     assert s["state_tape"] and "STATE tape" in s["workload"] and "T=2000" in s["workload"]
     par = s["parity"]
-    assert par["models_compared"] >= 24 and par["loglik_max_rel_err"] < 1e-9, par
-    assert par["state_means_max_abs_err"] < 1e-9 and par["state_vars_max_abs_err"] < 1e-9, par
+    assert par["loglik_models_compared"] >= 256 and par["loglik_max_rel_err"] < 1e-9, par
+    assert par["state_models_compared"] >= 32 and par["state_means_max_abs_err"] < 1e-9 and par["state_vars_max_abs_err"] < 1e-9, par
+    assert s["roofline"]["bound"] == "fp64" and "smoother_dk_kernel" in s["roofline"]["kernels"]
     assert s["models_per_s"] >= STATE_VARIANCES_FLOOR, s
 
 
