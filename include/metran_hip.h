@@ -179,8 +179,14 @@ MK_API int mk_sync(mk_context *ctx);
  *   MK_VARIANT_WIDE_FILTER    n > 16, N <= 32: 0 by batch size -- filter_split_kernel (series on the lanes, factor block
  *                             replicated: 2 or 4 models per wavefront) for more than 2 instances per SIMD of the device,
  *                             filter_kernel<N,K,64> (one state per lane) below; 1 the latter always; 2 the former always
- *                             (the MK_OUT_TAPE path always runs the split kernel: the tape exists in that layout only) */
-enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_COUNT = 3 };
+ *                             (the MK_OUT_TAPE path always runs the split kernel: the tape exists in that layout only)
+ *   MK_VARIANT_SINGLE_RECORD  mk_filter with ONE record, at most MK_SPARSE_RECORD_MAX_INSTANCES instances, n <= 16 and both record
+ *                             sets (the 7-tuple of seqkalmanfilter for a single Metran model): 0 the observed steps walked one
+ *                             after the other and the records of the empty steps written in closed form by a second, parallel
+ *                             kernel (kalmanfilter.py:335 skips the update on those steps; examples/data: 343 of 6255 steps
+ *                             carry data), 1 the batched filter_kernel step by step */
+enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_SINGLE_RECORD = 3, MK_VARIANT_COUNT = 4 };
+#define MK_SPARSE_RECORD_MAX_INSTANCES 16
 MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value);
 MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value);
 /* Tell the context that the CONTENTS of an observation buffer it has seen changed in place (same pointer): per-record

@@ -300,7 +300,7 @@ MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
 {
     MK_CTX(ctx);
     if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
-    if (value < 0 || value > (which == MK_VARIANT_SMOOTHER16 ? 1 : 2))
+    if (value < 0 || value > ((which == MK_VARIANT_SMOOTHER16 || which == MK_VARIANT_SINGLE_RECORD) ? 1 : 2))
         return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for the two wide selectors)");
     ctx->variant[which] = value;
     return MK_OK;
@@ -496,6 +496,56 @@ static int records_filter(const mk_problem *p, const mk_outputs *o)
     return 1;
 }
 
+// The single-record routes (loglik_sparse_kernel): every instance shares ONE uploaded record, whose observed steps are
+// listed once per record on the device; the objective (mk_loglik) and -- round 5 -- the record-writing filter of a few
+// instances walk that list, the runs of empty steps in closed form.  d_F / d_Xp NULL: objective only.
+static int sparse_route(mk_context *ctx, const mk_problem *p, double *d_mle, double *d_F, double *d_Xp, int64_t rs, int time_major,
+                        int64_t *d_sigmacount, uint32_t *d_status)
+{
+    if (ctx->tlist_cap < p->T + 1) {
+        if (ctx->tlist) MK_HIP(hipFree(ctx->tlist));
+        ctx->tlist = nullptr;
+        ctx->tlist_cap = 0;
+        MK_HIP(hipMalloc((void **)&ctx->tlist, sizeof(int) * (size_t)(p->T + 1)));
+        ctx->tlist_cap = p->T + 1;
+        ctx->tlist_obs = nullptr;
+    }
+    mk::SparseArgs a;
+    a.B = p->n_instances;
+    a.T = p->T;
+    a.warmup = p->warmup;
+    a.ostep = (p->obs_time_major ? p->n_records : 1) * p->N; // one record: both layouts coincide
+    a.obs = p->d_obs;
+    a.phi = p->d_phi;
+    a.q = p->d_q;
+    a.loadings = p->d_loadings;
+    a.obsvar = p->d_obsvar;
+    a.x0 = p->d_x0;
+    a.P0 = p->d_P0;
+    a.tlist = ctx->tlist;
+    a.rebuild = !(ctx->tlist_obs == p->d_obs && ctx->tlist_T == p->T && ctx->tlist_N == p->N && ctx->tlist_ostep == a.ostep);
+    // the list is only known to describe this record once the launch that (re)builds it has been accepted: the key
+    // is dropped first and committed after a successful dispatch, so a failed call leaves no stale key behind.
+    // (Stream order: the list is built and read on ctx->stream; mk_set_stream drops the key when the stream changes.)
+    ctx->tlist_obs = nullptr;
+    a.mle = d_mle;
+    a.status = d_status;
+    a.F = d_F;
+    a.Xp = d_Xp;
+    a.rs = rs;
+    a.bs = time_major ? 1 : p->T;
+    a.ts = time_major ? p->n_instances : 1;
+    a.sigmacount = (long long *)d_sigmacount;
+    MK_HIP(timing_start(ctx, 0));
+    MK_HIP(dispatch_sparse((int)p->N, (int)p->K, a, ctx->stream));
+    ctx->tlist_obs = p->d_obs;
+    ctx->tlist_T = p->T;
+    ctx->tlist_N = p->N;
+    ctx->tlist_ostep = a.ostep;
+    MK_HIP(timing_stop(ctx, 0));
+    return MK_OK;
+}
+
 static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
 {
     if (!p->d_obs || !p->d_loadings) return fail(MK_ERR_INVALID, "d_obs and d_loadings are required");
@@ -503,6 +553,14 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     if (tape < 0) return tape;
     const int rec = tape ? 0 : records_filter(p, o);
     if (rec < 0) return rec;
+    // ONE record, a handful of instances, both record sets (the 7-tuple of seqkalmanfilter: what Metran.solve() asks of the
+    // engine ~80 times): a launch of the batched filter is T sequential steps for at most a few wavefronts -- latency, not
+    // throughput.  Real Metran records are sparse (examples/data: 343 observed of 6255 daily steps, kalmanfilter.py:335 skips
+    // the update on the others), so the observed steps are walked one after the other and every empty step's records are
+    // written in closed form by a second, fully parallel kernel (mk_kernels.hip: loglik_sparse_kernel<.., REC>, fill_gaps_kernel).
+    if (rec && p->n_records == 1 && p->n_instances <= MK_SPARSE_RECORD_MAX_INSTANCES && p->N + p->K <= 16 && o->d_Xp &&
+        !(o->flags & MK_OUT_PACKED_SYM) && specialised(p->N, p->K) && !ctx->variant[MK_VARIANT_SINGLE_RECORD])
+        return sparse_route(ctx, p, o->d_mle, o->d_F, o->d_Xp, o->record_stride, (int)o->time_major, o->d_sigmacount, o->d_status);
     mk::FilterArgs a;
     a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER]; // 0 auto, 1 lane per state, 2 split
     a.tape = tape;
@@ -633,42 +691,7 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
     if (p->n_records == 1 && p->N + p->K <= 16 && p->d_obs && p->d_loadings && specialised(p->N, p->K)) {
         // every instance shares the one record (the solver's finite-difference points): walk only its
         // observed steps, the runs of empty steps in closed form (loglik_sparse_kernel)
-        if (ctx->tlist_cap < p->T + 1) {
-            if (ctx->tlist) MK_HIP(hipFree(ctx->tlist));
-            ctx->tlist = nullptr;
-            ctx->tlist_cap = 0;
-            MK_HIP(hipMalloc((void **)&ctx->tlist, sizeof(int) * (size_t)(p->T + 1)));
-            ctx->tlist_cap = p->T + 1;
-            ctx->tlist_obs = nullptr;
-        }
-        mk::SparseArgs a;
-        a.B = p->n_instances;
-        a.T = p->T;
-        a.warmup = p->warmup;
-        a.ostep = (p->obs_time_major ? p->n_records : 1) * p->N; // one record: both layouts coincide
-        a.obs = p->d_obs;
-        a.phi = p->d_phi;
-        a.q = p->d_q;
-        a.loadings = p->d_loadings;
-        a.obsvar = p->d_obsvar;
-        a.x0 = p->d_x0;
-        a.P0 = p->d_P0;
-        a.tlist = ctx->tlist;
-        a.rebuild = !(ctx->tlist_obs == p->d_obs && ctx->tlist_T == p->T && ctx->tlist_N == p->N && ctx->tlist_ostep == a.ostep);
-        // the list is only known to describe this record once the launch that (re)builds it has been accepted: the key
-        // is dropped first and committed after a successful dispatch, so a failed call leaves no stale key behind.
-        // (Stream order: the list is built and read on ctx->stream; mk_set_stream drops the key when the stream changes.)
-        ctx->tlist_obs = nullptr;
-        a.mle = d_mle;
-        a.status = nullptr;
-        MK_HIP(timing_start(ctx, 0));
-        MK_HIP(dispatch_sparse((int)p->N, (int)p->K, a, ctx->stream));
-        ctx->tlist_obs = p->d_obs;
-        ctx->tlist_T = p->T;
-        ctx->tlist_N = p->N;
-        ctx->tlist_ostep = a.ostep;
-        MK_HIP(timing_stop(ctx, 0));
-        return MK_OK;
+        return sparse_route(ctx, p, d_mle, nullptr, nullptr, 0, 0, nullptr, nullptr);
     }
     mk_outputs o;
     memset(&o, 0, sizeof(o));

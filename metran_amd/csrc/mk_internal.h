@@ -100,6 +100,12 @@ struct SparseArgs { // objective of ONE record (all instances share it), observe
     int rebuild;                     // 0: tlist still describes this record (mk_capi caches it per uploaded record)
     double *mle;
     unsigned *status;
+    // record outputs (round 5, the single-record engine route: loglik_sparse_kernel<.., REC = true> + fill_gaps_kernel):
+    // F / Xp = filtered / predicted record arrays of rs = record_stride(n) doubles per (instance, step), block (b, t) at
+    // (b*bs + t*ts)*rs; NULL = objective only
+    double *F, *Xp;
+    long rs, bs, ts;
+    long long *sigmacount;
 };
 
 hipError_t launch_filter(int N, int K, const FilterArgs &a, hipStream_t s);

@@ -1457,11 +1457,17 @@ __global__ void __launch_bounds__(256) observed_steps_kernel(long T, int N, long
     if (tid == 0) tlist[0] = s_base;
 }
 
-template <int N, int K, int G>
+// REC (round 5): the same walk also WRITES the packed records of the observed steps -- predicted moments before the updates,
+// filtered moments and the compressed (sigma, detf) entry after them -- and fill_gaps_kernel then writes the records of the
+// empty steps in closed form, fully parallel.  This is the single-record engine route (mk_filter with one record, a
+// handful of instances, all four state arrays: what Metran.solve() drives through seqkalmanfilter ~80 times): on
+// examples/data 343 sequential steps instead of 6255.
+template <int N, int K, int G, bool REC = false>
 __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
 {
     constexpr int n = N + K;
     static_assert(G == 16 && n <= 16, "sparse objective kernel: one model per 16-lane group");
+    [[maybe_unused]] constexpr int NV = record_payload(n);
     using Gp = Group<G>;
     constexpr int GPB = 256 / G;
     constexpr bool HOIST = (N * K <= 32);
@@ -1525,6 +1531,11 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
         }
         const unsigned long long ball = __ballot(lane < N && isfinite(y));
         const auto vm = Gp::group_bits(ball);
+        if constexpr (REC) { // predicted moments of step t (:332-333): mean element r, covariance as symmetric column runs
+            double *rp = a.Xp + (inst * a.bs + t * a.ts) * a.rs;
+            rp[r] = x;
+            store_cols<n>(rp + n + r, P);
+        }
         double sigma = 0.0, fmant = 1.0;
         int fexp = 0;
         sfor<0, N>(MK_LAMBDA(jc) {
@@ -1558,6 +1569,16 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
                 fmant = __builtin_amdgcn_frexp_mant(fmant);
             }
         });
+        if constexpr (REC) { // filtered moments of step t (:384-390); the compressed (sigma, detf) entry i in record i's pad (:380-382)
+            double *rf_ = a.F + (inst * a.bs + t * a.ts) * a.rs;
+            rf_[r] = x;
+            store_cols<n>(rf_ + n + r, P);
+            if (lead) {
+                double *pad = a.F + (inst * a.bs + (long)i * a.ts) * a.rs + NV;
+                pad[0] = sigma;
+                pad[1] = fma((double)fexp, kLn2, log(fmant));
+            }
+        }
         if (i >= a.warmup) { // compressed index of the observed step (:563-564)
             sum_sig += sigma;
             run_mant *= fmant;
@@ -1570,6 +1591,53 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
         const double sum_det = fma((double)run_exp, kLn2, log(run_mant));
         if (a.mle) a.mle[inst] = ((double)nobs * kLog2Pi + sum_det) + sum_sig;
         if (a.status) a.status[inst] = (fmin_seen > 0.0) ? 0u : MK_FLAG_NONPOSITIVE_F;
+        if (REC && a.sigmacount) a.sigmacount[inst] = cnt;
+    }
+}
+
+// The records of the steps WITHOUT an observation, after loglik_sparse_kernel<.., REC> has written those of the observed ones:
+// over a run of empty steps the recursion is closed-form under a diagonal transition (kalmanfilter.py:318-331 applied g times,
+// :384-390 with no update): with (x_a, P_a) the filtered moments of the last observed step t_a < t (or the initial moments,
+// t_a = -1) and g = t - t_a,
+//     x_t = phi^g o x_a,   P_t[r][c] = (phi_r phi_c)^g P_a[r][c] + [r = c] q_r (1 - phi_r^(2g)) / (1 - phi_r^2)
+// are BOTH the predicted and the filtered moments of step t.  One workgroup per (instance, step), one thread per record
+// element; the previous observed step by bisection of the list.  Also zeroes the (sigma, detf) pads beyond the compressed
+// entries (np.zeros, :307-308).
+__global__ void __launch_bounds__(256) fill_gaps_kernel(SparseArgs a, int n)
+{
+    const long t = blockIdx.x, inst = blockIdx.y;
+    const int cnt = a.tlist[0], NV = n + n * n;
+    int lo = 0, hi = cnt; // number of observed steps < t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tlist[1 + mid] < t) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool observed = lo < cnt && a.tlist[1 + lo] == t;
+    double *rF = a.F + (inst * a.bs + t * a.ts) * a.rs, *rP = a.Xp + (inst * a.bs + t * a.ts) * a.rs;
+    const long ta = lo > 0 ? a.tlist[lo] : -1; // last observed step before t (entry lo - 1 of the list)
+    const double g = (double)(t - ta);
+    const double *src = ta >= 0 ? a.F + (inst * a.bs + ta * a.ts) * a.rs : nullptr;
+    for (int e = threadIdx.x; e < (int)a.rs; e += 256) {
+        if (e >= NV) { // the record pads: compressed entries live in records 0 .. cnt-1 of the filtered array
+            if (t >= cnt) rF[e] = 0.0;
+            rP[e] = 0.0;
+            continue;
+        }
+        if (observed) continue;
+        double v;
+        if (e < n) {
+            const double x0 = src ? src[e] : (a.x0 ? a.x0[inst * n + e] : 0.0);
+            v = x0 * exp(g * log(a.phi[inst * n + e]));
+        } else {
+            const int rr = (e - n) / n, cc = (e - n) % n;
+            const double p0 = src ? src[e] : (a.P0 ? a.P0[(inst * n + rr) * n + cc] : (rr == cc ? 1.0 : 0.0));
+            const double lr = log(a.phi[inst * n + rr]), lc = log(a.phi[inst * n + cc]);
+            v = p0 * exp(g * (lr + lc));
+            if (rr == cc) v = fma(a.q[inst * n + rr], lr == 0.0 ? g : expm1(2.0 * g * lr) / expm1(2.0 * lr), v); // sum_{i<g} phi^(2i)
+        }
+        rF[e] = v;
+        rP[e] = v;
     }
 }
 
@@ -2093,6 +2161,12 @@ static hipError_t launch_sparse_nk(const SparseArgs &a, hipStream_t s)
     if constexpr (n <= 16) {
         constexpr int GPB = 256 / 16;
         if (a.rebuild) hipLaunchKernelGGL(observed_steps_kernel, dim3(1), dim3(256), 0, s, a.T, N, a.ostep, a.obs, a.tlist);
+        if (a.F && a.Xp) { // record outputs: the observed steps one after the other, then every empty step in parallel
+            if (a.rs != record_stride_c(n)) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((loglik_sparse_kernel<N, K, 16, true>), dim3((unsigned)((a.B + GPB - 1) / GPB)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(fill_gaps_kernel, dim3((unsigned)a.T, (unsigned)a.B), dim3(256), 0, s, a, n);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((loglik_sparse_kernel<N, K, 16>), dim3((unsigned)((a.B + GPB - 1) / GPB)), dim3(256), 0, s, a);
         return hipGetLastError();
     } else {

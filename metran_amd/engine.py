@@ -98,7 +98,8 @@ class BatchedKalman:
     # ------------------------------------------------------------------ kernel variants (A/B measurements)
     _VARIANTS = {"smoother16": (0, ("record", "blk")),
                  "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded")),
-                 "wide_filter": (2, ("auto", "lane_per_state", "split"))}
+                 "wide_filter": (2, ("auto", "lane_per_state", "split")),
+                 "single_record": (3, ("sparse", "stepwise"))}
     # variants every new engine starts with (name -> value); empty = the library's defaults.  The GPU test tier sets
     # {"wide_filter": "split"} so that its small batches keep exercising the split kernels, which "auto" reserves for
     # batches of more than two models per SIMD (tests/conftest.py; tests/test_hip_layouts.py checks "auto" itself)

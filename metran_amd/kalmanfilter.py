@@ -168,15 +168,51 @@ def seqkalmanfilter_hip(observations, transition_matrix, transition_covariance, 
     x0 = np.asarray(filtered_state_mean, dtype=np.float64)[None]
     P0 = np.asarray(filtered_state_covariance, dtype=np.float64)[None]
     r = kf.filter(phi[None], q[None], warmup=1, x0=x0, P0=P0)
-    check_status(r["status"], "seqkalmanfilter_hip")
-    sc = int(r["sigmacount"][0].item())
-    cpu = lambda k: r[k][0].cpu().numpy()  # noqa: E731
-    out = (cpu("sigmas"), cpu("detfs"), sc, cpu("F"), cpu("Pf"), cpu("Xp"), cpu("Pp"))
+    host = _records_to_host(r, len(phi))
+    check_status(host["status"], "seqkalmanfilter_hip")
+    sc = int(host["sigmacount"][0])
+    out = (host["sigmas"], host["detfs"], sc, host["F"], host["Pf"], host["Xp"], host["Pp"])
     # the reference hands these very array objects to kalmansmoother (run_smoother, kalmanfilter.py:676-694): remembered by
-    # identity AND content, so that the smoother may use the device-resident moments only while the host copies are
-    # still what this call returned
-    kf._adapter_filter = dict(arrays=out[3:7], digest=_content_hash(*out[3:7]), phi=phi.copy(), q=q.copy(), device=r)
+    # identity; the smoother then checks them against the device-resident moments before it uses those
+    kf._adapter_filter = dict(arrays=out[3:7], phi=phi.copy(), q=q.copy(), device=r)
     return out
+
+
+def _records_to_host(r, n):
+    """The results of a ONE-model record launch on the host with two device-to-host copies and one synchronisation: the
+    filtered and the predicted record arrays ``[T, RS]`` go into pinned buffers as they are, and the reference-shaped
+    arrays handed back -- ``F [T,n]``, ``Pf [T,n,n]``, ``sigmas [T]``, ... -- are numpy VIEWS of those buffers (six separate
+    ``.cpu()`` calls on strided device views cost six gather kernels, six pageable copies and six synchronisations: more
+    than the launch itself on examples/data).  Falls back to plain copies for anything that is not a record launch."""
+    import torch
+
+    rf, rp = r.get("_rec_filt"), r.get("_rec_pred")
+    if rf is None or rp is None or rf.shape[0] != 1 or not (rf[0].is_contiguous() and rp[0].is_contiguous()):
+        # (np.array: a host tensor's .cpu().numpy() shares its memory -- what is handed back must not alias what the engine keeps)
+        host = {k: np.array(r[k][0].cpu().numpy()) for k in ("sigmas", "detfs", "F", "Pf", "Xp", "Pp")}
+        host["status"], host["sigmacount"] = r["status"].cpu().numpy(), r["sigmacount"].cpu().numpy()
+        return host
+    T, RS = int(rf.shape[1]), int(rf.shape[2])
+    hf = torch.empty((T, RS), dtype=torch.float64, pin_memory=True)
+    hp = torch.empty((T, RS), dtype=torch.float64, pin_memory=True)
+    hs = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    hf.copy_(rf[0], non_blocking=True)
+    hp.copy_(rp[0], non_blocking=True)
+    hs[0:1].copy_(r["status"].to(torch.int64), non_blocking=True)
+    hs[1:2].copy_(r["sigmacount"], non_blocking=True)
+    torch.cuda.current_stream(rf.device).synchronize()
+    af, ap, st = hf.numpy(), hp.numpy(), hs.numpy()
+    nv = n + n * n
+    return {"F": af[:, :n], "Pf": af[:, n:nv].reshape(T, n, n), "sigmas": af[:, nv], "detfs": af[:, nv + 1],
+            "Xp": ap[:, :n], "Pp": ap[:, n:nv].reshape(T, n, n), "status": st[0:1].astype(np.int32), "sigmacount": st[1:2]}
+
+
+def _same_as_device(given, device):
+    """Whether the four moment arrays a caller hands to the smoother are (still) what the filter launch left on the device."""
+    for a, k in zip(given, ("F", "Pf", "Xp", "Pp")):
+        if not np.array_equal(np.asarray(a), device[k][0].cpu().numpy()):
+            return False
+    return True
 
 
 def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predicted_state_means,
@@ -186,8 +222,9 @@ def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predict
 
     The reference reads all four moment arrays as they are handed in (:453-474).  Two routes, same answer:
 
-    * the arrays are the very objects the preceding ``seqkalmanfilter_hip`` call returned, unchanged (what the reference's
-      ``run_smoother`` passes, :676-694): the filtered moments are still resident on the device as packed records and the
+    * the arrays are the very objects the preceding ``seqkalmanfilter_hip`` call returned, unchanged -- identity, and equality
+      with the moments still on the device, checked here (what the reference's ``run_smoother`` passes, :676-694): the
+      filtered moments are still resident on the device as packed records and the
       specialised smoother runs on them (it recomputes the predicted moments from the filtered ones and the remembered q --
       exactly the arrays the filter wrote);
     * any other arrays -- a caller's own filtered / predicted moments, or returned arrays edited since: ``mk_smooth_dense``,
@@ -204,7 +241,7 @@ def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predict
     if T < 2:  # :450-451: the last step's smoothed moments are the filtered ones
         return np.array(filtered_state_means, dtype=np.float64), np.array(filtered_state_covariances, dtype=np.float64)
     if (last is not None and all(g is a for g, a in zip(given, last["arrays"])) and np.array_equal(phi, last["phi"])
-            and _content_hash(*given) == last["digest"]):
+            and _same_as_device(given, last["device"])):
         rf = last["device"]
         r = kf.smooth(phi[None], last["q"][None], rf["F"], rf["Pf"])
     else:

@@ -6,9 +6,13 @@ import pytest
 
 import oracle
 from metran_amd.params import phi_q_from_alpha
-from metran_amd.synthetic import make_dfm
+from metran_amd.synthetic import make_dfm, make_dfm_batch
 
 pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
 
 
 def _sparse_record(N, K, T, seed, keep_every, first):
@@ -96,3 +100,55 @@ def test_observed_step_list_is_cached_per_record_and_invalidated(g1):
     ph, qq = phi.cpu().numpy(), q.cpu().numpy()
     ref = oracle.dfm_batch(y[None], ph, qq, g1["loadings"][None], smooth=False, outputs="mle")["mle"][0]
     assert abs(fresh - ref) < 1e-8 and stale == first and abs(first - ref) > 1e-3
+
+
+@pytest.mark.parametrize("N,K,T,keep_every,first", [(5, 1, 400, 17, "observed"), (8, 2, 300, 5, "empty"), (3, 1, 120, 1, "observed"), (14, 2, 90, 7, "empty")])
+def test_single_record_filter_walks_the_observed_steps(N, K, T, keep_every, first):
+    """The record-writing filter of ONE record (the engine route of Metran.solve: mk_filter, <= 16 instances, all four state
+    arrays): observed steps walked one after the other, the records of the empty steps written in closed form by a second
+    kernel (kalmanfilter.py:335).  Against the oracle, and against the step-by-step batched kernel
+    (``set_variant("single_record", "stepwise")``); three parameter sets on the one record, initial moments, observation
+    variances, a persistence of exactly zero."""
+    from metran_amd.engine import BatchedKalman
+    from metran_amd.params import observation_matrix
+
+    d = make_dfm_batch(1, N, K, T, seed=60 + N, missing=0.2, first_step=first)
+    y = d["obs"][0].copy()
+    mask = np.ones(T, bool)
+    mask[::keep_every] = False
+    y[mask] = np.nan                                   # runs of keep_every - 1 empty steps
+    if first == "empty":
+        y[:3] = np.nan
+    y[-2:] = np.nan                                    # and an empty tail
+    n = N + K
+    rng = np.random.default_rng(N)
+    S = 3
+    phi = np.clip(d["phi"][0][None] * (1.0 + 0.02 * rng.standard_normal((S, n))), 0.0, 0.999999)
+    phi[1, 0] = 0.0                                    # alpha at its lower bound: phi underflows to 0
+    q = d["q"][0][None] * (1.0 + 0.02 * rng.standard_normal((S, n)))
+    R = rng.uniform(0.0, 0.2, N) * (rng.random(N) < 0.5)
+    x0 = rng.normal(size=(S, n))
+    A = rng.normal(size=(S, n, n))
+    P0 = A @ A.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+    kf = BatchedKalman()
+    kf.set_observations(y[None]).set_loadings(d["loadings"], R[None])
+    assert kf.get_variant("single_record") == "sparse"
+    r = kf.filter(phi, q, x0=x0, P0=P0)
+    kf.set_variant("single_record", "stepwise")
+    r2 = kf.filter(phi, q, x0=x0, P0=P0)
+    o, oi, oc = oracle.set_observations(y)
+    for s in range(S):
+        sg, df, sc, F, Pf, Xp, Pp = oracle.seqkalmanfilter(o, np.diag(phi[s]), np.diag(q[s]), observation_matrix(d["loadings"][0]), R, oi, oc,
+                                                           x0[s], P0[s])
+        for res in (r, r2):
+            assert int(_np(res["sigmacount"])[s]) == sc
+            np.testing.assert_allclose(_np(res["F"])[s], F, atol=1e-10)
+            np.testing.assert_allclose(_np(res["Pf"])[s], Pf, atol=1e-10)
+            np.testing.assert_allclose(_np(res["Xp"])[s], Xp, atol=1e-10)
+            np.testing.assert_allclose(_np(res["Pp"])[s], Pp, atol=1e-10)
+            np.testing.assert_allclose(_np(res["sigmas"])[s, :sc], sg[:sc], rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(_np(res["detfs"])[s, :sc], df[:sc], atol=1e-10)
+            assert not _np(res["sigmas"])[s, sc:].any() and not _np(res["detfs"])[s, sc:].any()
+            ref = oracle.get_mle(sg[:sc], df[:sc], oc)
+            assert abs(_np(res["mle"])[s] - ref) <= 1e-9 * abs(ref)
+    kf.close()
