@@ -483,12 +483,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             trec[(N + k) * XS + jr] = Q[k];
                             if (l == 0) {
                                 double *sd = trec + SO + (N + k) * SS;
+                                if constexpr (PAIRS) { // 16-byte stores: the side rows are 16-byte aligned
 #pragma unroll
-                                for (int k2 = 0; k2 < K; ++k2) sd[k2] = PF[k2 <= k ? pf(k2, k) : pf(k, k2)];
-                                sd[SW - 4] = xk[k];
-                                sd[SW - 3] = PF[pf(k, k)];
-                                sd[SW - 2] = qnan;
-                                sd[SW - 1] = 0.0;
+                                    for (int k2 = 0; k2 < K; k2 += 2)
+                                        *reinterpret_cast<v2d *>(sd + k2) = v2d{PF[k2 <= k ? pf(k2, k) : pf(k, k2)], PF[k2 + 1 <= k ? pf(k2 + 1, k) : pf(k, k2 + 1)]};
+                                    *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{xk[k], PF[pf(k, k)]};
+                                    *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
+                                } else {
+#pragma unroll
+                                    for (int k2 = 0; k2 < K; ++k2) sd[k2] = PF[k2 <= k ? pf(k2, k) : pf(k, k2)];
+                                    sd[SW - 4] = xk[k];
+                                    sd[SW - 3] = PF[pf(k, k)];
+                                    sd[SW - 2] = qnan;
+                                    sd[SW - 1] = 0.0;
+                                }
                             }
                         });
                     }

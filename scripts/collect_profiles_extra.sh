@@ -1,6 +1,6 @@
 #!/bin/bash
 # Box-side: rocprofv3 kernel-trace stats of the non-headline measurements quoted in DESIGN.md section 6
-# (configs[3] projection path, adjoint gradient, sparse objective on examples/data, batched calibration).
+# (state outputs of configs[3]'s batch, adjoint gradient, the drop-in on examples/data, batched calibration).
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_extra; mkdir -p $OUT
@@ -11,8 +11,8 @@ run() { # name, command...
     if [ -n "$f" ]; then head -1 $f > $OUT/${name}_kernel_stats.csv; grep "mk::" $f >> $OUT/${name}_kernel_stats.csv; fi
     tail -2 $OUT/$name.log | cut -c1-400
 }
-PROJ=1 B=4096 T=2000 run c4_projection python scripts/probe_c4.py
-run adjoint_gradient python scripts/probe_grad.py
-run sparse_objective_examples_data python scripts/probe_g1.py
+run c4_state_variances python bench.py --config c4s --no-cpu-baseline --no-secondary --no-live-traffic --steps 3 --warmup 1
+run adjoint_gradient python scripts/probe.py kernels --what grad --batch 8192
+run dropin_examples_data python scripts/probe.py dropin
 run calibrate_batch python scripts/bench_calibrate.py
 cat $OUT/*_kernel_stats.csv | cut -c1-170
