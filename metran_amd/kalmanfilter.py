@@ -10,7 +10,8 @@ dropped in at Metran's two plug points:
   ``run_smoother`` looks up by global name (:685-691).
 * ``SPKalmanFilter``       -- same methods/attributes as the reference class (:479-778) with
   ``engine="hip"``; usable stand-alone (``Metran._init_kalmanfilter`` override).
-* ``install(metran_module)`` patches the three module globals of an imported reference.
+* ``simulate_hip`` / ``decompose_hip`` -- replace ``SPKalmanFilter.simulate`` / ``.decompose`` (:569-644).
+* ``install(metran_module)`` patches the three module globals and the two methods of an imported reference.
 
 All arithmetic runs in ``libmetran_hip.so``; nothing here falls back to the CPU.
 The engine supports Metran's model structure only: diagonal transition matrix / covariance
@@ -25,7 +26,8 @@ from .engine import BatchedKalman, MetranHipError
 
 logger = logging.getLogger(__name__)
 
-__all__ = ["seqkalmanfilter_hip", "kalmansmoother_hip", "SPKalmanFilter", "install", "uninstall", "get_engine", "set_engine",
+__all__ = ["seqkalmanfilter_hip", "kalmansmoother_hip", "simulate_hip", "decompose_hip", "SPKalmanFilter", "install", "uninstall",
+           "get_engine", "set_engine",
            "observations_to_nan_encoded", "MetranHipError"]
 
 import threading
@@ -92,7 +94,7 @@ def get_engine():
     kf = getattr(_LOCAL, "engine", None)
     if kf is None:
         kf = _LOCAL.engine = BatchedKalman()
-        kf._adapter_upload = kf._adapter_filter = None
+        kf._adapter_upload = kf._adapter_filter = kf._adapter_smooth = kf._adapter_simulated = None
     return kf
 
 
@@ -103,7 +105,7 @@ def set_engine(engine):
     prev = getattr(_LOCAL, "engine", None)
     _LOCAL.engine = engine
     if engine is not None:
-        engine._adapter_upload = engine._adapter_filter = None
+        engine._adapter_upload = engine._adapter_filter = engine._adapter_smooth = engine._adapter_simulated = None
     return prev
 
 
@@ -248,7 +250,54 @@ def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predict
         F, Pf, Xp, Pp = (np.ascontiguousarray(a, dtype=np.float64)[None] for a in given)
         r = kf.smooth_dense(phi[None], F, Pf, Xp, Pp)
     check_status(r["status"], "kalmansmoother_hip")
-    return r["S"][0].cpu().numpy(), r["Ps"][0].cpu().numpy()
+    S, Ps = r["S"][0].cpu().numpy(), r["Ps"][0].cpu().numpy()
+    kf._adapter_smooth = dict(arrays=(S, Ps), device=(r["S"], r["Ps"]))  # simulate_hip projects them where they are
+    return S, Ps
+
+
+def _resident(kf, means, covariances):
+    """The device copies of (means, covariances) when they are the very arrays the last smoother / filter call of this thread's
+    engine returned (so that projecting them needs no upload), else the host arrays with a leading batch axis."""
+    sm = getattr(kf, "_adapter_smooth", None)
+    if sm is not None and means is sm["arrays"][0] and (covariances is None or covariances is sm["arrays"][1]):
+        return sm["device"]
+    fl = getattr(kf, "_adapter_filter", None)
+    if fl is not None and means is fl["arrays"][0] and (covariances is None or covariances is fl["arrays"][1]):
+        return fl["device"]["F"], fl["device"]["Pf"]
+    return np.asarray(means, dtype=np.float64)[None], None if covariances is None else np.asarray(covariances, dtype=np.float64)[None]
+
+
+def simulate_hip(self, observation_matrix, method="smoother"):
+    """Drop-in for ``SPKalmanFilter.simulate`` (metran/kalmanfilter.py:569-603; row a9): the projected means and the clipped
+    diagonal of the projected covariances for every time step, by ``mk_simulate`` (one thread per (t, series)) instead of a Python
+    loop over the T steps -- on examples/data that loop, run twice per ``Metran.get_simulation``, is most of the call.
+    Works on any object carrying the reference's state attributes: ``install()`` binds it to the reference class, the mirror
+    class below uses it.  Returns the same two lists of per-step arrays."""
+    if method == "filter":
+        means, covariances = self.filtered_state_means, self.filtered_state_covariances
+    else:
+        means, covariances = self.smoothed_state_means, self.smoothed_state_covariances
+    kf = get_engine()
+    Z = np.ascontiguousarray(observation_matrix, dtype=np.float64)
+    key = (id(means), id(covariances), Z.shape, Z.tobytes())
+    hit = getattr(kf, "_adapter_simulated", None)
+    if hit is None or hit[0] != key or hit[1] is not means:  # get_simulated_means and _variances ask for the same projection
+        m_dev, c_dev = _resident(kf, means, covariances)
+        sm, sv = kf.simulate(Z, m_dev, c_dev)
+        hit = kf._adapter_simulated = (key, means, sm[0].cpu().numpy(), sv[0].cpu().numpy())
+    return list(hit[2]), list(hit[3])
+
+
+def decompose_hip(self, observation_matrix, method="smoother"):
+    """Drop-in for ``SPKalmanFilter.decompose`` (metran/kalmanfilter.py:605-644): specific and common dynamic components of the
+    projection, by ``mk_decompose``.  Same nested lists as the reference."""
+    means = self.filtered_state_means if method == "filter" else self.smoothed_state_means
+    kf = get_engine()
+    m_dev, _ = _resident(kf, means, None)
+    sdf, cdf = kf.decompose(np.ascontiguousarray(observation_matrix, dtype=np.float64), m_dev)
+    sdf = sdf[0].cpu().numpy()
+    cdf = cdf[0].cpu().numpy()
+    return list(sdf), [list(c) for c in cdf]
 
 
 class SPKalmanFilter:
@@ -371,23 +420,8 @@ class SPKalmanFilter:
         nobs = np.sum(self.observation_count[warmup:])
         return nobs * np.log(2 * np.pi) + np.sum(detfs) + np.sum(sigmas)
 
-    def simulate(self, observation_matrix, method="smoother"):
-        """kalmanfilter.py:569-603 (projection on the device)."""
-        if method == "filter":
-            means, covariances = self.filtered_state_means, self.filtered_state_covariances
-        else:
-            means, covariances = self.smoothed_state_means, self.smoothed_state_covariances
-        sm, sv = self._engine().simulate(np.asarray(observation_matrix, dtype=np.float64), means[None],
-                                         covariances[None])
-        return list(sm[0].cpu().numpy()), list(sv[0].cpu().numpy())
-
-    def decompose(self, observation_matrix, method="smoother"):
-        """kalmanfilter.py:605-644"""
-        means = self.filtered_state_means if method == "filter" else self.smoothed_state_means
-        sdf, cdf = self._engine().decompose(np.asarray(observation_matrix, dtype=np.float64), means[None])
-        sdf = sdf[0].cpu().numpy()
-        cdf = cdf[0].cpu().numpy()
-        return list(sdf), [list(c) for c in cdf]
+    simulate = simulate_hip    # kalmanfilter.py:569-603 (projection on the device)
+    decompose = decompose_hip  # kalmanfilter.py:605-644
 
 
 _PATCHED = {}
@@ -399,15 +433,21 @@ def install(metran_module=None):
     ``Metran.solve`` builds a fresh ``SPKalmanFilter(engine=engine)`` (metran/metran.py:1025, :243),
     whose ``__init__`` binds ``filtermethod`` to the module globals ``seqkalmanfilter_np`` /
     ``seqkalmanfilter`` (:501-504) and whose ``run_smoother`` resolves ``kalmansmoother`` at call
-    time (:685) -- so replacing those three globals is sufficient and touches nothing else."""
+    time (:685) -- so replacing those three globals is sufficient for the filter and the smoother.  Row a9's two projection
+    methods of the class (``simulate`` / ``decompose``: Python loops over the time steps) are bound at class level as well."""
     if metran_module is None:
         import metran as metran_module  # the reference, if importable
     km = metran_module.kalmanfilter
     if km not in _PATCHED:
-        _PATCHED[km] = (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother)
+        _PATCHED[km] = (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother, km.SPKalmanFilter.simulate,
+                        km.SPKalmanFilter.decompose)
     km.seqkalmanfilter = seqkalmanfilter_hip
     km.seqkalmanfilter_np = seqkalmanfilter_hip
     km.kalmansmoother = kalmansmoother_hip
+    # row a9: the two projection methods of the reference class are Python loops over the T steps (:595-602, :633-643);
+    # bound at class level they serve every SPKalmanFilter the reference constructs (Metran.solve builds fresh ones)
+    km.SPKalmanFilter.simulate = simulate_hip
+    km.SPKalmanFilter.decompose = decompose_hip
     return km
 
 
@@ -416,4 +456,5 @@ def uninstall(metran_module=None):
         import metran as metran_module
     km = metran_module.kalmanfilter
     if km in _PATCHED:
-        km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother = _PATCHED.pop(km)
+        (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother, km.SPKalmanFilter.simulate,
+         km.SPKalmanFilter.decompose) = _PATCHED.pop(km)
