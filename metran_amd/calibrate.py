@@ -31,7 +31,7 @@ class CalibrationResult(dict):
 
 def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
                     ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto",
-                    stderr=False, compact=0.5, compact_min=256, fd_below=0):
+                    stderr=False, compact=0.5, compact_min=256, fd_below=0, launch_budget=8192):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
@@ -50,6 +50,10 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     ``fd_below`` instances (0 = never).  A handful of stragglers is latency-bound: one objective launch over (n+1) R
     instances takes as long as one over R, the forward + backward pair of the adjoint 4-5 times as long; the price is
     the differencing error in the last iterations (what scipy's L-BFGS-B works with throughout).
+    ``launch_budget``: instances one latency-bound objective launch may carry (8192 = two wavefronts per SIMD of the 16-lane
+    kernels: 1.3 x the time of a single round).  With differenced gradients, a flight whose (n+1) R instances fit gets the
+    gradient of every trial with the trial, and as many step lengths per searching model at once as fit (up to the whole
+    back-tracking budget): a straggler that exhausts its budget then costs ONE launch instead of a dozen.
     """
     import torch
 
@@ -114,49 +118,35 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         return torch.where((xc <= lo) & (g > 0), torch.zeros_like(g), g)
 
     f, g = value_and_grad(x)
-    S, Y, rho = [], [], []            # L-BFGS history, each [R,n] / [R]
+    f, g = f.contiguous(), g.contiguous()
+    # L-BFGS history: a ring of history + 1 slots [slot, R, n] -- `hist_len` live pairs, the oldest in slot `hist_pos`; the slot
+    # behind the newest receives the tentative pair of an iteration (kept only if some model's pair is usable)
+    H1 = history + 1
+    Sh = torch.zeros((H1, R, n), **f64)
+    Yh = torch.zeros((H1, R, n), **f64)
+    rho = torch.zeros((H1, R), **f64)
+    hist_len = hist_pos = 0
     active = torch.ones(R, dtype=torch.bool, device=dev)
+    pg, d = torch.empty_like(x), torch.empty_like(x)
+    xt, xe = torch.empty_like(x), torch.empty_like(x)
     nit = 0
     for nit in range(1, maxiter + 1):
-        pg = proj_grad(x, g)
-        active &= pg.abs().amax(1) > gtol
-        n_act = int(active.sum())
+        # projected gradient, convergence test on it, two-loop recursion with its safeguards: ONE launch (mk_lbfgs.hip; one
+        # thread per model) and one host synchronisation for the count
+        n_act = kf.lbfgs_direction(x, g, lo, active, Sh, Yh, rho, hist_len, hist_pos, gtol, pg, d)
         if n_act == 0:
             break
         if compact and R > compact_min and n_act < compact * R:
             X_all[orig], F_all[orig], G_all[orig] = x, f, g      # everybody's current state; the inactive ones are final
             keep = active.nonzero().squeeze(1)
             kf = kf.subset(keep)
-            x, f, g, lo, pg, orig = x[keep], f[keep], g[keep], lo[keep], pg[keep], orig[keep]
-            S, Y, rho = [t[keep] for t in S], [t[keep] for t in Y], [t[keep] for t in rho]
+            x, f, g, lo, pg, d, orig = (t[keep].contiguous() for t in (x, f, g, lo, pg, d, orig))
+            Sh, Yh, rho = Sh[:, keep].contiguous(), Yh[:, keep].contiguous(), rho[:, keep].contiguous()
             R = n_act
             active = torch.ones(R, dtype=torch.bool, device=dev)
+            xt, xe = torch.empty_like(x), torch.empty_like(x)
         if grad_mode == "adjoint" and fd_below and (n + 1) * R <= fd_below:
             grad_mode = "fd"
-        # two-loop recursion, all models at once
-        qv = pg.clone()
-        al = []
-        for s_, y_, r_ in zip(reversed(S), reversed(Y), reversed(rho)):
-            a_ = r_ * (s_ * qv).sum(1)
-            al.append(a_)
-            qv = qv - a_[:, None] * y_
-        if S:
-            gamma = (S[-1] * Y[-1]).sum(1) / (Y[-1] * Y[-1]).sum(1).clamp_min(1e-300)
-            qv = qv * gamma[:, None]
-        for (s_, y_, r_), a_ in zip(zip(S, Y, rho), reversed(al)):
-            b_ = r_ * (y_ * qv).sum(1)
-            qv = qv + (a_ - b_)[:, None] * s_
-        d = -qv
-        # fall back to steepest descent where the direction is not a descent direction
-        bad = (d * pg).sum(1) >= 0
-        d = torch.where(bad[:, None], -pg, d)
-        if not S:
-            d = d / pg.abs().amax(1, keepdim=True).clamp_min(1e-300)  # first step: unit-scale move
-        # a parameter ON its bound with the gradient pushing into it stays there: the history pairs carry its gradient
-        # changes (y) though not its moves (s = 0), so the two-loop product can hand it a component pointing INTO the
-        # feasible side -- uphill, and invisible to the Armijo test below, whose slope is the projected gradient's
-        d = torch.where((x <= lo) & (g > 0), torch.zeros_like(d), d)
-        d = torch.where(active[:, None], d, torch.zeros_like(d))
         # Armijo back-tracking on the projected path, one trial per searching model per launch
         step = torch.ones(R, **f64)
         searching = active.clone()
@@ -164,14 +154,14 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         # differenced gradients on a flight that fits one round of wavefronts: the n difference points of every TRIAL ride
         # in its launch (a launch is latency-bound there: T sequential steps whatever the number of instances), so an
         # accepted trial needs no second launch for its gradient
-        speculate = grad_mode == "fd" and (n + 1) * R <= 4096
-        g_acc = g
+        speculate = grad_mode == "fd" and (n + 1) * R <= launch_budget
+        g_acc = g.clone() if speculate else None
         # ... and SEVERAL step lengths of every searching model ride in one launch while they fit (S_tr x (n+1) x R instances
-        # <= 4096): with models in lock-step some model needs a short step in most iterations, and on a small flight every
+        # <= launch_budget): with models in lock-step some model needs a short step in most iterations, and on a small flight every
         # back-tracking round is a latency-bound launch of its own (round 3: 4.6 launches per iteration over the tail).  The
         # largest of the simultaneous trials that passes the Armijo test is taken.
-        S_tr = max(1, min(4, 4096 // ((n + 1) * R))) if speculate else 1
-        ratios = torch.tensor([1.0, 0.35, 0.12, 0.04][:S_tr], **f64)
+        S_tr = max(1, min(max_backtracks, launch_budget // ((n + 1) * R))) if speculate else 1
+        ratios = torch.tensor([0.35 ** k for k in range(S_tr)], **f64)   # 1, 0.35, 0.12, 0.04, ...: twelve of them reach 1e-5
         # the same budget of trial POINTS per model either way (max_backtracks): a straggler whose differenced gradient no longer
         # yields an acceptable step uses all of it before it is declared done, and on a small flight every round is a launch
         for _ in range(-(-max_backtracks // S_tr)):
@@ -190,10 +180,10 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
                 ok = ok_s.any(0)
                 first = torch.argmax(ok_s.to(torch.int8), 0)                                # largest passing step of each model
                 sel = first[None, :, None].expand(1, R, n)
-                xt = torch.gather(xt_s, 0, sel)[0]
+                xt1 = torch.gather(xt_s, 0, sel)[0]
                 ft = torch.gather(ft_s, 0, first[None])[0]
                 gt = ((torch.gather(fv[:, 1:], 0, first[None, None, :].expand(1, n, R))[0] - ft[None]) / eps).transpose(0, 1)
-                x_new = torch.where(ok[:, None], xt, x_new)
+                x_new = torch.where(ok[:, None], xt1, x_new)
                 f_new = torch.where(ok, ft, f_new)
                 g_acc = torch.where(ok[:, None], gt, g_acc)
                 searching &= ~ok
@@ -205,54 +195,42 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
                 theta = torch.where(torch.isfinite(ft_l) & (curv > 0), -gd_l / (2.0 * curv), torch.full_like(ft_l, 0.1))
                 step = torch.where(searching, step * float(ratios[-1]) * theta.clamp(0.1, 0.5), step)
                 continue
-            xt = torch.maximum(x + step[:, None] * d, lo)
-            xe = torch.where(searching[:, None], xt, x_new)          # settled models: at the point they settled on
+            # one trial per searching model: trial point, launch, Armijo test + next step length -- two small launches around
+            # the filter's (mk_lbfgs_trial / mk_lbfgs_armijo), one synchronisation for the number of models still searching
+            kf.lbfgs_trial(x, d, step, lo, searching, x_new, xt, xe)   # settled models: at the point they settled on
             if speculate:
+                before = searching.clone()
                 ft, gt = value_and_grad(xe)
             else:
                 ft = value(xe)
-            gd = (pg * (xt - x)).sum(1)                 # directional derivative along the trial displacement (< 0)
-            ok = searching & (ft <= f + 1e-4 * gd) & torch.isfinite(ft)
-            x_new = torch.where(ok[:, None], xt, x_new)
-            f_new = torch.where(ok, ft, f_new)
-            if speculate:
-                g_acc = torch.where(ok[:, None], gt, g_acc)
-            searching &= ~ok
-            if not bool(searching.any()):
-                break
-            # next trial: the minimiser of the parabola through f, its slope and the rejected value, kept inside
-            # [0.1, 0.5] of the rejected step (plain halving needs log2 of the ratio in launches, and every launch costs
+            # next trial of a rejected model: the minimiser of the parabola through f, its slope and the rejected value, kept
+            # inside [0.1, 0.5] of the rejected step (plain halving needs log2 of the ratio in launches, and every launch costs
             # the whole flight: with thousands of models in lock-step some model needs 1/64 in most iterations)
-            curv = ft - f - gd                          # > 0 wherever the Armijo test failed with a finite value
-            theta = torch.where(torch.isfinite(ft) & (curv > 0), -gd / (2.0 * curv), torch.full_like(ft, 0.1))
-            step = torch.where(searching, step * theta.clamp(0.1, 0.5), step)
-        active &= ~searching  # no acceptable step: this model is done (at numerical precision)
-        f_prev = f
-        g_prev = g
+            n_search = kf.lbfgs_armijo(ft.contiguous(), f, pg, xt, x, searching, step, x_new, f_new)
+            if speculate:
+                g_acc = torch.where((before & ~searching)[:, None], gt, g_acc)
+            if n_search == 0:
+                break
+        # a model still searching found no acceptable step: it is done (at numerical precision) and keeps its old gradient
         if grad_mode == "adjoint":
-            # the last trial launch evaluated every model AT x_new (a model that found no step: at a rejected point --
-            # it keeps its old gradient, and stops)
+            # the last trial launch evaluated every model AT x_new (a model that found no step: at a rejected point)
             launches += 1
-            g_new = torch.where(searching[:, None], g, kf.loglik_backward_alpha())
-            f_tmp = f_new
+            g_cand, f_tmp, keep_old = kf.loglik_backward_alpha(), f_new, True
         elif speculate:
-            f_tmp, g_new = f_new, g_acc
+            g_cand, f_tmp, keep_old = g_acc, f_new, False
         else:
-            f_tmp, g_new = value_and_grad(x_new)
-        s_ = x_new - x
-        y_ = g_new - g_prev
-        sy = (s_ * y_).sum(1)
-        good = sy > 1e-10 * (y_ * y_).sum(1).clamp_min(1e-300)
-        if bool(good.any()):
-            S.append(torch.where(good[:, None], s_, torch.zeros_like(s_)))
-            Y.append(torch.where(good[:, None], y_, torch.zeros_like(y_)))
-            rho.append(torch.where(good, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy)))
-            if len(S) > history:
-                S.pop(0), Y.pop(0), rho.pop(0)
-        x, f, g = x_new, f_tmp, g_new
-        # scipy's relative-reduction test: (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol
-        rel = (f_prev - f) / torch.maximum(torch.maximum(f_prev.abs(), f.abs()), torch.ones_like(f))
-        active &= rel > ftol
+            f_tmp, g_cand = value_and_grad(x_new)
+            keep_old = False
+        # the pair (s, y) of this step into the ring, (x, f, g) <- the accepted point, scipy's relative-reduction test
+        # (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol: ONE launch (mk_lbfgs_update)
+        slot_new = (hist_pos + hist_len) % H1
+        n_good = kf.lbfgs_update(x, f, g, x_new.contiguous(), f_tmp.contiguous(), g_cand.contiguous(), keep_old, searching, active, ftol,
+                                 Sh, Yh, rho, slot_new)
+        if n_good > 0:
+            if hist_len < history:
+                hist_len += 1
+            else:
+                hist_pos = (hist_pos + 1) % H1
         if verbose:
             print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
     X_all[orig], F_all[orig], G_all[orig], active_all[orig] = x, f, g, active

@@ -13,6 +13,7 @@
 
 #include "mk_generic.h"
 #include "mk_internal.h"
+#include "mk_lbfgs.h"
 
 struct mk_context {
     int device;
@@ -31,6 +32,7 @@ struct mk_context {
     int variant[MK_VARIANT_COUNT]; // mk_set_kernel_variant: which of two equivalent (tested) kernels serves a shape class
     double *gws;       // workspace of the size-generic smoother (mk_generic.hip), grown on demand
     size_t gws_cap;    // ... in doubles
+    int *lb_counters;  // device int[4] of the L-BFGS kernels (mk_lbfgs.hip)
 };
 
 static thread_local char g_err[512] = "";
@@ -260,6 +262,7 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->tlist_T = ctx->tlist_N = ctx->tlist_ostep = 0;
     ctx->gws = nullptr;
     ctx->gws_cap = 0;
+    ctx->lb_counters = nullptr;
     for (int &v : ctx->variant) v = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
@@ -284,6 +287,7 @@ MK_API int mk_destroy(mk_context *ctx)
         }
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     if (ctx->gws) (void)hipFree(ctx->gws);
+    if (ctx->lb_counters) (void)hipFree(ctx->lb_counters);
     delete ctx;
     return MK_OK;
 }
@@ -840,6 +844,124 @@ MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *p, double *d
     MK_HIP(dispatch_adjoint((int)p->N, (int)p->K, a, ctx->stream));
     MK_HIP(timing_stop(ctx, 1)); // reported in the smoother slot of mk_last_kernel_ms / mk_kernel_ms_totals
     return MK_OK;
+}
+
+// ---- lock-step L-BFGS of the batched calibration (mk_lbfgs.hip) ----
+static int lbfgs_run(mk_context *ctx, int which, mk::LbfgsArgs &a, int counter, int *h_count)
+{
+    if (a.R <= 0 || a.n <= 0 || a.n > MK_LBFGS_MAX_N || a.H < 1 || a.H > MK_LBFGS_MAX_H)
+        return fail(MK_ERR_INVALID, "mk_lbfgs: need R >= 1, 1 <= n <= %d, 1 <= ring slots <= %d", MK_LBFGS_MAX_N, MK_LBFGS_MAX_H);
+    if (!ctx->lb_counters) MK_HIP(hipMalloc((void **)&ctx->lb_counters, 4 * sizeof(int)));
+    a.counters = ctx->lb_counters;
+    if (counter >= 0) MK_HIP(hipMemsetAsync(ctx->lb_counters + counter, 0, sizeof(int), ctx->stream));
+    MK_HIP(mk::launch_lbfgs(which, a, ctx->stream));
+    if (counter >= 0 && h_count) {
+        MK_HIP(hipMemcpyAsync(h_count, ctx->lb_counters + counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MK_OK;
+}
+
+MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t ring_slots, int64_t len, int64_t pos, const double *d_x,
+                              const double *d_g, const double *d_lo, uint8_t *d_active, const double *d_Sh, const double *d_Yh,
+                              const double *d_rho, double gtol, double *d_pg, double *d_d, int *h_nactive)
+{
+    MK_CTX(ctx);
+    if (!d_x || !d_g || !d_lo || !d_active || !d_pg || !d_d || (len > 0 && (!d_Sh || !d_Yh || !d_rho)) || len < 0 || len >= ring_slots ||
+        pos < 0 || pos >= ring_slots)
+        return fail(MK_ERR_INVALID, "mk_lbfgs_direction: bad argument");
+    mk::LbfgsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    a.n = (int)n;
+    a.H = (int)ring_slots;
+    a.len = (int)len;
+    a.pos = (int)pos;
+    a.gtol = gtol;
+    a.x = const_cast<double *>(d_x);
+    a.g = const_cast<double *>(d_g);
+    a.lo = d_lo;
+    a.active = d_active;
+    a.Sh = const_cast<double *>(d_Sh);
+    a.Yh = const_cast<double *>(d_Yh);
+    a.rho = const_cast<double *>(d_rho);
+    a.pg = d_pg;
+    a.d = d_d;
+    return lbfgs_run(ctx, 0, a, 0, h_nactive);
+}
+
+MK_API int mk_lbfgs_trial(mk_context *ctx, int64_t R, int64_t n, const double *d_x, const double *d_d, const double *d_step, const double *d_lo,
+                          const uint8_t *d_searching, const double *d_x_new, double *d_xt, double *d_xe)
+{
+    MK_CTX(ctx);
+    if (!d_x || !d_d || !d_step || !d_lo || !d_searching || !d_x_new || !d_xt || !d_xe) return fail(MK_ERR_INVALID, "mk_lbfgs_trial: null pointer");
+    mk::LbfgsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    a.n = (int)n;
+    a.H = 1;
+    a.x = const_cast<double *>(d_x);
+    a.d = const_cast<double *>(d_d);
+    a.step = const_cast<double *>(d_step);
+    a.lo = d_lo;
+    a.searching = const_cast<uint8_t *>(d_searching);
+    a.x_new = const_cast<double *>(d_x_new);
+    a.xt = d_xt;
+    a.xe = d_xe;
+    return lbfgs_run(ctx, 1, a, -1, nullptr);
+}
+
+MK_API int mk_lbfgs_armijo(mk_context *ctx, int64_t R, int64_t n, const double *d_ft, const double *d_f, const double *d_pg, const double *d_xt,
+                           const double *d_x, uint8_t *d_searching, double *d_step, double *d_x_new, double *d_f_new, int *h_nsearching)
+{
+    MK_CTX(ctx);
+    if (!d_ft || !d_f || !d_pg || !d_xt || !d_x || !d_searching || !d_step || !d_x_new || !d_f_new)
+        return fail(MK_ERR_INVALID, "mk_lbfgs_armijo: null pointer");
+    mk::LbfgsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    a.n = (int)n;
+    a.H = 1;
+    a.ft = d_ft;
+    a.f = const_cast<double *>(d_f);
+    a.pg = const_cast<double *>(d_pg);
+    a.xt = const_cast<double *>(d_xt);
+    a.x = const_cast<double *>(d_x);
+    a.searching = d_searching;
+    a.step = d_step;
+    a.x_new = d_x_new;
+    a.f_new = d_f_new;
+    return lbfgs_run(ctx, 2, a, 1, h_nsearching);
+}
+
+MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t ring_slots, int64_t slot_new, double *d_x, double *d_f, double *d_g,
+                           const double *d_x_new, const double *d_f_new, const double *d_g_new, int keep_old_gradient_if_searching,
+                           const uint8_t *d_searching, uint8_t *d_active, double ftol, double *d_Sh, double *d_Yh, double *d_rho, int *h_ngood)
+{
+    MK_CTX(ctx);
+    if (!d_x || !d_f || !d_g || !d_x_new || !d_f_new || !d_g_new || !d_searching || !d_active || !d_Sh || !d_Yh || !d_rho || slot_new < 0 ||
+        slot_new >= ring_slots)
+        return fail(MK_ERR_INVALID, "mk_lbfgs_update: bad argument");
+    mk::LbfgsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = R;
+    a.n = (int)n;
+    a.H = (int)ring_slots;
+    a.slot_new = (int)slot_new;
+    a.keep_old = keep_old_gradient_if_searching;
+    a.ftol = ftol;
+    a.x = d_x;
+    a.f = d_f;
+    a.g = d_g;
+    a.x_new = const_cast<double *>(d_x_new);
+    a.f_new = const_cast<double *>(d_f_new);
+    a.g_new = d_g_new;
+    a.searching = const_cast<uint8_t *>(d_searching);
+    a.active = d_active;
+    a.Sh = d_Sh;
+    a.Yh = d_Yh;
+    a.rho = d_rho;
+    return lbfgs_run(ctx, 3, a, 2, h_ngood);
 }
 
 MK_API int mk_alpha_grad(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K, const double *alpha,

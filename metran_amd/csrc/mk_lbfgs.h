@@ -1,0 +1,31 @@
+// mk_lbfgs.h -- the lock-step L-BFGS kernels of the batched calibration (mk_lbfgs.hip): argument block shared with the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MK_LBFGS_MAX_N 64  /* parameters per model (= states: one alpha per state) */
+#define MK_LBFGS_MAX_H 17  /* ring slots: at most 16 live pairs + the tentative one */
+
+namespace mk {
+
+struct LbfgsArgs {
+    long R;                 // models
+    int n, H, len, pos;     // parameters per model; ring slots; live pairs; slot of the oldest live pair
+    int slot_new;           // update: slot the tentative pair is written to
+    int keep_old;           // update: models that found no step keep their old gradient (adjoint mode: g_new is only valid elsewhere)
+    double gtol, ftol;
+    double *x, *g, *f;      // current point [R,n], gradient [R,n], objective [R]
+    const double *lo;       // lower bounds [R,n]
+    unsigned char *active, *searching; // [R]
+    double *Sh, *Yh, *rho;  // history ring [H,R,n], [H,R,n], [H,R]
+    double *pg, *d;         // projected gradient, search direction [R,n]
+    double *step;           // [R]
+    double *xt, *xe;        // trial point, point to evaluate [R,n]
+    double *x_new, *f_new;  // accepted point so far [R,n], its objective [R]
+    const double *ft;       // objective at the trial points [R]
+    const double *g_new;    // gradient at the accepted points [R,n]
+    int *counters;          // device int[4]: #active (direction), #still searching (armijo), #good pairs (update)
+};
+
+hipError_t launch_lbfgs(int which, const LbfgsArgs &a, hipStream_t s); // 0 direction, 1 trial, 2 armijo, 3 update
+
+} // namespace mk

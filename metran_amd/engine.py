@@ -784,6 +784,47 @@ class BatchedKalman:
         check(self._L.mk_sum(self._ctx, int(values.numel()), self._p(values), self._p(out)))
         return out[0]
 
+    # ------------------------------------------------------------------ lock-step L-BFGS (calibrate_batch; mk_lbfgs.hip)
+    def lbfgs_direction(self, x, g, lo, active, Sh, Yh, rho, hist_len, hist_pos, gtol, pg, d):
+        """Projected gradient into ``pg``, ``active &= max|pg| > gtol``, the two-loop recursion over the ``hist_len`` live pairs of
+        the history ring (oldest in slot ``hist_pos``) with its safeguards into ``d``.  Returns the number of active models."""
+        R, n = (int(v) for v in x.shape)
+        cnt = ctypes.c_int(0)
+        self._bind_stream()
+        check(self._L.mk_lbfgs_direction(self._ctx, R, n, int(Sh.shape[0]), int(hist_len), int(hist_pos), self._p(x), self._p(g), self._p(lo),
+                                         self._p(active), self._p(Sh), self._p(Yh), self._p(rho), float(gtol), self._p(pg), self._p(d),
+                                         ctypes.byref(cnt)))
+        return int(cnt.value)
+
+    def lbfgs_trial(self, x, d, step, lo, searching, x_new, xt, xe):
+        """``xt = max(x + step d, lo)``; ``xe = xt`` for the searching models, their accepted point for the settled ones."""
+        R, n = (int(v) for v in x.shape)
+        self._bind_stream()
+        check(self._L.mk_lbfgs_trial(self._ctx, R, n, self._p(x), self._p(d), self._p(step), self._p(lo), self._p(searching), self._p(x_new),
+                                     self._p(xt), self._p(xe)))
+
+    def lbfgs_armijo(self, ft, f, pg, xt, x, searching, step, x_new, f_new):
+        """Armijo test of the searching models at their trial points (in place: ``x_new, f_new, searching, step``).  Returns the
+        number of models still searching."""
+        R, n = (int(v) for v in x.shape)
+        cnt = ctypes.c_int(0)
+        self._bind_stream()
+        check(self._L.mk_lbfgs_armijo(self._ctx, R, n, self._p(ft), self._p(f), self._p(pg), self._p(xt), self._p(x), self._p(searching),
+                                      self._p(step), self._p(x_new), self._p(f_new), ctypes.byref(cnt)))
+        return int(cnt.value)
+
+    def lbfgs_update(self, x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, slot_new):
+        """The pair of the accepted points into ring slot ``slot_new``, ``(x, f, g) <- (x_new, f_new, g_new)`` (models still
+        searching keep their old gradient if ``keep_old``), ``active &= ~searching & (relative reduction > ftol)``.  Returns the
+        number of models whose pair is usable (the caller keeps the slot only if that is > 0)."""
+        R, n = (int(v) for v in x.shape)
+        cnt = ctypes.c_int(0)
+        self._bind_stream()
+        check(self._L.mk_lbfgs_update(self._ctx, R, n, int(Sh.shape[0]), int(slot_new), self._p(x), self._p(f), self._p(g), self._p(x_new),
+                                      self._p(f_new), self._p(g_new), 1 if keep_old else 0, self._p(searching), self._p(active),
+                                      float(ftol), self._p(Sh), self._p(Yh), self._p(rho), ctypes.byref(cnt)))
+        return int(cnt.value)
+
     # ------------------------------------------------------------------ instrumentation
     def enable_timing(self, enable=True, accumulate=False):
         """hipEvents around every hot-kernel launch.  ``accumulate``: every launch keeps its own event pair until

@@ -10,9 +10,79 @@ import oracle
 from metran_amd.params import phi_q_from_alpha
 
 
-class OracleEngine:
+class TorchLbfgs:
+    """The four lock-step L-BFGS steps of ``calibrate_batch`` as plain torch operations -- the code the driver ran until round 5,
+    kept as the restatement of ``metran_amd/csrc/mk_lbfgs.hip`` (same arguments and in-place conventions as
+    ``BatchedKalman.lbfgs_*``): the CPU tier runs the driver over it, tests/test_lbfgs_gpu.py compares the kernels with it."""
+
+    @staticmethod
+    def lbfgs_direction(x, g, lo, active, Sh, Yh, rho, hist_len, hist_pos, gtol, pg, d):
+        H = Sh.shape[0]
+        bound = (x <= lo) & (g > 0)
+        pg.copy_(torch.where(bound, torch.zeros_like(g), g))
+        active &= pg.abs().amax(1) > gtol
+        slots = [(hist_pos + i) % H for i in range(hist_len)]          # oldest ... newest
+        qv = pg.clone()
+        al = []
+        for sl in reversed(slots):
+            a_ = rho[sl] * (Sh[sl] * qv).sum(1)
+            al.append(a_)
+            qv = qv - a_[:, None] * Yh[sl]
+        if slots:
+            sl = slots[-1]
+            gamma = (Sh[sl] * Yh[sl]).sum(1) / (Yh[sl] * Yh[sl]).sum(1).clamp_min(1e-300)
+            qv = qv * gamma[:, None]
+        for sl, a_ in zip(slots, reversed(al)):
+            b_ = rho[sl] * (Yh[sl] * qv).sum(1)
+            qv = qv + (a_ - b_)[:, None] * Sh[sl]
+        dd = -qv
+        bad = (dd * pg).sum(1) >= 0
+        dd = torch.where(bad[:, None], -pg, dd)
+        if not slots:
+            dd = dd / pg.abs().amax(1, keepdim=True).clamp_min(1e-300)
+        dd = torch.where(bound, torch.zeros_like(dd), dd)
+        d.copy_(torch.where(active[:, None], dd, torch.zeros_like(dd)))
+        return int(active.sum())
+
+    @staticmethod
+    def lbfgs_trial(x, d, step, lo, searching, x_new, xt, xe):
+        xt.copy_(torch.maximum(x + step[:, None] * d, lo))
+        xe.copy_(torch.where(searching[:, None], xt, x_new))
+
+    @staticmethod
+    def lbfgs_armijo(ft, f, pg, xt, x, searching, step, x_new, f_new):
+        gd = (pg * (xt - x)).sum(1)
+        ok = searching & (ft <= f + 1e-4 * gd) & torch.isfinite(ft)
+        x_new.copy_(torch.where(ok[:, None], xt, x_new))
+        f_new.copy_(torch.where(ok, ft, f_new))
+        searching &= ~ok
+        curv = ft - f - gd
+        theta = torch.where(torch.isfinite(ft) & (curv > 0), -gd / (2.0 * curv), torch.full_like(ft, 0.1))
+        step.copy_(torch.where(searching, step * theta.clamp(0.1, 0.5), step))
+        return int(searching.sum())
+
+    @staticmethod
+    def lbfgs_update(x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, slot_new):
+        gn = torch.where(searching[:, None], g, g_new) if keep_old else g_new
+        s_ = x_new - x
+        y_ = gn - g
+        sy = (s_ * y_).sum(1)
+        good = sy > 1e-10 * (y_ * y_).sum(1).clamp_min(1e-300)
+        Sh[slot_new] = torch.where(good[:, None], s_, torch.zeros_like(s_))
+        Yh[slot_new] = torch.where(good[:, None], y_, torch.zeros_like(y_))
+        rho[slot_new] = torch.where(good, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy))
+        rel = (f - f_new) / torch.maximum(torch.maximum(f.abs(), f_new.abs()), torch.ones_like(f))
+        active &= ~searching & (rel > ftol)
+        x.copy_(x_new)
+        g.copy_(gn)
+        f.copy_(f_new)
+        return int(good.sum())
+
+
+class OracleEngine(TorchLbfgs):
     """The slice of ``BatchedKalman`` that ``calibrate_batch`` touches, on the CPU, values from the C oracle
-    (``oracle_dfm_batch``) and gradients from the numpy adjoint restatement (tests/adjoint_ref.py)."""
+    (``oracle_dfm_batch``) and gradients from the numpy adjoint restatement (tests/adjoint_ref.py); the L-BFGS steps from the
+    torch restatement above."""
 
     def __init__(self, obs=None, loadings=None, adjoint=True, log=None):
         self.device = torch.device("cpu")

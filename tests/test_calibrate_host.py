@@ -80,14 +80,19 @@ def test_compaction_leaves_every_models_iterates_unchanged(models):
 
 
 def test_differenced_small_flight_takes_several_trials_per_launch(models, optima):
-    """gradient="fd" on a flight with (n+1) R <= 4096 instances: every launch carries S_tr = 4 step lengths x (n+1)
-    difference points x R models, and an accepted trial needs no further launch for its gradient."""
+    """gradient="fd" on a flight whose (n+1) R instances fit the launch budget: every launch carries S_tr step lengths x (n+1)
+    difference points x R models -- as many as fit, up to the whole back-tracking budget of 12 (round 5; four before) -- and an
+    accepted trial needs no further launch for its gradient."""
     eng = OracleEngine(*models, adjoint=False)
-    res = calibrate_batch(eng, gradient="auto", compact=0)
-    check_against_scipy(res, optima)
     n, R = eng.n, eng.R
+    res = calibrate_batch(eng, gradient="auto", compact=0, launch_budget=4 * (n + 1) * R)
+    check_against_scipy(res, optima)
     assert eng.log[0] == ("loglik", (n + 1) * R)
     assert all(k == "loglik" and b == 4 * (n + 1) * R for k, b in eng.log[1:])
+    eng12 = OracleEngine(*models, adjoint=False)
+    res12 = calibrate_batch(eng12, gradient="auto", compact=0)          # default budget: all twelve step lengths at once
+    check_against_scipy(res12, optima)
+    assert all(b == 12 * (n + 1) * R for _, b in eng12.log[1:]) and len(eng12.log) <= len(eng.log)
     assert res.launches == len(eng.log) and res.nfev == sum(b for _, b in eng.log)
     # the differenced gradient the result carries is the forward difference at the result
     f, g = res.obj.numpy(), res.grad.numpy()
