@@ -184,8 +184,13 @@ MK_API int mk_sync(mk_context *ctx);
  *                             sets (the 7-tuple of seqkalmanfilter for a single Metran model): 0 the observed steps walked one
  *                             after the other and the records of the empty steps written in closed form by a second, parallel
  *                             kernel (kalmanfilter.py:335 skips the update on those steps; examples/data: 343 of 6255 steps
- *                             carry data), 1 the batched filter_kernel step by step */
-enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_SINGLE_RECORD = 3, MK_VARIANT_COUNT = 4 };
+ *                             carry data), 1 the batched filter_kernel step by step
+ *   MK_VARIANT_KERNEL_FAMILY  0 the specialised kernels where a shape has them, 1 the size-generic kernels (mk_generic.hip) for EVERY
+ *                             shape (mk_filter / mk_loglik / mk_smooth / mk_filter_smooth with dense arrays or full-square records):
+ *                             the second, independent implementation of the same recursions, for cross-checks and for timing
+ *                             what specialisation buys */
+enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_SINGLE_RECORD = 3,
+       MK_VARIANT_KERNEL_FAMILY = 4, MK_VARIANT_COUNT = 5 };
 #define MK_SPARSE_RECORD_MAX_INSTANCES 16
 MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value);
 MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value);

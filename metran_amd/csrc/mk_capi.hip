@@ -124,8 +124,9 @@ bool aot_state_dim(int64_t n)
 }
 bool specialised(int64_t N, int64_t K) { return aot_shape(N, K) || find_module(N, K) != nullptr; }
 bool generic_shape(int64_t N, int64_t K) { return N >= 1 && K >= 1 && N + K <= MK_GENERIC_MAX_STATES; }
-hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s)
+hipError_t dispatch_filter(int N, int K, const mk::FilterArgs &a, hipStream_t s, bool force_generic = false)
 {
+    if (force_generic) return generic_shape(N, K) ? mk::launch_filter_generic(N, K, a, s) : hipErrorInvalidValue;
     if (aot_shape(N, K)) return mk::launch_filter(N, K, a, s);
     if (const ShapeModule *m = find_module(N, K)) return (hipError_t)m->launch_filter(&a, (void *)s);
     if (generic_shape(N, K)) return mk::launch_filter_generic(N, K, a, s); // any shape, not specialised (mk_generic.hip)
@@ -167,8 +168,11 @@ hipError_t dispatch_smoother(mk_context *ctx, int N, int K, const mk::SmootherAr
 {
     // the plain smoother depends on n = N + K only; the projecting one needs the exact (N, K)
     const bool proj = a.sim_means || a.sim_vars;
-    if (proj ? aot_shape(N, K) : aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
-    if (const ShapeModule *m = find_module(N, K, !proj)) return (hipError_t)m->launch_smoother(&a, (void *)s);
+    const bool force_generic = ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1;
+    if (!force_generic) {
+        if (proj ? aot_shape(N, K) : aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
+        if (const ShapeModule *m = find_module(N, K, !proj)) return (hipError_t)m->launch_smoother(&a, (void *)s);
+    }
     if (generic_shape(N, K)) {
         mk::GenericSmootherArgs g;
         g.a = a;
@@ -304,7 +308,7 @@ MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
 {
     MK_CTX(ctx);
     if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
-    if (value < 0 || value > ((which == MK_VARIANT_SMOOTHER16 || which == MK_VARIANT_SINGLE_RECORD) ? 1 : 2))
+    if (value < 0 || value > ((which == MK_VARIANT_SMOOTHER16 || which == MK_VARIANT_SINGLE_RECORD || which == MK_VARIANT_KERNEL_FAMILY) ? 1 : 2))
         return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for the two wide selectors)");
     ctx->variant[which] = value;
     return MK_OK;
@@ -563,7 +567,8 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     // the update on the others), so the observed steps are walked one after the other and every empty step's records are
     // written in closed form by a second, fully parallel kernel (mk_kernels.hip: loglik_sparse_kernel<.., REC>, fill_gaps_kernel).
     if (rec && p->n_records == 1 && p->n_instances <= MK_SPARSE_RECORD_MAX_INSTANCES && p->N + p->K <= 16 && o->d_Xp &&
-        !(o->flags & MK_OUT_PACKED_SYM) && specialised(p->N, p->K) && !ctx->variant[MK_VARIANT_SINGLE_RECORD])
+        !(o->flags & MK_OUT_PACKED_SYM) && specialised(p->N, p->K) && !ctx->variant[MK_VARIANT_SINGLE_RECORD] &&
+        !ctx->variant[MK_VARIANT_KERNEL_FAMILY])
         return sparse_route(ctx, p, o->d_mle, o->d_F, o->d_Xp, o->record_stride, (int)o->time_major, o->d_sigmacount, o->d_status);
     mk::FilterArgs a;
     a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER]; // 0 auto, 1 lane per state, 2 split
@@ -596,11 +601,11 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.Xp = o->d_Xp;
     a.Pp = o->d_Pp;
     a.status = o->d_status;
-    if (a.sym && !specialised(p->N, p->K))
-        return fail(MK_ERR_SHAPE, "packed-symmetric records exist for specialised shapes only (N=%lld, K=%lld runs the size-generic "
+    if ((a.sym || a.tape) && (!specialised(p->N, p->K) || ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1))
+        return fail(MK_ERR_SHAPE, "packed-symmetric records and the tape exist for specialised shapes only (N=%lld, K=%lld runs the size-generic "
                                   "kernels: mk_shape_specialised)", (long long)p->N, (long long)p->K);
     MK_HIP(timing_start(ctx, 0));
-    MK_HIP(dispatch_filter((int)p->N, (int)p->K, a, ctx->stream));
+    MK_HIP(dispatch_filter((int)p->N, (int)p->K, a, ctx->stream, ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1));
     MK_HIP(timing_stop(ctx, 0));
     return MK_OK;
 }
@@ -671,7 +676,7 @@ static int do_smooth(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     }
     a.status = o->d_status;
     MK_HIP(timing_start(ctx, 1));
-    if ((sym || tape) && !specialised(p->N, p->K))
+    if ((sym || tape) && (!specialised(p->N, p->K) || ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1))
         return fail(MK_ERR_SHAPE, "packed-symmetric records and the tape exist for specialised shapes only (N=%lld, K=%lld runs the "
                                   "size-generic kernels: mk_shape_specialised)", (long long)p->N, (long long)p->K);
     MK_HIP(dispatch_smoother(ctx, (int)p->N, (int)p->K, a, ctx->stream));
@@ -692,7 +697,7 @@ MK_API int mk_loglik(mk_context *ctx, const mk_problem *p, double *d_mle)
     MK_CTX(ctx);
     if (int rc = check_problem(p)) return rc;
     if (!d_mle) return fail(MK_ERR_INVALID, "d_mle is required");
-    if (p->n_records == 1 && p->N + p->K <= 16 && p->d_obs && p->d_loadings && specialised(p->N, p->K)) {
+    if (p->n_records == 1 && p->N + p->K <= 16 && p->d_obs && p->d_loadings && specialised(p->N, p->K) && !ctx->variant[MK_VARIANT_KERNEL_FAMILY]) {
         // every instance shares the one record (the solver's finite-difference points): walk only its
         // observed steps, the runs of empty steps in closed form (loglik_sparse_kernel)
         return sparse_route(ctx, p, d_mle, nullptr, nullptr, 0, 0, nullptr, nullptr);
@@ -800,7 +805,7 @@ MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *p, double *d
     if (!d_work || !d_sigmacount || ((phases & MK_GRAD_FORWARD) && !d_mle) || ((phases & MK_GRAD_BACKWARD) && (!d_gphi || !d_gq)))
         return fail(MK_ERR_INVALID, "mk_loglik_grad: d_work and d_sigmacount are required; d_mle by the forward pass, d_gphi and d_gq by the backward pass");
     const int64_t n = p->N + p->K;
-    if (!specialised(p->N, p->K))
+    if (!specialised(p->N, p->K) || ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1)
         return fail(MK_ERR_SHAPE, "the adjoint gradient exists for specialised shapes (N + K <= 64: ahead-of-time list or a shape "
                                   "module); N=%lld, K=%lld runs the size-generic kernels, difference mk_loglik instead",
                     (long long)p->N, (long long)p->K);

@@ -99,7 +99,8 @@ class BatchedKalman:
     _VARIANTS = {"smoother16": (0, ("record", "blk")),
                  "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded")),
                  "wide_filter": (2, ("auto", "lane_per_state", "split")),
-                 "single_record": (3, ("sparse", "stepwise"))}
+                 "single_record": (3, ("sparse", "stepwise")),
+                 "kernel_family": (4, ("specialised", "generic"))}
     # variants every new engine starts with (name -> value); empty = the library's defaults.  The GPU test tier sets
     # {"wide_filter": "split"} so that its small batches keep exercising the split kernels, which "auto" reserves for
     # batches of more than two models per SIMD (tests/conftest.py; tests/test_hip_layouts.py checks "auto" itself)
@@ -476,7 +477,7 @@ class BatchedKalman:
     def has_adjoint(self):
         """Whether ``loglik_grad`` (``mk_loglik_grad``) serves this engine's shape: ``adjoint_kernel`` for n <= 16 (four
         models per wavefront), ``adjoint_wide_kernel`` for 16 < n <= 64 (one model per wavefront)."""
-        return self.N is not None and self.n <= 64 and self.specialised()
+        return self.N is not None and self.n <= 64 and self.specialised() and self.get_variant("kernel_family") == "specialised"
 
     def loglik_grad_alpha(self, alpha, dt=1.0, warmup=1):
         """``(mle [B], d mle / d alpha [B,n])`` for Metran's parametrisation (``params_from_alpha`` forward,
@@ -608,7 +609,8 @@ class BatchedKalman:
         """True when ``simulate_smoothed`` runs the inverse-free backward pass over the filter's tape (``MK_OUT_TAPE``:
         ``mk_split.hip`` OUT = 4 + ``mk_dk.hip``) instead of filtered records + the RTS smoother: wide models served by the
         split filter (16 < n, N <= 32), full-square engine, ``projection_path`` not "records"."""
-        ok = (self.loadings is not None and not self.packed_sym and bool(self._L.mk_tape_supported(self.N, self.K)))
+        ok = (self.loadings is not None and not self.packed_sym and bool(self._L.mk_tape_supported(self.N, self.K))
+              and self.get_variant("kernel_family") == "specialised")
         if self.projection_path == "tape" and not ok:
             raise MetranHipError("projection_path='tape' needs a model with 16 < N + K, N <= 32 and a full-square engine "
                                  "(got N=%s, K=%s)" % (self.N, getattr(self, "K", None)))

@@ -53,9 +53,15 @@ def _extra_flags():
 
 
 def _source_hash():
+    """Identity of what a shape module is compiled from: the four kernel files and their headers in full; of the public header
+    only what the kernels consume (the MK_API / MK_FLAG_* / MK_OUT_* definitions) -- a new entry point or a reworded comment in
+    include/metran_hip.h does not orphan every prebuilt module (the argument structs are guarded separately: mkmod_abi)."""
     h = hashlib.sha256()
     for f in _SOURCES:
-        h.update(open(f, "rb").read())
+        data = open(f, "rb").read()
+        if f.endswith("metran_hip.h"):
+            data = b"\n".join(ln for ln in data.splitlines() if ln.startswith((b"#define MK_API", b"#define MK_FLAG_", b"#define MK_OUT_")))
+        h.update(data)
     h.update(" ".join(_extra_flags()).encode())
     return h.hexdigest()[:16]
 

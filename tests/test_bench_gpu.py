@@ -95,7 +95,7 @@ def test_secondary_factor_analysis_and_calibration(line):
     f1 = line["secondary"]["f1_calibration"]
     assert "error" not in f1, f1
     assert f1["converged_frac"] > 0.95 and f1["frac_at_or_below_true_parameter_objective"] > 0.95, f1
-    assert f1["models_per_s"] >= 4000.0, f1
+    assert f1["models_per_s"] >= 8000.0, f1    # round 5: 9.9-11 k (0.75-0.83 s for 8192 models); round 4: 10.9 k on its lease
 
 
 def test_secondary_dropin_configs0(line):
@@ -110,6 +110,9 @@ def test_secondary_dropin_configs0(line):
         assert c1[k]["solve_s"] > 0 and c1[k]["get_simulation_s"] > 0 and c1[k]["simulation_rows"] == ref["simulation_rows"]
     assert abs(c1["hip_engine_scipy_solver"]["nfev"] - 77) <= 14
     assert c1["hip_solver_adjoint"]["nfev"] < 40
+    # round 5: the single-record route walks the observed steps only, simulate / decompose run on the device:
+    # 0.164 s / 0.016 s measured through the unmodified class (round 4: 0.374 / 0.049); floors with a wide margin for a slow host
+    assert c1["hip_engine_scipy_solver"]["solve_s"] < 0.30 and c1["hip_engine_scipy_solver"]["get_simulation_s"] < 0.035, c1
 
 
 def test_secondary_factor_analysis_wide(line):

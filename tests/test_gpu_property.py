@@ -171,3 +171,40 @@ def test_objective_and_gradient_property(key, g, jit_cache):
                 ref = hard_models.oracle_model(oracle, gs, 0, smooth=False)["mle"]
                 assert abs(got[s] - ref) <= 1e-9 * max(1.0, abs(ref)), (b, s, g["patterns"][b])
             kf.close()
+
+
+@pytest.mark.parametrize("key,g", GROUPS, ids=IDS)
+def test_generic_kernel_family_property(key, g, jit_cache):
+    """The same sweep through the SECOND implementation of the recursions: ``set_variant("kernel_family", "generic")`` sends every
+    shape -- also the ones with specialised kernels -- through ``mk_generic.hip`` (one model per workgroup, covariance in LDS,
+    LDL^T smoother): all six state arrays, the objective, the projection and the state variances against the oracle at the
+    specialised kernels' tolerances.  Two independent GPU implementations and the CPU restatement agree on every sampled model."""
+    N, K, T, B = key
+    kf = _engine(g, "model_major" if (N + T) % 2 else "time_major")
+    kf.set_variant("kernel_family", "generic")
+    assert not kf.has_adjoint() and not kf.tape_path()
+    r = kf.filter_smooth(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+    s = kf.smooth_state_variances(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+    p = kf.simulate_smoothed(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+    mle = _np(kf.loglik(g["phi"], g["q"], x0=g["x0"], P0=g["P0"]))
+    for b in range(B):
+        ref = hard_models.oracle_model(oracle, g, b)
+        sc = ref["sigmacount"]
+        what = "model %d (%s)" % (b, g["patterns"][b])
+        assert int(_np(r["sigmacount"])[b]) == sc, what
+        for val in (_np(r["mle"])[b], mle[b], _np(s["mle"])[b], _np(p["mle"])[b]):
+            assert abs(val - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+        np.testing.assert_allclose(_np(r["sigmas"])[b, :sc], ref["sigmas"][:sc], rtol=1e-9, atol=1e-10, err_msg=what)
+        np.testing.assert_allclose(_np(r["detfs"])[b, :sc], ref["detfs"][:sc], rtol=0, atol=1e-10 + 1e-15 / float(g["q"][b].min()), err_msg=what)
+        scale = max(1.0, float(np.abs(ref["Pp"]).max()), float(np.abs(ref["F"]).max()))
+        for k in ("F", "Pf", "Xp", "Pp"):
+            np.testing.assert_allclose(_np(r[k])[b], ref[k], rtol=0, atol=1e-10 * scale, err_msg=what + " " + k)
+        tol = hard_models.smoother_tolerance(g, b, ref)
+        np.testing.assert_allclose(_np(r["S"])[b], ref["S"], rtol=0, atol=tol, err_msg=what + " S")
+        np.testing.assert_allclose(_np(r["Ps"])[b], ref["Ps"], rtol=0, atol=tol, err_msg=what + " Ps")
+        np.testing.assert_allclose(_np(s["S"])[b], ref["S"], rtol=0, atol=tol, err_msg=what + " state means")
+        np.testing.assert_allclose(_np(s["var"])[b], np.diagonal(ref["Ps"], axis1=1, axis2=2), rtol=0, atol=tol, err_msg=what + " state variances")
+        np.testing.assert_allclose(_np(p["sim_means"])[b], ref["S"] @ ref["Z"].T, rtol=0, atol=2 * tol, err_msg=what + " sim_means")
+        np.testing.assert_allclose(_np(p["sim_vars"])[b], np.maximum(np.einsum("jn,tnm,jm->tj", ref["Z"], ref["Ps"], ref["Z"]), 0.0), rtol=0,
+                                   atol=2 * tol, err_msg=what + " sim_vars")
+    kf.close()
