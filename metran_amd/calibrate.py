@@ -31,7 +31,7 @@ class CalibrationResult(dict):
 
 def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
                     ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto",
-                    stderr=False, compact=0.5, compact_min=256, fd_below=0, launch_budget=8192):
+                    stderr=False, compact=0.5, compact_min=256, fd_below=0, launch_budget=None):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
@@ -50,8 +50,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     ``fd_below`` instances (0 = never).  A handful of stragglers is latency-bound: one objective launch over (n+1) R
     instances takes as long as one over R, the forward + backward pair of the adjoint 4-5 times as long; the price is
     the differencing error in the last iterations (what scipy's L-BFGS-B works with throughout).
-    ``launch_budget``: instances one latency-bound objective launch may carry (8192 = two wavefronts per SIMD of the 16-lane
-    kernels: 1.3 x the time of a single round).  With differenced gradients, a flight whose (n+1) R instances fit gets the
+    ``launch_budget``: instances one latency-bound objective launch may carry (default: two wavefronts per SIMD of an MI355X --
+    8192 instances of the 16-lane kernels, four models per wavefront, 4096 of the wide ones: 1.3 x the time of a single round).  With differenced gradients, a flight whose (n+1) R instances fit gets the
     gradient of every trial with the trial, and as many step lengths per searching model at once as fit (up to the whole
     back-tracking budget): a straggler that exhausts its budget then costs ONE launch instead of a dozen.
     """
@@ -59,6 +59,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
 
     R, n = kf.R, kf.n
     dev = kf.device
+    if launch_budget is None:
+        launch_budget = 8192 if n <= 16 else 4096
     f64 = dict(dtype=torch.float64, device=dev)
     x = torch.full((R, n), float(alpha0), **f64) if np.isscalar(alpha0) else kf._dev(alpha0, (R, n), "alpha0").clone()
     lo = torch.full((R, n), float(pmin), **f64) if np.isscalar(pmin) else kf._dev(pmin, (R, n), "pmin")

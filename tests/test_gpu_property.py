@@ -84,6 +84,21 @@ def test_filter_smooth_property(key, g, jit_cache):
         tol = hard_models.smoother_tolerance(g, b, ref)
         np.testing.assert_allclose(_np(r["S"])[b], ref["S"], rtol=0, atol=tol, err_msg=what + " S")
         np.testing.assert_allclose(_np(r["Ps"])[b], ref["Ps"], rtol=0, atol=tol, err_msg=what + " Ps")
+    if N + K > 16 and N <= 32:
+        # the GPU tier's engines start with the split-layout wide filter forced (tests/conftest.py); what a batch this small
+        # gets by DEFAULT is one state per lane (filter_kernel<N,K,64>): the same sweep through it (round-4 advice)
+        kf.set_variant("wide_filter", "auto")
+        assert kf.resolved_wide_filter(B) == "lane_per_state"
+        r2 = kf.filter_smooth(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
+        for b in range(B):
+            ref = hard_models.oracle_model(oracle, g, b)
+            what = "model %d (%s), one state per lane" % (b, g["patterns"][b])
+            assert abs(_np(r2["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+            scale = max(1.0, float(np.abs(ref["Pp"]).max()), float(np.abs(ref["F"]).max()))
+            for k in ("F", "Pf", "Xp", "Pp"):
+                np.testing.assert_allclose(_np(r2[k])[b], ref[k], rtol=0, atol=1e-10 * scale, err_msg=what + " " + k)
+            tol = hard_models.smoother_tolerance(g, b, ref)
+            np.testing.assert_allclose(_np(r2["Ps"])[b], ref["Ps"], rtol=0, atol=tol, err_msg=what + " Ps")
     kf.close()
 
 
