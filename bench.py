@@ -741,7 +741,7 @@ def secondary_factor_analysis(dev, R=4096, T=1000, N=8, K=2, reps=3, scipy_subse
         FactorAnalysisBatch._lockstep_minres = orig_lock
 
 
-def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200):
+def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200, missing=0.0):
     """Row f1 in the driver's record: ``calibrate_batch`` (lock-step L-BFGS-B on the adjoint gradient) of B independent
     models from the default start to convergence."""
     import torch
@@ -750,7 +750,7 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
     from metran_amd.engine import BatchedKalman
     from metran_amd.synthetic import make_dfm_batch_torch
 
-    d = make_dfm_batch_torch(B, N, K, T, seed=5000, device=dev, missing=0.0)
+    d = make_dfm_batch_torch(B, N, K, T, seed=5000, device=dev, missing=missing)
     kf = BatchedKalman(local_rank, layout="time_major")
     try:
         kf.set_observations(d["obs"]).set_loadings(d["loadings"])
@@ -761,8 +761,10 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         true_obj = kf.loglik(d["phi"], d["q"])
-        return {"workload": "calibrate_batch: %d x (%d series, %d factors), T=%d, fp64, adjoint gradient (forward differences once 11 x active models <= 4096)" % (B, N, K, T),
+        return {"workload": "calibrate_batch: %d x (%d series, %d factors), T=%d, %d %% missing, fp64, adjoint gradient (forward differences once "
+                            "%d x active models <= 4096), the L-BFGS step on the device (mk_lbfgs.hip)" % (B, N, K, T, round(100 * missing), N + K + 1),
                 "seconds": dt, "models_per_s": B / dt, "iterations": int(res.nit), "objective_evaluations": int(res.nfev),
+                "launches": int(res.launches),
                 "converged_frac": float(res.converged.double().mean()),
                 "frac_at_or_below_true_parameter_objective": float((res.obj <= true_obj + 1e-6).double().mean())}
     finally:
@@ -1033,6 +1035,7 @@ def main():
                          ("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
                          ("f4_factor_analysis_32x4", lambda: secondary_factor_analysis(dev, N=32, K=4, reps=2, scipy_subset=256)),
                          ("f1_calibration", lambda: secondary_calibration(local_rank, dev)),
+                         ("f1_calibration_32x4", lambda: secondary_calibration(local_rank, dev, B=512, N=32, K=4, T=500, missing=0.3)),
                          ("c1_dropin", secondary_dropin)):
             try:
                 res["secondary"][name] = fn()
