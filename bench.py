@@ -757,12 +757,13 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
         calibrate_batch(kf, maxiter=2)  # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = calibrate_batch(kf, maxiter=maxiter, fd_below=4096)   # (differenced gradients for the last stragglers, as scripts/bench_calibrate.py)
+        fd_below = 4096 if N + K <= 16 else 2048   # (differenced gradients for the last stragglers: one round of wavefronts)
+        res = calibrate_batch(kf, maxiter=maxiter, fd_below=fd_below)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         true_obj = kf.loglik(d["phi"], d["q"])
         return {"workload": "calibrate_batch: %d x (%d series, %d factors), T=%d, %d %% missing, fp64, adjoint gradient (forward differences once "
-                            "%d x active models <= 4096), the L-BFGS step on the device (mk_lbfgs.hip)" % (B, N, K, T, round(100 * missing), N + K + 1),
+                            "%d x active models <= %d), the L-BFGS step on the device (mk_lbfgs.hip)" % (B, N, K, T, round(100 * missing), N + K + 1, fd_below),
                 "seconds": dt, "models_per_s": B / dt, "iterations": int(res.nit), "objective_evaluations": int(res.nfev),
                 "launches": int(res.launches),
                 "converged_frac": float(res.converged.double().mean()),

@@ -253,30 +253,37 @@ MK_API int mk_smooth_dense(mk_context *ctx, int64_t B, int64_t T, int64_t n, con
 
 /* ---- lock-step L-BFGS of the batched calibration (mk_lbfgs.hip) ----------------------------------
  * What ScipySolve.solve leaves to scipy's L-BFGS-B for ONE model (metran/solver.py:222-305: bounds alpha >= pmin, m history pairs,
- * pgtol on the projected gradient, ftol on the relative reduction) for R models in lock-step, one thread per model.  Arrays are
- * [R,n] row-major doubles (the history ring d_Sh / d_Yh [ring_slots,R,n], d_rho [ring_slots,R]; `len` live pairs starting at slot
- * `pos`, ring_slots = m + 1: the slot after the newest pair receives the tentative one), masks are bytes.  A host pointer h_*, if
- * given, receives the kernel's count after a stream synchronisation (NULL: asynchronous).
+ * pgtol on the projected gradient, ftol on the relative reduction) for R models at once, one thread per model.  Arrays are [R,n]
+ * row-major doubles; every model has its own history ring d_Sh / d_Yh [history,R,n], d_rho [history,R] with d_hlen [R] live pairs
+ * starting at slot d_hpos [R] (int32); masks are bytes.  A host pointer h_*, if given, receives the kernel's count after a stream
+ * synchronisation (NULL: asynchronous).
  *   mk_lbfgs_direction  projected gradient d_pg, d_active &= max|pg| > gtol, two-loop recursion, steepest descent where the
- *                       direction is not a descent direction, unit-scale first step, zero on active bounds -> d_d; #active
+ *                       direction is not a descent direction, unit-scale first step, zero on active bounds -> d_d; #active.
+ *                       With d_phase / d_step / d_nback (own line search per model): a model with phase 1 keeps direction and step,
+ *                       the others start a new search (step 1, nback 0, phase 1)
  *   mk_lbfgs_trial      d_xt = max(x + step d, lo); d_xe = searching ? xt : x_new
  *   mk_lbfgs_armijo     searching models: accept (x_new, f_new <- xt, ft) if ft <= f + 1e-4 pg.(xt - x) and ft finite, else
- *                       step *= clamp(parabola minimiser, 0.1, 0.5); #still searching
- *   mk_lbfgs_update     pair (s, y, rho) of the accepted points into slot_new (zeros where s.y <= 1e-10 y.y), (x, f, g) <- new
- *                       (models still searching keep their old gradient if asked), d_active &= !searching & relative
- *                       reduction > ftol; #good pairs (the caller keeps the slot only if > 0) */
-MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t ring_slots, int64_t len, int64_t pos, const double *d_x,
-                              const double *d_g, const double *d_lo, uint8_t *d_active, const double *d_Sh, const double *d_Yh,
-                              const double *d_rho, double gtol, double *d_pg, double *d_d, int *h_nactive);
+ *                       step *= clamp(parabola minimiser, 0.1, 0.5); #still searching.  Lock-step form (d_nback NULL): an
+ *                       accepted model leaves d_searching.  Own-line-search form: d_accepted marks the accepted models (they stay
+ *                       in d_searching = the active mask), a model that has used max_backtracks trial points leaves it; #accepted
+ *   mk_lbfgs_update     for the models of d_mask (NULL: all): pair (s, y, rho) of the accepted point into the model's ring if
+ *                       s.y > 1e-10 y.y (skipped otherwise, as scipy does), (x, f, g) <- new (lock-step form: models still in
+ *                       d_searching keep their old gradient if asked and leave d_active), d_active &= relative reduction > ftol,
+ *                       phase <- 0; #usable pairs */
+MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t history, const double *d_x, const double *d_g, const double *d_lo,
+                              uint8_t *d_active, const double *d_Sh, const double *d_Yh, const double *d_rho, const int *d_hlen,
+                              const int *d_hpos, double gtol, double *d_pg, double *d_d, uint8_t *d_phase, double *d_step, int *d_nback,
+                              int *h_nactive);
 MK_API int mk_lbfgs_trial(mk_context *ctx, int64_t R, int64_t n, const double *d_x, const double *d_d, const double *d_step,
                           const double *d_lo, const uint8_t *d_searching, const double *d_x_new, double *d_xt, double *d_xe);
 MK_API int mk_lbfgs_armijo(mk_context *ctx, int64_t R, int64_t n, const double *d_ft, const double *d_f, const double *d_pg,
                            const double *d_xt, const double *d_x, uint8_t *d_searching, double *d_step, double *d_x_new,
-                           double *d_f_new, int *h_nsearching);
-MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t ring_slots, int64_t slot_new, double *d_x, double *d_f,
-                           double *d_g, const double *d_x_new, const double *d_f_new, const double *d_g_new,
-                           int keep_old_gradient_if_searching, const uint8_t *d_searching, uint8_t *d_active, double ftol,
-                           double *d_Sh, double *d_Yh, double *d_rho, int *h_ngood);
+                           double *d_f_new, int *d_nback, int64_t max_backtracks, uint8_t *d_accepted, int *h_nsearching,
+                           int *h_naccepted);
+MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t history, double *d_x, double *d_f, double *d_g,
+                           const double *d_x_new, const double *d_f_new, const double *d_g_new, int keep_old_gradient_if_searching,
+                           const uint8_t *d_searching, const uint8_t *d_mask, uint8_t *d_active, double ftol, double *d_Sh,
+                           double *d_Yh, double *d_rho, int *d_hlen, int *d_hpos, uint8_t *d_phase, int *h_ngood);
 
 /* seqkalmanfilter + get_mle for B instances (kalmanfilter.py:236-400, 550-567).
  * Uses d_mle, d_sigmas, d_detfs, d_sigmacount, d_F, d_Pf, d_Xp, d_Pp, d_status of `out`. */

@@ -111,13 +111,14 @@ API = {
     "mk_loglik_grad": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_loglik_grad_phases": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int]),
-    "mk_lbfgs_direction": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_double, c_void_p, c_void_p, POINTER(c_int)]),
+    "mk_lbfgs_direction": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "mk_lbfgs_trial": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_lbfgs_armijo": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_void_p, POINTER(c_int)]),
-    "mk_lbfgs_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
+                                c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "mk_lbfgs_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                POINTER(c_int)]),
     "mk_alpha_grad": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double, c_void_p,
                               c_void_p, c_void_p]),
     "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

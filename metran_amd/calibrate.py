@@ -31,7 +31,7 @@ class CalibrationResult(dict):
 
 def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, history=10, eps=1e-8,
                     ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto",
-                    stderr=False, compact=0.5, compact_min=256, fd_below=0, launch_budget=None):
+                    stderr=False, compact=0.5, compact_min=256, fd_below=0, launch_budget=None, own_search_above=None):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
@@ -50,8 +50,19 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     ``fd_below`` instances (0 = never).  A handful of stragglers is latency-bound: one objective launch over (n+1) R
     instances takes as long as one over R, the forward + backward pair of the adjoint 4-5 times as long; the price is
     the differencing error in the last iterations (what scipy's L-BFGS-B works with throughout).
+    ``own_search_above``: with the adjoint gradient and MORE than this many models in flight every model runs its own line search
+    across iterations (one forward + at most one backward launch per iteration; a model either takes a new direction or its next
+    shorter step) instead of the lock-step search, whose every back-tracking round is a launch over the whole flight that only a
+    few models need.  Each model's sequence of trial points is the same either way.  Below the threshold a launch is
+    latency-bound whatever its size, back-tracking rounds are cheap and backward passes are not (2.5 x a forward pass): lock-step.
+    Default (measured, profiles/r05/ab_line_search.log): 2048 for models of at most 16 states, 0 -- always -- for wider ones,
+    whose stragglers rarely back-track, so that their own search costs them no iterations while the lock-step one pays a
+    back-tracking round of somebody's in most iterations.
+    ``compact_min`` holds while the adjoint gradient is in use (a launch of fewer models than wavefront slots is latency-bound: a
+    smaller flight is no faster).  It does not stop the compaction that brings the flight under ``fd_below``, nor those after it
+    that let at least four step lengths of every model ride in one launch.
     ``launch_budget``: instances one latency-bound objective launch may carry (default: two wavefronts per SIMD of an MI355X --
-    8192 instances of the 16-lane kernels, four models per wavefront, 4096 of the wide ones: 1.3 x the time of a single round).  With differenced gradients, a flight whose (n+1) R instances fit gets the
+    8192 instances of the 16-lane kernels, four models per wavefront; 2048 of the wide ones, one model per wavefront: measured, 4096 wide instances take 14 ms where 512 take 5.5).  With differenced gradients, a flight whose (n+1) R instances fit gets the
     gradient of every trial with the trial, and as many step lengths per searching model at once as fit (up to the whole
     back-tracking budget): a straggler that exhausts its budget then costs ONE launch instead of a dozen.
     """
@@ -60,7 +71,9 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     R, n = kf.R, kf.n
     dev = kf.device
     if launch_budget is None:
-        launch_budget = 8192 if n <= 16 else 4096
+        launch_budget = 8192 if n <= 16 else 2048
+    if own_search_above is None:
+        own_search_above = 2048 if n <= 16 else 0
     f64 = dict(dtype=torch.float64, device=dev)
     x = torch.full((R, n), float(alpha0), **f64) if np.isscalar(alpha0) else kf._dev(alpha0, (R, n), "alpha0").clone()
     lo = torch.full((R, n), float(pmin), **f64) if np.isscalar(pmin) else kf._dev(pmin, (R, n), "pmin")
@@ -121,35 +134,69 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
 
     f, g = value_and_grad(x)
     f, g = f.contiguous(), g.contiguous()
-    # L-BFGS history: a ring of history + 1 slots [slot, R, n] -- `hist_len` live pairs, the oldest in slot `hist_pos`; the slot
-    # behind the newest receives the tentative pair of an iteration (kept only if some model's pair is usable)
-    H1 = history + 1
-    Sh = torch.zeros((H1, R, n), **f64)
-    Yh = torch.zeros((H1, R, n), **f64)
-    rho = torch.zeros((H1, R), **f64)
-    hist_len = hist_pos = 0
+    # L-BFGS history: every model has its own ring of `history` pairs [slot, R, n] (hlen live pairs from slot hpos): with the
+    # adjoint gradient every model runs its OWN line search (below), so models take their steps in different iterations
+    Sh = torch.zeros((history, R, n), **f64)
+    Yh = torch.zeros((history, R, n), **f64)
+    rho = torch.zeros((history, R), **f64)
+    hlen = torch.zeros(R, dtype=torch.int32, device=dev)
+    hpos = torch.zeros(R, dtype=torch.int32, device=dev)
     active = torch.ones(R, dtype=torch.bool, device=dev)
-    pg, d = torch.empty_like(x), torch.empty_like(x)
+    phase = torch.zeros(R, dtype=torch.uint8, device=dev)   # 1: in the middle of its line search
+    nback = torch.zeros(R, dtype=torch.int32, device=dev)
+    accepted = torch.zeros(R, dtype=torch.bool, device=dev)
+    step = torch.ones(R, **f64)
+    pg, d = torch.zeros_like(x), torch.zeros_like(x)
     xt, xe = torch.empty_like(x), torch.empty_like(x)
+    x_new, f_new = x.clone(), f.clone()
     nit = 0
     for nit in range(1, maxiter + 1):
         # projected gradient, convergence test on it, two-loop recursion with its safeguards: ONE launch (mk_lbfgs.hip; one
-        # thread per model) and one host synchronisation for the count
-        n_act = kf.lbfgs_direction(x, g, lo, active, Sh, Yh, rho, hist_len, hist_pos, gtol, pg, d)
+        # thread per model) and one host synchronisation for the count.  A model in the middle of its line search (adjoint mode)
+        # keeps its direction and its shortened step.
+        own = grad_mode == "adjoint" and R > own_search_above
+        n_act = kf.lbfgs_direction(x, g, lo, active, Sh, Yh, rho, hlen, hpos, gtol, pg, d, phase if own else None,
+                                   step if own else None, nback if own else None)
         if n_act == 0:
             break
-        if compact and R > compact_min and n_act < compact * R:
+        to_fd = grad_mode == "adjoint" and fd_below and (n + 1) * n_act <= fd_below < (n + 1) * R
+        more_trials = grad_mode == "fd" and launch_budget // ((n + 1) * R) < 4
+        if compact and n_act < compact * R and (R > compact_min or to_fd or more_trials):
             X_all[orig], F_all[orig], G_all[orig] = x, f, g      # everybody's current state; the inactive ones are final
             keep = active.nonzero().squeeze(1)
             kf = kf.subset(keep)
-            x, f, g, lo, pg, d, orig = (t[keep].contiguous() for t in (x, f, g, lo, pg, d, orig))
+            x, f, g, lo, pg, d, orig, hlen, hpos, phase, nback, step, x_new, f_new = (
+                t[keep].contiguous() for t in (x, f, g, lo, pg, d, orig, hlen, hpos, phase, nback, step, x_new, f_new))
             Sh, Yh, rho = Sh[:, keep].contiguous(), Yh[:, keep].contiguous(), rho[:, keep].contiguous()
             R = n_act
             active = torch.ones(R, dtype=torch.bool, device=dev)
+            accepted = torch.zeros(R, dtype=torch.bool, device=dev)
             xt, xe = torch.empty_like(x), torch.empty_like(x)
         if grad_mode == "adjoint" and fd_below and (n + 1) * R <= fd_below:
             grad_mode = "fd"
-        # Armijo back-tracking on the projected path, one trial per searching model per launch
+        if own and not (grad_mode == "adjoint" and R > own_search_above):
+            # the flight has shrunk below the threshold (or switched to differences): lock-step from here on.  A model in the
+            # middle of its line search restarts it at the unit step -- same direction, same trial points.
+            own = False
+            phase.zero_()
+        if own:
+            # ---- adjoint gradient: every model runs its OWN line search across iterations.  An iteration is ONE recording forward
+            # launch -- each active model at its own trial point, a fresh unit step or the next shorter one -- and, if any trial was
+            # accepted, ONE backward launch for the gradients there.  (Round 4 ran the line search in lock-step: with thousands of
+            # models in flight some model backtracks in most iterations, and every back-tracking round was a launch over the
+            # whole flight that only those few needed.)  A model's own sequence of trial points is what it was.
+            kf.lbfgs_trial(x, d, step, lo, active, x, xt, xe)
+            ft = value(xe)
+            n_search, n_acc = kf.lbfgs_armijo(ft.contiguous(), f, pg, xt, x, active, step, x_new, f_new, nback, max_backtracks, accepted)
+            if n_acc > 0:
+                launches += 1
+                g_cand = kf.loglik_backward_alpha()
+                kf.lbfgs_update(x, f, g, x_new, f_new, g_cand.contiguous(), False, None, active, ftol, Sh, Yh, rho, hlen, hpos, accepted, phase)
+            if verbose:
+                print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
+            continue
+        # ---- lock-step Armijo back-tracking, one trial per searching model per launch (differenced gradients; the adjoint
+        # gradient on a flight of at most `own_search_above` models)
         step = torch.ones(R, **f64)
         searching = active.clone()
         x_new, f_new = x.clone(), f.clone()
@@ -207,7 +254,7 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
                 ft = value(xe)
             # next trial of a rejected model: the minimiser of the parabola through f, its slope and the rejected value, kept
             # inside [0.1, 0.5] of the rejected step (plain halving needs log2 of the ratio in launches, and every launch costs
-            # the whole flight: with thousands of models in lock-step some model needs 1/64 in most iterations)
+            # the whole flight)
             n_search = kf.lbfgs_armijo(ft.contiguous(), f, pg, xt, x, searching, step, x_new, f_new)
             if speculate:
                 g_acc = torch.where((before & ~searching)[:, None], gt, g_acc)
@@ -223,16 +270,10 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         else:
             f_tmp, g_cand = value_and_grad(x_new)
             keep_old = False
-        # the pair (s, y) of this step into the ring, (x, f, g) <- the accepted point, scipy's relative-reduction test
-        # (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol: ONE launch (mk_lbfgs_update)
-        slot_new = (hist_pos + hist_len) % H1
-        n_good = kf.lbfgs_update(x, f, g, x_new.contiguous(), f_tmp.contiguous(), g_cand.contiguous(), keep_old, searching, active, ftol,
-                                 Sh, Yh, rho, slot_new)
-        if n_good > 0:
-            if hist_len < history:
-                hist_len += 1
-            else:
-                hist_pos = (hist_pos + 1) % H1
+        # the pair (s, y) of this step into every model's ring (skipped where it is not usable, as scipy does), (x, f, g) <- the
+        # accepted point, scipy's relative-reduction test (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol: ONE launch
+        kf.lbfgs_update(x, f, g, x_new.contiguous(), f_tmp.contiguous(), g_cand.contiguous(), keep_old, searching, active, ftol,
+                        Sh, Yh, rho, hlen, hpos)
         if verbose:
             print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
     X_all[orig], F_all[orig], G_all[orig], active_all[orig] = x, f, g, active

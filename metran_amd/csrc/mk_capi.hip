@@ -867,21 +867,19 @@ static int lbfgs_run(mk_context *ctx, int which, mk::LbfgsArgs &a, int counter, 
     return MK_OK;
 }
 
-MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t ring_slots, int64_t len, int64_t pos, const double *d_x,
-                              const double *d_g, const double *d_lo, uint8_t *d_active, const double *d_Sh, const double *d_Yh,
-                              const double *d_rho, double gtol, double *d_pg, double *d_d, int *h_nactive)
+MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t history, const double *d_x, const double *d_g, const double *d_lo,
+                              uint8_t *d_active, const double *d_Sh, const double *d_Yh, const double *d_rho, const int *d_hlen,
+                              const int *d_hpos, double gtol, double *d_pg, double *d_d, uint8_t *d_phase, double *d_step, int *d_nback,
+                              int *h_nactive)
 {
     MK_CTX(ctx);
-    if (!d_x || !d_g || !d_lo || !d_active || !d_pg || !d_d || (len > 0 && (!d_Sh || !d_Yh || !d_rho)) || len < 0 || len >= ring_slots ||
-        pos < 0 || pos >= ring_slots)
-        return fail(MK_ERR_INVALID, "mk_lbfgs_direction: bad argument");
+    if (!d_x || !d_g || !d_lo || !d_active || !d_pg || !d_d || !d_Sh || !d_Yh || !d_rho || !d_hlen || !d_hpos)
+        return fail(MK_ERR_INVALID, "mk_lbfgs_direction: null pointer");
     mk::LbfgsArgs a;
     memset(&a, 0, sizeof(a));
     a.R = R;
     a.n = (int)n;
-    a.H = (int)ring_slots;
-    a.len = (int)len;
-    a.pos = (int)pos;
+    a.H = (int)history;
     a.gtol = gtol;
     a.x = const_cast<double *>(d_x);
     a.g = const_cast<double *>(d_g);
@@ -890,8 +888,13 @@ MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t rin
     a.Sh = const_cast<double *>(d_Sh);
     a.Yh = const_cast<double *>(d_Yh);
     a.rho = const_cast<double *>(d_rho);
+    a.hlen = const_cast<int *>(d_hlen);
+    a.hpos = const_cast<int *>(d_hpos);
     a.pg = d_pg;
     a.d = d_d;
+    a.phase = d_phase;
+    a.step = d_step;
+    a.nback = d_nback;
     return lbfgs_run(ctx, 0, a, 0, h_nactive);
 }
 
@@ -917,10 +920,11 @@ MK_API int mk_lbfgs_trial(mk_context *ctx, int64_t R, int64_t n, const double *d
 }
 
 MK_API int mk_lbfgs_armijo(mk_context *ctx, int64_t R, int64_t n, const double *d_ft, const double *d_f, const double *d_pg, const double *d_xt,
-                           const double *d_x, uint8_t *d_searching, double *d_step, double *d_x_new, double *d_f_new, int *h_nsearching)
+                           const double *d_x, uint8_t *d_searching, double *d_step, double *d_x_new, double *d_f_new, int *d_nback,
+                           int64_t max_backtracks, uint8_t *d_accepted, int *h_nsearching, int *h_naccepted)
 {
     MK_CTX(ctx);
-    if (!d_ft || !d_f || !d_pg || !d_xt || !d_x || !d_searching || !d_step || !d_x_new || !d_f_new)
+    if (!d_ft || !d_f || !d_pg || !d_xt || !d_x || !d_searching || !d_step || !d_x_new || !d_f_new || (d_nback && !d_accepted))
         return fail(MK_ERR_INVALID, "mk_lbfgs_armijo: null pointer");
     mk::LbfgsArgs a;
     memset(&a, 0, sizeof(a));
@@ -936,23 +940,36 @@ MK_API int mk_lbfgs_armijo(mk_context *ctx, int64_t R, int64_t n, const double *
     a.step = d_step;
     a.x_new = d_x_new;
     a.f_new = d_f_new;
-    return lbfgs_run(ctx, 2, a, 1, h_nsearching);
+    a.nback = d_nback;
+    a.max_backtracks = (int)max_backtracks;
+    a.mask = d_accepted;
+    if (!ctx->lb_counters) MK_HIP(hipMalloc((void **)&ctx->lb_counters, 4 * sizeof(int)));
+    MK_HIP(hipMemsetAsync(ctx->lb_counters + 3, 0, sizeof(int), ctx->stream));
+    if (int rc = lbfgs_run(ctx, 2, a, 1, h_naccepted ? nullptr : h_nsearching)) return rc;
+    if (h_naccepted) { // both counts with one synchronisation
+        int two[4];
+        MK_HIP(hipMemcpyAsync(two, ctx->lb_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MK_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_nsearching) *h_nsearching = two[1];
+        *h_naccepted = two[3];
+    }
+    return MK_OK;
 }
 
-MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t ring_slots, int64_t slot_new, double *d_x, double *d_f, double *d_g,
-                           const double *d_x_new, const double *d_f_new, const double *d_g_new, int keep_old_gradient_if_searching,
-                           const uint8_t *d_searching, uint8_t *d_active, double ftol, double *d_Sh, double *d_Yh, double *d_rho, int *h_ngood)
+MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t history, double *d_x, double *d_f, double *d_g, const double *d_x_new,
+                           const double *d_f_new, const double *d_g_new, int keep_old_gradient_if_searching, const uint8_t *d_searching,
+                           const uint8_t *d_mask, uint8_t *d_active, double ftol, double *d_Sh, double *d_Yh, double *d_rho, int *d_hlen,
+                           int *d_hpos, uint8_t *d_phase, int *h_ngood)
 {
     MK_CTX(ctx);
-    if (!d_x || !d_f || !d_g || !d_x_new || !d_f_new || !d_g_new || !d_searching || !d_active || !d_Sh || !d_Yh || !d_rho || slot_new < 0 ||
-        slot_new >= ring_slots)
-        return fail(MK_ERR_INVALID, "mk_lbfgs_update: bad argument");
+    if (!d_x || !d_f || !d_g || !d_x_new || !d_f_new || !d_g_new || !(d_searching || d_mask) || !d_active || !d_Sh || !d_Yh || !d_rho || !d_hlen ||
+        !d_hpos)
+        return fail(MK_ERR_INVALID, "mk_lbfgs_update: null pointer");
     mk::LbfgsArgs a;
     memset(&a, 0, sizeof(a));
     a.R = R;
     a.n = (int)n;
-    a.H = (int)ring_slots;
-    a.slot_new = (int)slot_new;
+    a.H = (int)history;
     a.keep_old = keep_old_gradient_if_searching;
     a.ftol = ftol;
     a.x = d_x;
@@ -962,10 +979,14 @@ MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t ring_s
     a.f_new = const_cast<double *>(d_f_new);
     a.g_new = d_g_new;
     a.searching = const_cast<uint8_t *>(d_searching);
+    a.mask = const_cast<uint8_t *>(d_mask);
     a.active = d_active;
     a.Sh = d_Sh;
     a.Yh = d_Yh;
     a.rho = d_rho;
+    a.hlen = d_hlen;
+    a.hpos = d_hpos;
+    a.phase = d_phase;
     return lbfgs_run(ctx, 3, a, 2, h_ngood);
 }
 

@@ -3,15 +3,19 @@
 #include <hip/hip_runtime.h>
 
 #define MK_LBFGS_MAX_N 64  /* parameters per model (= states: one alpha per state) */
-#define MK_LBFGS_MAX_H 17  /* ring slots: at most 16 live pairs + the tentative one */
+#define MK_LBFGS_MAX_H 16  /* history pairs per model (ring slots) */
 
 namespace mk {
 
 struct LbfgsArgs {
     long R;                 // models
-    int n, H, len, pos;     // parameters per model; ring slots; live pairs; slot of the oldest live pair
-    int slot_new;           // update: slot the tentative pair is written to
+    int n, H;               // parameters per model; ring slots (= history pairs kept)
     int keep_old;           // update: models that found no step keep their old gradient (adjoint mode: g_new is only valid elsewhere)
+    int max_backtracks;     // armijo (own line search per model): trial points a model may use before it is declared done
+    int *hlen, *hpos;       // [R] live pairs of every model's ring and the slot of its oldest one
+    unsigned char *phase;   // [R] 0: takes a new direction at the next mk_lbfgs_direction, 1: in the middle of its line search
+    int *nback;             // [R] trial points used in the current line search
+    unsigned char *mask;    // update: models to update [R] (NULL = all); armijo: receives the accepted models
     double gtol, ftol;
     double *x, *g, *f;      // current point [R,n], gradient [R,n], objective [R]
     const double *lo;       // lower bounds [R,n]

@@ -5,11 +5,14 @@
 // points, Armijo test and history update were ~130 separate torch operations and three to five host synchronisations per
 // iteration -- at 8192 models two thirds of the wall time of a calibration whose filter / adjoint kernels take 0.3 s
 // (scripts/probe.py calibrate --trace).  Here every model is ONE thread and an iteration is four launches:
-//     lbfgs_direction_kernel   projected gradient, convergence test on it, two-loop recursion over the history ring, descent
-//                              and bound safeguards                                   -> pg, d, active, #active
+//     lbfgs_direction_kernel   projected gradient, convergence test on it, two-loop recursion over the model's history ring,
+//                              descent and bound safeguards (models in the middle of a line search keep theirs) -> pg, d, #active
 //     lbfgs_trial_kernel       x + step d projected on the bounds; settled models stay at their accepted point   -> xt, xe
 //     lbfgs_armijo_kernel      sufficient-decrease test, acceptance, next step length from the parabola         -> #searching
-//     lbfgs_update_kernel      the new (s, y, rho) pair into the ring, (x, f, g) <- accepted point, scipy's relative-reduction test
+//                              (own-line-search form: back-tracking budget per model, accepted mask             -> #accepted)
+//     lbfgs_update_kernel      the new (s, y, rho) pair into the model's ring if it is usable (scipy skips it otherwise),
+//                              (x, f, g) <- accepted point, scipy's relative-reduction test
+// Every model has its OWN ring (hlen, hpos): models accept steps in different iterations when each runs its own line search.
 // The arithmetic is that of the torch code it replaces (tests/oracle_engine.py keeps it as the restatement the CPU tests and
 // tests/test_lbfgs_gpu.py compare with), sums taken in index order.  All arrays are [R, n] row-major (the ring [H, R, n]); masks
 // are bytes; n <= MK_LBFGS_MAX_N.
@@ -27,7 +30,12 @@ __global__ void __launch_bounds__(TPB) lbfgs_direction_kernel(LbfgsArgs a)
 {
     const long r = (long)blockIdx.x * TPB + threadIdx.x;
     if (r >= a.R) return;
-    const int n = a.n, H = a.H, len = a.len;
+    const int n = a.n, H = a.H;
+    if (a.phase && a.phase[r] && a.active[r]) { // in the middle of its line search: direction, slope and step stay
+        atomicAdd(a.counters + 0, 1);
+        return;
+    }
+    const int len = a.hlen[r], pos = a.hpos[r];
     const double *x = a.x + r * n, *g = a.g + r * n, *lo = a.lo + r * n;
     double *pg = a.pg + r * n, *d = a.d + r * n;
     double q[MK_LBFGS_MAX_N], al[MK_LBFGS_MAX_H];
@@ -48,9 +56,12 @@ __global__ void __launch_bounds__(TPB) lbfgs_direction_kernel(LbfgsArgs a)
         return;
     }
     atomicAdd(a.counters + 0, 1);
+    if (a.step) a.step[r] = 1.0;  // a new line search starts at the unit step
+    if (a.nback) a.nback[r] = 0;
+    if (a.phase) a.phase[r] = 1;
     // two-loop recursion; pair i = 0 is the NEWEST: slot (pos + len - 1 - i) mod H
     for (int i = 0; i < len; ++i) {
-        const int slot = (a.pos + len - 1 - i) % H;
+        const int slot = (pos + len - 1 - i) % H;
         const double *s = a.Sh + ((long)slot * a.R + r) * n, *y = a.Yh + ((long)slot * a.R + r) * n;
         double dot = 0.0;
         for (int c = 0; c < n; ++c) dot += s[c] * q[c];
@@ -59,7 +70,7 @@ __global__ void __launch_bounds__(TPB) lbfgs_direction_kernel(LbfgsArgs a)
         for (int c = 0; c < n; ++c) q[c] -= ai * y[c];
     }
     if (len > 0) {
-        const int slot = (a.pos + len - 1) % H;
+        const int slot = (pos + len - 1) % H;
         const double *s = a.Sh + ((long)slot * a.R + r) * n, *y = a.Yh + ((long)slot * a.R + r) * n;
         double sy = 0.0, yy = 0.0;
         for (int c = 0; c < n; ++c) {
@@ -70,7 +81,7 @@ __global__ void __launch_bounds__(TPB) lbfgs_direction_kernel(LbfgsArgs a)
         for (int c = 0; c < n; ++c) q[c] *= gamma;
     }
     for (int i = len - 1; i >= 0; --i) { // oldest first
-        const int slot = (a.pos + len - 1 - i) % H;
+        const int slot = (pos + len - 1 - i) % H;
         const double *s = a.Sh + ((long)slot * a.R + r) * n, *y = a.Yh + ((long)slot * a.R + r) * n;
         double dot = 0.0;
         for (int c = 0; c < n; ++c) dot += y[c] * q[c];
@@ -104,18 +115,31 @@ __global__ void __launch_bounds__(TPB) lbfgs_armijo_kernel(LbfgsArgs a)
 {
     const long r = (long)blockIdx.x * TPB + threadIdx.x;
     if (r >= a.R) return;
-    if (!a.searching[r]) return;
+    if (!a.searching[r]) {
+        if (a.mask) a.mask[r] = 0;
+        return;
+    }
     const int n = a.n;
     double gd = 0.0; // directional derivative along the trial displacement (< 0)
     for (int c = 0; c < n; ++c) gd += a.pg[r * n + c] * (a.xt[r * n + c] - a.x[r * n + c]);
     const double ft = a.ft[r], f = a.f[r];
     const bool fin = isfinite(ft);
     const bool ok = fin && (ft <= f + 1e-4 * gd);
+    if (a.mask) a.mask[r] = ok ? 1 : 0;
     if (ok) {
         for (int c = 0; c < n; ++c) a.x_new[r * n + c] = a.xt[r * n + c];
         a.f_new[r] = ft;
-        a.searching[r] = 0;
+        if (a.nback) atomicAdd(a.counters + 3, 1); // own line search: the model stays in the flight, its step is taken by the update
+        else a.searching[r] = 0;
         return;
+    }
+    if (a.nback) { // own line search: the budget of trial points is per model; beyond it the model is done (at numerical precision)
+        const int nb = a.nback[r] + 1;
+        a.nback[r] = nb;
+        if (nb >= a.max_backtracks) {
+            a.searching[r] = 0;
+            return;
+        }
     }
     atomicAdd(a.counters + 1, 1);
     // next trial: the minimiser of the parabola through f, its slope and the rejected value, kept inside [0.1, 0.5] of the step
@@ -129,25 +153,30 @@ __global__ void __launch_bounds__(TPB) lbfgs_update_kernel(LbfgsArgs a)
 {
     const long r = (long)blockIdx.x * TPB + threadIdx.x;
     if (r >= a.R) return;
-    const int n = a.n;
-    const bool srch = a.searching[r] != 0; // no acceptable step: this model is done, and keeps its old gradient
-    double *s = a.Sh + ((long)a.slot_new * a.R + r) * n, *y = a.Yh + ((long)a.slot_new * a.R + r) * n;
+    if (a.mask && !a.mask[r]) return; // own line search: only the models whose trial was accepted take their step now
+    const int n = a.n, H = a.H;
+    const bool srch = a.searching && !a.mask && a.searching[r] != 0; // lock-step form: no acceptable step -- done, old gradient kept
+    const int len = a.hlen[r], pos = a.hpos[r];
+    const int slot = (pos + len) % H; // behind the newest pair; with a full ring that is the oldest one, which the new pair replaces
     double sy = 0.0, yy = 0.0;
     for (int c = 0; c < n; ++c) {
         const double gn = (a.keep_old && srch) ? a.g[r * n + c] : a.g_new[r * n + c];
         const double sc = a.x_new[r * n + c] - a.x[r * n + c], yc = gn - a.g[r * n + c];
-        s[c] = sc;
-        y[c] = yc;
         sy += sc * yc;
         yy += yc * yc;
     }
-    const bool good = sy > 1e-10 * fmax(yy, 1e-300);
+    const bool good = sy > 1e-10 * fmax(yy, 1e-300); // (scipy's L-BFGS-B skips the update otherwise)
     if (good) {
-        a.rho[(long)a.slot_new * a.R + r] = 1.0 / fmax(sy, 1e-300);
+        double *s = a.Sh + ((long)slot * a.R + r) * n, *y = a.Yh + ((long)slot * a.R + r) * n;
+        for (int c = 0; c < n; ++c) {
+            const double gn = (a.keep_old && srch) ? a.g[r * n + c] : a.g_new[r * n + c];
+            s[c] = a.x_new[r * n + c] - a.x[r * n + c];
+            y[c] = gn - a.g[r * n + c];
+        }
+        a.rho[(long)slot * a.R + r] = 1.0 / fmax(sy, 1e-300);
+        if (len < H) a.hlen[r] = len + 1;
+        else a.hpos[r] = (pos + 1) % H;
         atomicAdd(a.counters + 2, 1);
-    } else {
-        a.rho[(long)a.slot_new * a.R + r] = 0.0;
-        for (int c = 0; c < n; ++c) s[c] = y[c] = 0.0;
     }
     const double f_prev = a.f[r], f_now = a.f_new[r];
     for (int c = 0; c < n; ++c) {
@@ -156,6 +185,7 @@ __global__ void __launch_bounds__(TPB) lbfgs_update_kernel(LbfgsArgs a)
         a.g[r * n + c] = gn;
     }
     a.f[r] = f_now;
+    if (a.phase) a.phase[r] = 0; // the next direction call gives this model a new one
     // scipy's relative-reduction test: (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol stops the model
     const double rel = (f_prev - f_now) / fmax(fmax(fabs(f_prev), fabs(f_now)), 1.0);
     const bool act = a.active[r] && !srch && (rel > a.ftol);

@@ -787,15 +787,17 @@ class BatchedKalman:
         return out[0]
 
     # ------------------------------------------------------------------ lock-step L-BFGS (calibrate_batch; mk_lbfgs.hip)
-    def lbfgs_direction(self, x, g, lo, active, Sh, Yh, rho, hist_len, hist_pos, gtol, pg, d):
-        """Projected gradient into ``pg``, ``active &= max|pg| > gtol``, the two-loop recursion over the ``hist_len`` live pairs of
-        the history ring (oldest in slot ``hist_pos``) with its safeguards into ``d``.  Returns the number of active models."""
+    def lbfgs_direction(self, x, g, lo, active, Sh, Yh, rho, hlen, hpos, gtol, pg, d, phase=None, step=None, nback=None):
+        """Projected gradient into ``pg``, ``active &= max|pg| > gtol``, the two-loop recursion over every model's own history
+        ring (``hlen`` live pairs from slot ``hpos``) with its safeguards into ``d``.  With ``phase / step / nback`` (own line
+        search per model) a model in the middle of its search keeps direction and step, the others start a new one.  Returns the
+        number of active models."""
         R, n = (int(v) for v in x.shape)
         cnt = ctypes.c_int(0)
         self._bind_stream()
-        check(self._L.mk_lbfgs_direction(self._ctx, R, n, int(Sh.shape[0]), int(hist_len), int(hist_pos), self._p(x), self._p(g), self._p(lo),
-                                         self._p(active), self._p(Sh), self._p(Yh), self._p(rho), float(gtol), self._p(pg), self._p(d),
-                                         ctypes.byref(cnt)))
+        check(self._L.mk_lbfgs_direction(self._ctx, R, n, int(Sh.shape[0]), self._p(x), self._p(g), self._p(lo), self._p(active), self._p(Sh),
+                                         self._p(Yh), self._p(rho), self._p(hlen), self._p(hpos), float(gtol), self._p(pg), self._p(d),
+                                         self._p(phase), self._p(step), self._p(nback), ctypes.byref(cnt)))
         return int(cnt.value)
 
     def lbfgs_trial(self, x, d, step, lo, searching, x_new, xt, xe):
@@ -805,26 +807,30 @@ class BatchedKalman:
         check(self._L.mk_lbfgs_trial(self._ctx, R, n, self._p(x), self._p(d), self._p(step), self._p(lo), self._p(searching), self._p(x_new),
                                      self._p(xt), self._p(xe)))
 
-    def lbfgs_armijo(self, ft, f, pg, xt, x, searching, step, x_new, f_new):
-        """Armijo test of the searching models at their trial points (in place: ``x_new, f_new, searching, step``).  Returns the
-        number of models still searching."""
+    def lbfgs_armijo(self, ft, f, pg, xt, x, searching, step, x_new, f_new, nback=None, max_backtracks=0, accepted=None):
+        """Armijo test of the searching models at their trial points (in place: ``x_new, f_new, searching, step``).  Lock-step form:
+        returns the number of models still searching.  Own-line-search form (``nback``, ``accepted`` given): an accepted model is
+        marked in ``accepted`` and stays in ``searching`` (the active mask), a model out of trial points leaves it; returns
+        ``(still searching, accepted)``."""
         R, n = (int(v) for v in x.shape)
-        cnt = ctypes.c_int(0)
+        ns, na = ctypes.c_int(0), ctypes.c_int(0)
         self._bind_stream()
+        own = nback is not None
         check(self._L.mk_lbfgs_armijo(self._ctx, R, n, self._p(ft), self._p(f), self._p(pg), self._p(xt), self._p(x), self._p(searching),
-                                      self._p(step), self._p(x_new), self._p(f_new), ctypes.byref(cnt)))
-        return int(cnt.value)
+                                      self._p(step), self._p(x_new), self._p(f_new), self._p(nback), int(max_backtracks), self._p(accepted),
+                                      ctypes.byref(ns), ctypes.byref(na) if own else None))
+        return (int(ns.value), int(na.value)) if own else int(ns.value)
 
-    def lbfgs_update(self, x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, slot_new):
-        """The pair of the accepted points into ring slot ``slot_new``, ``(x, f, g) <- (x_new, f_new, g_new)`` (models still
-        searching keep their old gradient if ``keep_old``), ``active &= ~searching & (relative reduction > ftol)``.  Returns the
-        number of models whose pair is usable (the caller keeps the slot only if that is > 0)."""
+    def lbfgs_update(self, x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, hlen, hpos, mask=None, phase=None):
+        """For the models of ``mask`` (None: all): the pair of the accepted point into the model's ring if it is usable,
+        ``(x, f, g) <- (x_new, f_new, g_new)`` (lock-step form: models still searching keep their old gradient if ``keep_old`` and
+        leave ``active``), ``active &= relative reduction > ftol``.  Returns the number of usable pairs."""
         R, n = (int(v) for v in x.shape)
         cnt = ctypes.c_int(0)
         self._bind_stream()
-        check(self._L.mk_lbfgs_update(self._ctx, R, n, int(Sh.shape[0]), int(slot_new), self._p(x), self._p(f), self._p(g), self._p(x_new),
-                                      self._p(f_new), self._p(g_new), 1 if keep_old else 0, self._p(searching), self._p(active),
-                                      float(ftol), self._p(Sh), self._p(Yh), self._p(rho), ctypes.byref(cnt)))
+        check(self._L.mk_lbfgs_update(self._ctx, R, n, int(Sh.shape[0]), self._p(x), self._p(f), self._p(g), self._p(x_new), self._p(f_new),
+                                      self._p(g_new), 1 if keep_old else 0, self._p(searching), self._p(mask), self._p(active), float(ftol),
+                                      self._p(Sh), self._p(Yh), self._p(rho), self._p(hlen), self._p(hpos), self._p(phase), ctypes.byref(cnt)))
         return int(cnt.value)
 
     # ------------------------------------------------------------------ instrumentation

@@ -101,6 +101,8 @@ def calibrate(a):
     N, K = (int(v) for v in a.shape.split(","))
     kf, d = _engine(N, K, a.T, a.batch, a.missing, "time_major", seed=5000)
     calibrate_batch(kf, maxiter=2)
+    if a.fd_below is None:
+        a.fd_below = 4096 if N + K <= 16 else 2048
     stamps, real_print = [], builtins.print
     if a.trace:  # per-iteration wall time and flight size from calibrate_batch's own verbose lines
         builtins.print = lambda *x, **k: (torch.cuda.synchronize(), stamps.append((time.perf_counter(), " ".join(str(v) for v in x))))
@@ -108,7 +110,7 @@ def calibrate(a):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     try:
-        res = calibrate_batch(kf, maxiter=200, fd_below=a.fd_below, gradient=a.gradient, verbose=a.trace)
+        res = calibrate_batch(kf, maxiter=a.maxiter, fd_below=a.fd_below, gradient=a.gradient, verbose=a.trace, own_search_above=a.own_above)
     finally:
         builtins.print = real_print
     torch.cuda.synchronize()
@@ -179,8 +181,10 @@ if __name__ == "__main__":
     p.add_argument("--batch", type=int, default=8192)
     p.add_argument("--T", type=int, default=1000)
     p.add_argument("--missing", type=float, default=0.0)
-    p.add_argument("--fd-below", type=int, default=4096)
+    p.add_argument("--fd-below", type=int, default=None, help="default: 4096 instances (models of at most 16 states), 2048 (wider)")
     p.add_argument("--gradient", default="auto")
+    p.add_argument("--maxiter", type=int, default=200)
+    p.add_argument("--own-above", type=int, default=None, help="own line search per model above this flight size")
     p.add_argument("--trace", action="store_true")
     p.set_defaults(fn=calibrate)
     sub.add_parser("dropin").set_defaults(fn=dropin)

@@ -11,37 +11,56 @@ from metran_amd.params import phi_q_from_alpha
 
 
 class TorchLbfgs:
-    """The four lock-step L-BFGS steps of ``calibrate_batch`` as plain torch operations -- the code the driver ran until round 5,
-    kept as the restatement of ``metran_amd/csrc/mk_lbfgs.hip`` (same arguments and in-place conventions as
-    ``BatchedKalman.lbfgs_*``): the CPU tier runs the driver over it, tests/test_lbfgs_gpu.py compares the kernels with it."""
+    """The L-BFGS steps of ``calibrate_batch`` as plain torch operations -- the restatement of ``metran_amd/csrc/mk_lbfgs.hip``
+    (same arguments and in-place conventions as ``BatchedKalman.lbfgs_*``; every model has its own history ring): the CPU tier
+    runs the driver over it, tests/test_lbfgs_gpu.py compares the kernels with it."""
 
     @staticmethod
-    def lbfgs_direction(x, g, lo, active, Sh, Yh, rho, hist_len, hist_pos, gtol, pg, d):
+    def _pair(Sh, Yh, rho, hlen, hpos, i):
+        """Pair i of every model counted from the NEWEST (i = 0), and whether the model has it."""
+        H, R = Sh.shape[0], Sh.shape[1]
+        slot = ((hpos + hlen - 1 - i) % H).long().clamp_min(0)
+        ar = torch.arange(R)
+        return Sh[slot, ar], Yh[slot, ar], rho[slot, ar], (i < hlen)
+
+    @staticmethod
+    def lbfgs_direction(x, g, lo, active, Sh, Yh, rho, hlen, hpos, gtol, pg, d, phase=None, step=None, nback=None):
         H = Sh.shape[0]
+        keep = (phase.bool() & active) if phase is not None else torch.zeros_like(active)   # in the middle of a line search
         bound = (x <= lo) & (g > 0)
-        pg.copy_(torch.where(bound, torch.zeros_like(g), g))
-        active &= pg.abs().amax(1) > gtol
-        slots = [(hist_pos + i) % H for i in range(hist_len)]          # oldest ... newest
-        qv = pg.clone()
+        pg_new = torch.where(bound, torch.zeros_like(g), g)
+        act_new = active & (pg_new.abs().amax(1) > gtol)
+        qv = pg_new.clone()
         al = []
-        for sl in reversed(slots):
-            a_ = rho[sl] * (Sh[sl] * qv).sum(1)
+        for i in range(H):
+            S_, Y_, r_, has = TorchLbfgs._pair(Sh, Yh, rho, hlen, hpos, i)
+            a_ = torch.where(has, r_ * (S_ * qv).sum(1), torch.zeros_like(r_))
             al.append(a_)
-            qv = qv - a_[:, None] * Yh[sl]
-        if slots:
-            sl = slots[-1]
-            gamma = (Sh[sl] * Yh[sl]).sum(1) / (Yh[sl] * Yh[sl]).sum(1).clamp_min(1e-300)
-            qv = qv * gamma[:, None]
-        for sl, a_ in zip(slots, reversed(al)):
-            b_ = rho[sl] * (Yh[sl] * qv).sum(1)
-            qv = qv + (a_ - b_)[:, None] * Sh[sl]
+            qv = qv - a_[:, None] * Y_
+        S_, Y_, _, has0 = TorchLbfgs._pair(Sh, Yh, rho, hlen, hpos, 0)
+        gamma = (S_ * Y_).sum(1) / (Y_ * Y_).sum(1).clamp_min(1e-300)
+        qv = torch.where(has0[:, None], qv * gamma[:, None], qv)
+        for i in range(H - 1, -1, -1):
+            S_, Y_, r_, has = TorchLbfgs._pair(Sh, Yh, rho, hlen, hpos, i)
+            b_ = r_ * (Y_ * qv).sum(1)
+            qv = torch.where(has[:, None], qv + (al[i] - b_)[:, None] * S_, qv)
         dd = -qv
-        bad = (dd * pg).sum(1) >= 0
-        dd = torch.where(bad[:, None], -pg, dd)
-        if not slots:
-            dd = dd / pg.abs().amax(1, keepdim=True).clamp_min(1e-300)
+        bad = (dd * pg_new).sum(1) >= 0
+        dd = torch.where(bad[:, None], -pg_new, dd)
+        first = hlen == 0
+        dd = torch.where(first[:, None], dd / pg_new.abs().amax(1, keepdim=True).clamp_min(1e-300), dd)
         dd = torch.where(bound, torch.zeros_like(dd), dd)
-        d.copy_(torch.where(active[:, None], dd, torch.zeros_like(dd)))
+        dd = torch.where(act_new[:, None], dd, torch.zeros_like(dd))
+        pg.copy_(torch.where(keep[:, None], pg, pg_new))
+        d.copy_(torch.where(keep[:, None], d, dd))
+        active.copy_(torch.where(keep, active, act_new))
+        started = active & ~keep
+        if step is not None:
+            step.copy_(torch.where(started, torch.ones_like(step), step))
+        if nback is not None:
+            nback.copy_(torch.where(started, torch.zeros_like(nback), nback))
+        if phase is not None:
+            phase.copy_(torch.where(started, torch.ones_like(phase), phase))
         return int(active.sum())
 
     @staticmethod
@@ -50,32 +69,51 @@ class TorchLbfgs:
         xe.copy_(torch.where(searching[:, None], xt, x_new))
 
     @staticmethod
-    def lbfgs_armijo(ft, f, pg, xt, x, searching, step, x_new, f_new):
+    def lbfgs_armijo(ft, f, pg, xt, x, searching, step, x_new, f_new, nback=None, max_backtracks=0, accepted=None):
         gd = (pg * (xt - x)).sum(1)
         ok = searching & (ft <= f + 1e-4 * gd) & torch.isfinite(ft)
         x_new.copy_(torch.where(ok[:, None], xt, x_new))
         f_new.copy_(torch.where(ok, ft, f_new))
-        searching &= ~ok
         curv = ft - f - gd
         theta = torch.where(torch.isfinite(ft) & (curv > 0), -gd / (2.0 * curv), torch.full_like(ft, 0.1))
-        step.copy_(torch.where(searching, step * theta.clamp(0.1, 0.5), step))
-        return int(searching.sum())
+        if nback is None:                                 # lock-step form
+            searching &= ~ok
+            step.copy_(torch.where(searching, step * theta.clamp(0.1, 0.5), step))
+            return int(searching.sum())
+        accepted.copy_(ok)                                # own line search per model
+        rejected = searching & ~ok
+        nback.copy_(torch.where(rejected, nback + 1, nback))
+        out = rejected & (nback >= max_backtracks)        # out of trial points: done (at numerical precision)
+        searching &= ~out
+        cont = rejected & ~out
+        step.copy_(torch.where(cont, step * theta.clamp(0.1, 0.5), step))
+        return int(cont.sum()), int(ok.sum())
 
     @staticmethod
-    def lbfgs_update(x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, slot_new):
-        gn = torch.where(searching[:, None], g, g_new) if keep_old else g_new
+    def lbfgs_update(x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, hlen, hpos, mask=None, phase=None):
+        H, R = Sh.shape[0], Sh.shape[1]
+        m = torch.ones_like(active) if mask is None else mask.bool()
+        srch = searching.bool() if (searching is not None and mask is None) else torch.zeros_like(active)
+        gn = torch.where(srch[:, None], g, g_new) if keep_old else g_new
         s_ = x_new - x
         y_ = gn - g
         sy = (s_ * y_).sum(1)
-        good = sy > 1e-10 * (y_ * y_).sum(1).clamp_min(1e-300)
-        Sh[slot_new] = torch.where(good[:, None], s_, torch.zeros_like(s_))
-        Yh[slot_new] = torch.where(good[:, None], y_, torch.zeros_like(y_))
-        rho[slot_new] = torch.where(good, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy))
+        good = m & (sy > 1e-10 * (y_ * y_).sum(1).clamp_min(1e-300))
+        slot = ((hpos + hlen) % H).long()
+        idx = good.nonzero().squeeze(1)
+        Sh[slot[idx], idx] = s_[idx]
+        Yh[slot[idx], idx] = y_[idx]
+        rho[slot[idx], idx] = 1.0 / sy[idx].clamp_min(1e-300)
+        full = hlen >= H
+        hpos.copy_(torch.where(good & full, (hpos + 1) % H, hpos))
+        hlen.copy_(torch.where(good & ~full, hlen + 1, hlen))
         rel = (f - f_new) / torch.maximum(torch.maximum(f.abs(), f_new.abs()), torch.ones_like(f))
-        active &= ~searching & (rel > ftol)
-        x.copy_(x_new)
-        g.copy_(gn)
-        f.copy_(f_new)
+        active.copy_(torch.where(m, active & ~srch & (rel > ftol), active))
+        x.copy_(torch.where(m[:, None], x_new, x))
+        g.copy_(torch.where(m[:, None], gn, g))
+        f.copy_(torch.where(m, f_new, f))
+        if phase is not None:
+            phase.copy_(torch.where(m, torch.zeros_like(phase), phase))
         return int(good.sum())
 
 

@@ -96,8 +96,10 @@ def test_secondary_factor_analysis_and_calibration(line):
     assert "error" not in f1, f1
     assert f1["converged_frac"] > 0.95 and f1["frac_at_or_below_true_parameter_objective"] > 0.95, f1
     f1w = line["secondary"]["f1_calibration_32x4"]                 # wide models beside it: 512 x (32,4), T = 500
-    assert "error" not in f1w and f1w["converged_frac"] > 0.95 and f1w["models_per_s"] >= 150.0, f1w   # round 3: 1.58-2.75 s for 512 models
-    assert f1["models_per_s"] >= 8000.0, f1    # round 5: 9.9-11 k (0.75-0.83 s for 8192 models); round 4: 10.9 k on its lease
+    assert "error" not in f1w and f1w["converged_frac"] > 0.95 and f1w["models_per_s"] >= 100.0, f1w
+    # (round 5: 3.9 s for 512 models TO CONVERGENCE, 200 iterations -- profiles/r05/ab_line_search.log; the round-3 figure of
+    # 2.75 s was 60 iterations with a third of the models converged)
+    assert f1["models_per_s"] >= 10000.0, f1    # round 5: 12-14 k (0.58-0.68 s for 8192 models); round 4: 10.9 k on its lease
 
 
 def test_secondary_dropin_configs0(line):

@@ -52,8 +52,8 @@ def test_adjoint_iteration_reaches_scipys_optimum(models, optima):
     eng = OracleEngine(*models)
     res = calibrate_batch(eng, gradient="adjoint", compact=0)
     check_against_scipy(res, optima)
-    # bookkeeping: every trial point is ONE recording forward launch over the R models in flight, every iteration ends in
-    # ONE backward launch; the first gradient is the only forward+backward pair
+    # bookkeeping (lock-step line search: the flight is small): every trial point is ONE recording forward launch over the R
+    # models in flight, every iteration ends in ONE backward launch; the first gradient is the only forward+backward pair
     kinds = [k for k, _ in eng.log]
     assert kinds[0] == "forward+backward" and kinds.count("forward+backward") == 1
     assert res.nit - 1 <= kinds.count("backward") <= res.nit
@@ -64,6 +64,34 @@ def test_adjoint_iteration_reaches_scipys_optimum(models, optima):
     for i, k in enumerate(kinds):
         if k == "backward":
             assert kinds[i - 1] == "forward"
+
+
+def test_own_line_search_per_model(models, optima):
+    """A flight above ``own_search_above``: every model runs its OWN line search across iterations -- an iteration is ONE
+    recording forward launch over the R models in flight, each at its own trial point, followed by ONE backward launch if any
+    trial was accepted.  Same optimum; and since a model's sequence of trial points does not depend on its neighbours, the
+    result of a model is the same whether it is calibrated alone or in the flight."""
+    eng = OracleEngine(*models)
+    res = calibrate_batch(eng, gradient="adjoint", compact=0, own_search_above=0)
+    check_against_scipy(res, optima)
+    kinds = [k for k, _ in eng.log]
+    assert kinds[0] == "forward+backward" and kinds.count("forward+backward") == 1
+    assert res.nit - 1 <= kinds.count("forward") <= res.nit and 0 < kinds.count("backward") <= kinds.count("forward")
+    assert all(b == eng.R for _, b in eng.log)
+    assert res.launches == 2 + kinds.count("forward") + kinds.count("backward")
+    assert res.nfev == eng.R * (1 + kinds.count("forward"))
+    for i, k in enumerate(kinds):
+        if k == "backward":
+            assert kinds[i - 1] == "forward"
+    obs, load = models
+    alone = calibrate_batch(OracleEngine(obs[3:4], load[3:4]), gradient="adjoint", compact=0, own_search_above=0)
+    assert torch.equal(alone.alpha[0], res.alpha[3]) and torch.equal(alone.obj[0], res.obj[3])
+    # ... and the lock-step search walks the same trial points: same iterates
+    lock = calibrate_batch(OracleEngine(*models), gradient="adjoint", compact=0)
+    np.testing.assert_allclose(lock.alpha.numpy(), res.alpha.numpy(), rtol=1e-9)
+    # the flight shrinks below the threshold in the middle of the run: lock-step from there on, same optimum
+    mixed = calibrate_batch(OracleEngine(*models), gradient="adjoint", compact=0.9, compact_min=2, own_search_above=3)
+    check_against_scipy(mixed, optima)
 
 
 def test_compaction_leaves_every_models_iterates_unchanged(models):
