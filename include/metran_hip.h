@@ -218,7 +218,9 @@ MK_API int64_t mk_record_stride(int64_t n);
 /* ... per PACKED-SYMMETRIC record (mk_outputs.flags & MK_OUT_PACKED_SYM). */
 MK_API int64_t mk_record_stride_sym(int64_t n);
 /* Doubles per (model, step) of the backward tape (mk_outputs.flags & MK_OUT_TAPE): N (N + K + 4); and whether the
- * tape path serves a shape (16 < N + K, N <= 32: the shapes of the split filter, mk_split.hip / mk_dk.hip). */
+ * tape path serves a shape (a specialised shape with 16 < N + K <= 63 -- the backward pass keeps the rows of its n x n matrix and
+ * one more on the 64 lanes; written by the split filter of mk_split.hip for N <= 32 and by the lane-per-state filter beyond,
+ * read by mk_dk.hip). */
 MK_API int64_t mk_tape_stride(int64_t N, int64_t K);
 MK_API int mk_tape_supported(int64_t N, int64_t K);
 /* ... of the STATE tape (MK_OUT_TAPE | MK_OUT_VAR_ONLY): (N + K)(N + K + 4); served for the same shapes. */

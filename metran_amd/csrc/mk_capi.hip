@@ -166,8 +166,10 @@ hipError_t generic_workspace(mk_context *ctx, long B, int n, double **ws)
 }
 hipError_t dispatch_smoother(mk_context *ctx, int N, int K, const mk::SmootherArgs &a, hipStream_t s)
 {
-    // the plain smoother depends on n = N + K only; the projecting one needs the exact (N, K)
-    const bool proj = a.sim_means || a.sim_vars;
+    // the plain smoother depends on n = N + K only; the projecting one and the tape's backward pass (the state tape without a
+    // projection included: a (16,2) tape walked by the (17,1) module's kernel was the defect the (16,2) state-tape test found)
+    // need the exact (N, K)
+    const bool proj = a.sim_means || a.sim_vars || a.tape != 0;
     const bool force_generic = ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1;
     if (!force_generic) {
         if (proj ? aot_shape(N, K) : aot_state_dim(N + K)) return mk::launch_smoother(N, K, a, s);
@@ -349,7 +351,7 @@ MK_API int64_t mk_tape_stride(int64_t N, int64_t K) { return mk::tape_stride_c((
 MK_API int64_t mk_state_tape_stride(int64_t N, int64_t K) { return mk::state_tape_stride_c((int)N, (int)K); }
 MK_API int mk_tape_supported(int64_t N, int64_t K)
 {
-    return (N + K > 16 && N <= 32 && K <= 16 && N + K + 1 <= 64 && specialised(N, K)) ? 1 : 0;
+    return (N + K > 16 && K <= 16 && N + K + 1 <= 64 && specialised(N, K)) ? 1 : 0;
 }
 // MK_OUT_TAPE (mk_outputs.flags): 0 = not asked for, 1 = asked for and consistent, 2 = the STATE tape (with MK_OUT_VAR_ONLY:
 // d_S / d_Ps are the smoothed state means / variances [B,T,n]), < 0 = an inconsistent description
@@ -358,7 +360,7 @@ static int tape_outputs(const mk_problem *p, const mk_outputs *o)
     if (!(o->flags & MK_OUT_TAPE)) return 0;
     if (o->flags & MK_OUT_PACKED_SYM) return fail(MK_ERR_INVALID, "MK_OUT_TAPE excludes MK_OUT_PACKED_SYM");
     if (!mk_tape_supported(p->N, p->K))
-        return fail(MK_ERR_SHAPE, "MK_OUT_TAPE serves 16 < N + K, N <= 32 (got N=%lld, K=%lld)", (long long)p->N, (long long)p->K);
+        return fail(MK_ERR_SHAPE, "MK_OUT_TAPE serves specialised shapes with 16 < N + K <= 63 (got N=%lld, K=%lld)", (long long)p->N, (long long)p->K);
     if (!p->d_loadings) return fail(MK_ERR_INVALID, "MK_OUT_TAPE needs d_loadings");
     if (o->flags & MK_OUT_VAR_ONLY) {
         if (!o->d_F || o->d_Pf || o->d_Xp || o->d_Pp || !o->d_S || !o->d_Ps)

@@ -38,6 +38,7 @@
 namespace mk {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
 // HASR: the observation variances R_j (mk_problem.d_obsvar) are not all zero.  Right after its update the filter's moments of
@@ -52,8 +53,10 @@ typedef __attribute__((address_space(1))) const void global_cvoid_t;
 // Beyond the projection's work: K products w_k = N pt_{N+k} (the r row yields r . pt_{N+k}), and one product of the step's
 // entries against them -- lane a reads ITS entry pt_a from the LDS block, w_k arrive DPP-replicated: c_a[k] = pt_a . w_k is
 // Vt[a][N+k] = Pt[a][N+k] - c_a[k] for an unobserved series a and Vt_FF[k'][k] at lane N + k'.  tests/dk_ref.py::dk_smooth_state.
+// More than 32 series (round 5; the tape then comes from the lane-per-state filter, mk_kernels.hip OUT = 4): the same kernel with
+// 64-bit series masks; the row of N alone is 2 n registers, so beyond n = 40 one wavefront per SIMD owns the register file.
 template <int N, int K, bool HASR, bool STATE = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) smoother_dk_kernel(SmootherArgs a)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N + K <= 40 ? 2 : 1, N + K <= 40 ? 2 : 1))) smoother_dk_kernel(SmootherArgs a)
 {
     static_assert(!(STATE && HASR), "the state outputs are served for R = 0 (Metran's observation variance, metran.py:382-384)");
     constexpr int n = N + K, SW = tape_side_c(K), RS = STATE ? state_tape_stride_c(N, K) : tape_stride_c(N, K);
@@ -62,7 +65,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int NB = (N + 15) / 16;          // DPP-replicated registers holding the series entries of a vector
     constexpr int NP = (n + 2) & ~1;           // >= n + 1, even: LDS rows of 16-byte pieces
     constexpr bool PAIRS = (N % 2 == 0 && K % 2 == 0); // side rows and their scalars are 16-byte aligned
-    constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
+    using mask_t = typename std::conditional<(N > 32), unsigned long long, unsigned>::type; // one bit per series
+    constexpr mask_t NM = N >= 8 * (int)sizeof(mask_t) ? ~(mask_t)0 : (((mask_t)1 << (N % (8 * (int)sizeof(mask_t)))) - (mask_t)1);
+    auto lowbit = [](mask_t m) __attribute__((always_inline)) { return N > 32 ? (int)__builtin_ctzll(m) : (int)__builtin_ctz((unsigned)m); };
     constexpr int QS = (N + 2) & ~1;           // series lanes 0..N-1 (+ one dummy slot)
     // the step's tape block is copied HBM -> LDS by the wavefront itself (global_load_lds: no registers, asynchronous):
     // 16 bytes a lane and instruction when the blocks are 16-byte aligned, 4 bytes otherwise
@@ -70,6 +75,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int NCH = (RS * 8 + CHUNK - 1) / CHUNK;
     constexpr int TBD = NCH * CHUNK / 8;       // doubles of the LDS image (block + what the last chunk over-reads)
     using G16 = Group<16>;
+    // beyond two wavefronts' worth of registers the compiler parks values in AGPRs and reloads them right before their use -- a VALU
+    // write it cannot know a DPP read follows: those instantiations take the guarded statements (mk_prims.h)
+    constexpr bool GD = (n > 40);
 
     const int lane = threadIdx.x, i16 = lane & 15;
     long inst = (long)blockIdx.x;
@@ -84,6 +92,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int GLT = STATE ? ((N * K + 1) & ~1) : 0; // STATE: loadings table [N][K]
     __shared__ __attribute__((aligned(16))) double lds[TBD + NP + NP + K * NP + K * K * QS + ((K * K + 1) & ~1) + GLT];
     double *tapeb = lds;                       // the step's tape block: N entries [ series part (N) | side row (SW) ]
+    // ... and its LDS address for the copy, taken from the array itself: a run-time generic -> LDS cast of `tapeb + offset` is
+    // folded by the compiler in most instantiations and mis-selected in one (hipcc 7.2, (48,3) inside a shape module:
+    // "V_CMP_NE_U32 0, src_shared_base: operand has incorrect register class")
+    lds_char_t *const tapeb3 = (lds_char_t *)lds;
     double *sideb = tapeb + SO;
     double *phim = tapeb + TBD;                // diag(Phi) [n]
     double *tbuf = phim + NP;                  // the new column j on its way to lane j's row
@@ -131,9 +143,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             long off = (long)c * CHUNK + (long)lane * CB_BYTES;
             if constexpr ((c + 1) * CHUNK > RS * 8) off = off < blk_bytes - CB_BYTES ? off : blk_bytes - CB_BYTES; // stay inside
             if constexpr (RS % 2 == 0)
-                __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + off), (lds_void_t *)((char *)tapeb + c * CHUNK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + off), (lds_void_t *)(tapeb3 + c * CHUNK), 16, 0, 0);
             else
-                __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + off), (lds_void_t *)((char *)tapeb + c * CHUNK), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + off), (lds_void_t *)(tapeb3 + c * CHUNK), 4, 0, 0);
         });
     };
 
@@ -169,24 +181,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double acc0 = 0.0, acc1 = 0.0;
         sfor<0, N / 16>(MK_LAMBDA(bb) { // sixteen columns per asm statement
             constexpr int c = 16 * decltype(bb)::value;
-            G16::fmac16(acc0, acc1, E.XB[c / 16], Nr[c], Nr[c + 1], Nr[c + 2], Nr[c + 3], Nr[c + 4], Nr[c + 5], Nr[c + 6], Nr[c + 7], Nr[c + 8],
+            G16::fmac16<GD>(acc0, acc1, E.XB[c / 16], Nr[c], Nr[c + 1], Nr[c + 2], Nr[c + 3], Nr[c + 4], Nr[c + 5], Nr[c + 6], Nr[c + 7], Nr[c + 8],
                         Nr[c + 9], Nr[c + 10], Nr[c + 11], Nr[c + 12], Nr[c + 13], Nr[c + 14], Nr[c + 15]);
         });
         sfor<0, (N % 16) / 4>(MK_LAMBDA(qq) {
             constexpr int c = 16 * (N / 16) + 4 * decltype(qq)::value;
-            G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16>(acc0, acc1, E.XB[c / 16], Nr[c], E.XB[(c + 1) / 16], Nr[c + 1],
+            G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16, false, GD>(acc0, acc1, E.XB[c / 16], Nr[c], E.XB[(c + 1) / 16], Nr[c + 1],
                                                                            E.XB[(c + 2) / 16], Nr[c + 2], E.XB[(c + 3) / 16], Nr[c + 3]);
         });
         sfor<16 * (N / 16) + 4 * ((N % 16) / 4), N>(MK_LAMBDA(cc) {
             constexpr int c = decltype(cc)::value;
-            G16::fmac<c % 16>(c % 2 ? acc1 : acc0, E.XB[c / 16], Nr[c]);
+            G16::fmac<c % 16, false, GD>(c % 2 ? acc1 : acc0, E.XB[c / 16], Nr[c]);
         });
         if constexpr (K == 4) {
-            G16::fmac4<0, 1, 2, 3>(acc0, acc1, E.XF, Nr[N], E.XF, Nr[N + 1], E.XF, Nr[N + 2], E.XF, Nr[N + 3]);
+            G16::fmac4<0, 1, 2, 3, false, GD>(acc0, acc1, E.XF, Nr[N], E.XF, Nr[N + 1], E.XF, Nr[N + 2], E.XF, Nr[N + 3]);
         } else {
             sfor<0, K>(MK_LAMBDA(kk) {
                 constexpr int k = decltype(kk)::value;
-                G16::fmac<k>(k % 2 ? acc1 : acc0, E.XF, Nr[N + k]);
+                G16::fmac<k, false, GD>(k % 2 ? acc1 : acc0, E.XF, Nr[N + k]);
             });
         }
         return acc0 + acc1;
@@ -222,7 +234,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             s2 = e[2];
         }
         const bool unobs = (s2 != s2);
-        const unsigned obsm = (unsigned)__ballot(lane < N && !unobs) & NM; // series observed at this step
+        const mask_t obsm = (mask_t)__ballot(lane < N && !unobs) & NM; // series observed at this step
         Ent ea, eb;
 
         // ---- STATE: the factor columns of Vt and the smoothed factor means, with (r, N) before the step's updates and BEFORE the
@@ -271,15 +283,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     constexpr int c = decltype(cc)::value;
                     if constexpr (c < N) {
                         if constexpr (K == 4)
-                            G16::fmac4x<c % 16>(cacc[0], cacc[1], cacc[2], cacc[3], WBk[0][c / 16], WBk[1][c / 16], WBk[2][c / 16],
+                            G16::fmac4x<c % 16, GD>(cacc[0], cacc[1], cacc[2], cacc[3], WBk[0][c / 16], WBk[1][c / 16], WBk[2][c / 16],
                                                  WBk[3][c / 16], rowp[c - c0]);
                         else
-                            sfor<0, K>(MK_LAMBDA(k2) { G16::fmac<c % 16>(cacc[decltype(k2)::value], WBk[decltype(k2)::value][c / 16], rowp[c - c0]); });
+                            sfor<0, K>(MK_LAMBDA(k2) { G16::fmac<c % 16, false, GD>(cacc[decltype(k2)::value], WBk[decltype(k2)::value][c / 16], rowp[c - c0]); });
                     } else {
                         if constexpr (K == 4)
-                            G16::fmac4x<c - N>(cacc[0], cacc[1], cacc[2], cacc[3], WFk[0], WFk[1], WFk[2], WFk[3], rowp[c - c0]);
+                            G16::fmac4x<c - N, GD>(cacc[0], cacc[1], cacc[2], cacc[3], WFk[0], WFk[1], WFk[2], WFk[3], rowp[c - c0]);
                         else
-                            sfor<0, K>(MK_LAMBDA(k2) { G16::fmac<c - N>(cacc[decltype(k2)::value], WFk[decltype(k2)::value], rowp[c - c0]); });
+                            sfor<0, K>(MK_LAMBDA(k2) { G16::fmac<c - N, false, GD>(cacc[decltype(k2)::value], WFk[decltype(k2)::value], rowp[c - c0]); });
                     }
                 });
             });
@@ -320,11 +332,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // ---- series not observed at this step: mean = s0 + pt.r, var = s1 - pt'N pt with (r, N) before the step's updates.
         // The products x_a w_a go back into the entry's own (consumed) LDS slots, beta into its constant-0 slot; lane u sums
         // its entry afterwards.
-        unsigned um = ~obsm & NM;
+        mask_t um = ~obsm & NM;
         auto unobs_step = [&](Ent &E, Ent &Enext) __attribute__((always_inline)) {
-            const int u = (int)__builtin_ctz(um);
-            um &= um - 1u;
-            load_ent(um ? (int)__builtin_ctz(um) : u, Enext); // the next entry's LDS reads in flight during this product
+            const int u = lowbit(um);
+            um &= um - (mask_t)1;
+            load_ent(um ? lowbit(um) : u, Enext); // the next entry's LDS reads in flight during this product
             __builtin_amdgcn_sched_barrier(0);
             const double w = matvec(E);
             tapeb[xa_off + u * xa_str] = lane < n ? E.xa * w : w;
@@ -334,7 +346,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // ten entries at a time -- does 0.4x the multiply-adds; it ran the kernel at 71 ms against 56: a uniform LDS read per
         // multiply-add costs more than the 22 broadcast multiply-adds it saves.)
         if (um && !MK_TUNE_SKIP(a, 64)) {
-            load_ent((int)__builtin_ctz(um), ea);
+            load_ent(lowbit(um), ea);
             while (true) {
                 unobs_step(ea, eb);
                 if (!um) break;
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (osv) *osv = (frow ? 0.0 : var) + st_vadd;
         }
         // ---- observed series, last first: the scalar updates of the filter walked backwards
-        unsigned om = obsm;
+        mask_t om = obsm;
         {
             // the loop over the series is UNROLLED (static j: an entry's LDS addresses are immediates, the column N[.][j] is a
             // named register -- no bit scan, no address arithmetic, no jump tables for N[.][j]); every position prefetches the
@@ -380,7 +392,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     constexpr int j = decltype(jj)::value;
                     if constexpr (j > 0) load_ent(j - 1, eo[(j - 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (om & (1u << j)) {
+                    if (om & ((mask_t)1 << j)) {
                         const Ent &E = eo[j & 1];
                         const double w = matvec(E);
                         const double beta = readlane_f64(w, n);
@@ -441,13 +453,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 double y0 = Nr[N + k] * phim[N + k], y1 = 0.0;
                 sfor<0, N / 4>(MK_LAMBDA(qq) {
                     constexpr int c = 4 * decltype(qq)::value;
-                    G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16>(y0, y1, CB[k][c / 16], Nr[c], CB[k][(c + 1) / 16], Nr[c + 1],
+                    G16::fmac4<c % 16, (c + 1) % 16, (c + 2) % 16, (c + 3) % 16, false, GD>(y0, y1, CB[k][c / 16], Nr[c], CB[k][(c + 1) / 16], Nr[c + 1],
                                                                                    CB[k][(c + 2) / 16], Nr[c + 2], CB[k][(c + 3) / 16],
                                                                                    Nr[c + 3]);
                 });
                 sfor<4 * (N / 4), N>(MK_LAMBDA(cc) {
                     constexpr int c = decltype(cc)::value;
-                    G16::fmac<c % 16>(c % 2 ? y1 : y0, CB[k][c / 16], Nr[c]);
+                    G16::fmac<c % 16, false, GD>(c % 2 ? y1 : y0, CB[k][c / 16], Nr[c]);
                 });
                 Yf[k] = y0 + y1;
             });
@@ -503,11 +515,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
-// Which calls the tape path serves: the shapes of the split filter (16 < n, N <= 32), projection outputs.
+// Which calls the tape path serves: wide models whose rows and the r row fit a wavefront (16 < n <= 63), projection / state outputs.
 template <int N, int K>
 static hipError_t launch_dk_nk(const SmootherArgs &a, hipStream_t s)
 {
-    if constexpr (N + K > 16 && N <= 32 && N + K + 1 <= 64 && K <= 16) {
+    if constexpr (N + K > 16 && N + K + 1 <= 64 && K <= 16) {
         if (a.tape == 2) { // the STATE tape: smoothed state means / variances (and, if asked for, the projection)
             if (a.rs != state_tape_stride_c(N, K) || a.obsvar) return hipErrorInvalidValue;
             hipLaunchKernelGGL((smoother_dk_kernel<N, K, false, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);

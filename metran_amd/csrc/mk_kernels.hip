@@ -25,7 +25,9 @@ namespace mk {
 // =====================================================================================
 // Sequential-processing Kalman filter + -2 log L            (kalmanfilter.py:236-400, 550-567)
 //   OUT  : 0 = no state outputs (solver objective, mk_loglik), 1 = predicted + filtered packed records,
-//          3 = filtered packed record only (input of a projecting smoother), 2 = any dense subset
+//          3 = filtered packed record only (input of a projecting smoother), 2 = any dense subset,
+//          4 = the BACKWARD TAPE of the inverse-free smoother (mk_dk.hip; G = 64 only: the shapes with more than 32 series,
+//              which the split layout of mk_split.hip -- the tape's writer for N <= 32 -- does not serve; same entries)
 //   BOOK : per-step sigmas/detfs are written (needs one log per step); otherwise the
 //          log-determinant is accumulated as a normalised product with ONE log at the end
 // =====================================================================================
@@ -53,6 +55,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
     static_assert(!SYM || OUT == 1 || OUT == 3, "packed-symmetric layout applies to record outputs");
     constexpr int n = N + K;
     static_assert(n <= G, "state dimension must fit the lane group");
+    constexpr bool TAPE = (OUT == 4);
+    static_assert(!TAPE || (G == 64 && MK_WIDE_FILTER_LOOP && N * K > 32), "the tape leaves the one-model-per-wavefront loop filter");
     using Gp = Group<G>;
     constexpr int GPB = 256 / G; // models per 256-thread workgroup
     constexpr bool HOIST = (N * K <= 32); // keep Z's loading block replicated in registers
@@ -160,6 +164,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
         RIO::put_pad(imgP, gw, 0.0, 0.0);
     }
     double pad0 = 0.0, pad1 = 0.0;
+    // TAPE: block of (model, step) = N (state tape: N + K) entries [ vector in the observable basis (n) | s0 s1 s2 0 ] of
+    // XS = n + 4 doubles (mk_internal.h); lane r < n holds element r of an entry's vector
+    [[maybe_unused]] constexpr int XS = tape_xs_c(N, K);
+    [[maybe_unused]] double *trec = TAPE ? a.F + inst * a.bs * a.rs : nullptr;
+    [[maybe_unused]] const long tstep = a.ts * a.rs;
 
     // ---- observation stream: tiles of 16 time steps through LDS ----
     // vmcnt retires vector-memory operations IN ORDER, so consuming a load makes the wavefront wait for
@@ -392,6 +401,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
 #pragma unroll
                     for (int c = 0; c < n; ++c) P[c] = fma(-dc[c], kr, P[c]);
                 }
+                if constexpr (TAPE) {
+                    // tape entry of the observed series j: [ kt = T k | v/f | 1/f | y_j | 0 ], the gain in the observable basis
+                    // (kt_l = k_l + sum_k g_lk k_{N+k} on the series lanes, the factor gains themselves on the factor lanes:
+                    // one 8 n-byte run), as filter_split_kernel writes it
+                    double kt = 0.0;
+                    sfor<0, K>(MK_LAMBDA(k) { kt = fma(gam[decltype(k)::value], Gp::template bcast<N + decltype(k)::value>(kr), kt); });
+                    kt = lane < N ? kr + kt : kr;
+                    trec[j * XS + r] = kt;
+                    const double yj = readlane_f64(y, j);
+                    if (lead) {
+                        double *sd = trec + j * XS + n;
+                        sd[0] = v * rf;
+                        sd[1] = rf;
+                        sd[2] = yj;
+                        sd[3] = 0.0;
+                    }
+                }
                 sfor<0, K>(MK_LAMBDA(k) { // factor-state replicas: gain elements of lanes N+k (off the critical path)
                     constexpr int kk = decltype(k)::value;
                     xk[kk] = fma(Gp::template bcast<N + kk>(kr), v, xk[kk]);
@@ -455,6 +481,64 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
             ++sc;
         }
         if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
+
+        if constexpr (TAPE) {
+            // entries of the series NOT observed at this step, from the filtered moments (mk_split.hip writes the same):
+            //     [ pt = T Pf z_u' (n) | z_u x_f | z_u Pf z_u' | NaN | 0 ],   d = Pf z_u' as in an update (no rank-one update),
+            //     pt_l = d_l + sum_k g_lk d_{N+k} on the series lanes (pt_u IS z_u Pf z_u'), d_{N+k} on the factor lanes
+            const double qnan = __builtin_nan("");
+            if (a.tape == 2) {
+                // STATE tape: entry N + k = column N + k of T Pf T' -- [ Pf[l][N+k] + sum_k' g_lk' Pf[N+k'][N+k] (series lanes),
+                // Pf[N+k'][N+k] (factor lanes) | x_f[N+k] | Pf[N+k][N+k] | NaN | 0 ]
+                sfor<0, K>(MK_LAMBDA(kc) {
+                    constexpr int k = decltype(kc)::value;
+                    double qk = 0.0;
+                    sfor<0, K>(MK_LAMBDA(k2) { qk = fma(gam[decltype(k2)::value], Gp::template bcast<N + decltype(k2)::value>(P[N + k]), qk); });
+                    qk = lane < N ? P[N + k] + qk : P[N + k];
+                    trec[(N + k) * XS + r] = qk;
+                    const double pkk = Gp::template bcast<N + k>(P[N + k]);
+                    if (lead) {
+                        double *sd = trec + (N + k) * XS + n;
+                        sd[0] = xk[k];
+                        sd[1] = pkk;
+                        sd[2] = qnan;
+                        sd[3] = 0.0;
+                    }
+                });
+            }
+            unsigned long long um = ~(unsigned long long)vm & Gp::full_mask(N);
+            double yh = x; // the filtered observable z_l x_f of every series lane
+            sfor<0, K>(MK_LAMBDA(k) { yh = fma(gam[decltype(k)::value], xk[decltype(k)::value], yh); });
+            while (um) {
+                const int u = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(um));
+                um &= um - 1;
+                double dr = 0.0;
+                switch (u) {
+#define MK_CASE_PU(c) \
+    case c:           \
+        if constexpr (c < N) dr = P[c]; \
+        break;
+                    MK_CASE_PU(0) MK_CASE_PU(1) MK_CASE_PU(2) MK_CASE_PU(3) MK_CASE_PU(4) MK_CASE_PU(5) MK_CASE_PU(6) MK_CASE_PU(7) MK_CASE_PU(8) MK_CASE_PU(9) MK_CASE_PU(10) MK_CASE_PU(11) MK_CASE_PU(12) MK_CASE_PU(13) MK_CASE_PU(14) MK_CASE_PU(15) MK_CASE_PU(16) MK_CASE_PU(17) MK_CASE_PU(18) MK_CASE_PU(19) MK_CASE_PU(20) MK_CASE_PU(21) MK_CASE_PU(22) MK_CASE_PU(23) MK_CASE_PU(24) MK_CASE_PU(25) MK_CASE_PU(26) MK_CASE_PU(27) MK_CASE_PU(28) MK_CASE_PU(29) MK_CASE_PU(30) MK_CASE_PU(31) MK_CASE_PU(32) MK_CASE_PU(33) MK_CASE_PU(34) MK_CASE_PU(35) MK_CASE_PU(36) MK_CASE_PU(37) MK_CASE_PU(38) MK_CASE_PU(39) MK_CASE_PU(40) MK_CASE_PU(41) MK_CASE_PU(42) MK_CASE_PU(43) MK_CASE_PU(44) MK_CASE_PU(45) MK_CASE_PU(46) MK_CASE_PU(47) MK_CASE_PU(48) MK_CASE_PU(49) MK_CASE_PU(50) MK_CASE_PU(51) MK_CASE_PU(52) MK_CASE_PU(53) MK_CASE_PU(54) MK_CASE_PU(55) MK_CASE_PU(56) MK_CASE_PU(57) MK_CASE_PU(58) MK_CASE_PU(59) MK_CASE_PU(60) MK_CASE_PU(61) MK_CASE_PU(62) MK_CASE_PU(63)
+#undef MK_CASE_PU
+                default: break;
+                }
+                const double *gu = gtab + u * K;
+                sfor<0, K>(MK_LAMBDA(k) { dr = fma(P[N + decltype(k)::value], gu[decltype(k)::value], dr); });
+                double pt = 0.0;
+                sfor<0, K>(MK_LAMBDA(k) { pt = fma(gam[decltype(k)::value], Gp::template bcast<N + decltype(k)::value>(dr), pt); });
+                pt = lane < N ? dr + pt : dr;
+                trec[u * XS + r] = pt;
+                const double s0 = readlane_f64(yh, u), s1 = readlane_f64(pt, u);
+                if (lead) {
+                    double *sd = trec + u * XS + n;
+                    sd[0] = s0;
+                    sd[1] = s1;
+                    sd[2] = qnan;
+                    sd[3] = 0.0;
+                }
+            }
+            trec += tstep;
+        }
 
         if constexpr (LDSOUT) {
             RIO::put(imgF, gw, r, x, P);
@@ -1974,6 +2058,15 @@ static hipError_t launch_filter_nk(const FilterArgs &a, hipStream_t s)
             const hipError_t e = launch_filter_split(N, K, a, s);
             if (e != hipErrorNotSupported) return e;
         }
+    }
+    if constexpr (n > 16 && N > 32) { // the backward tape of the shapes beyond the split layout: the lane-per-state loop filter writes it
+        if (a.tape) {
+            if (book) hipLaunchKernelGGL((filter_kernel<N, K, G, 4, true, false>), dim3(grid), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((filter_kernel<N, K, G, 4, false, false>), dim3(grid), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    } else if (a.tape) {
+        return hipErrorNotSupported;
     }
     if (!any && !book)
         hipLaunchKernelGGL((filter_kernel<N, K, G, 0, false, false>), dim3(grid), dim3(256), 0, s, a);

@@ -74,10 +74,14 @@ struct Group<16> {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true); // v_mov_b64_dpp row_newbcast:J
     }
     // acc += bcast<J>(src) * mul   /   acc -= bcast<J>(src) * mul
-    template <int J, bool NEG = false>
+    // GUARD (here and below): two wait states INSIDE the statement, ahead of its first DPP read.  The compiler does not see the
+    // DPP reads of an asm statement; a kernel that spills (AGPR reloads are VALU writes placed right before the use) asks for it.
+    template <int J, bool NEG = false, bool GUARD = false>
     static __device__ __forceinline__ void fmac(double &acc, double src, double mul)
     {
-        if constexpr (NEG)
+        if constexpr (GUARD)
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(NEG ? -mul : mul), "n"(J));
+        else if constexpr (NEG)
             asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
         else
             asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" MK_DPPMASK : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
@@ -95,11 +99,17 @@ struct Group<16> {
                          : "+v"(acc0), "+v"(acc1) : "v"(src0), "v"(mul0), "v"(src1), "v"(mul1), "n"(J0), "n"(J1));
     }
     // four in one statement, two accumulators alternating (acc0, acc1, acc0, acc1): the dot-form sweeps of the wide smoother
-    template <int J0, int J1, int J2, int J3, bool NEG = false>
+    template <int J0, int J1, int J2, int J3, bool NEG = false, bool GUARD = false>
     static __device__ __forceinline__ void fmac4(double &acc0, double &acc1, double s0, double m0, double s1, double m1, double s2,
                                                  double m2, double s3, double m3)
     {
-        if constexpr (NEG)
+        static_assert(!(GUARD && NEG), "guarded form: positive only");
+        if constexpr (GUARD)
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:%10" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, %5 row_newbcast:%11" MK_DPPMASK
+                         "\n\tv_fmac_f64_dpp %0, %6, %7 row_newbcast:%12" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %8, %9 row_newbcast:%13" MK_DPPMASK
+                         : "+v"(acc0), "+v"(acc1)
+                         : "v"(s0), "v"(m0), "v"(s1), "v"(m1), "v"(s2), "v"(m2), "v"(s3), "v"(m3), "n"(J0), "n"(J1), "n"(J2), "n"(J3));
+        else if constexpr (NEG)
             asm volatile("v_fmac_f64_dpp %0, %2, -%3 row_newbcast:%10" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %4, -%5 row_newbcast:%11" MK_DPPMASK
                          "\n\tv_fmac_f64_dpp %0, %6, -%7 row_newbcast:%12" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %8, -%9 row_newbcast:%13" MK_DPPMASK
                          : "+v"(acc0), "+v"(acc1)
@@ -112,10 +122,32 @@ struct Group<16> {
     }
     // sixteen in ONE statement (19 operands): the sixteen lanes of one replicated source register against sixteen
     // multipliers, two accumulators alternating -- a 16-column slice of a row-per-lane matrix-vector product (mk_dk.hip)
+    template <bool GUARD = false>
     static __device__ __forceinline__ void fmac16(double &acc0, double &acc1, double src, double m0, double m1, double m2, double m3,
                                                   double m4, double m5, double m6, double m7, double m8, double m9, double m10,
                                                   double m11, double m12, double m13, double m14, double m15)
     {
+        if constexpr (GUARD)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:0" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14" MK_DPPMASK "\n\t"
+                     "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15" MK_DPPMASK
+                     : "+v"(acc0), "+v"(acc1)
+                     : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7), "v"(m8), "v"(m9), "v"(m10),
+                       "v"(m11), "v"(m12), "v"(m13), "v"(m14), "v"(m15));
+        else
         asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:0" MK_DPPMASK "\n\t"
                      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1" MK_DPPMASK "\n\t"
                      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2" MK_DPPMASK "\n\t"
@@ -137,10 +169,16 @@ struct Group<16> {
                        "v"(m11), "v"(m12), "v"(m13), "v"(m14), "v"(m15));
     }
     // four independent accumulators, one broadcast lane, one multiplier: acc_i += bcast<J>(s_i) * mul
-    template <int J>
+    template <int J, bool GUARD = false>
     static __device__ __forceinline__ void fmac4x(double &a0, double &a1, double &a2, double &a3, double s0, double s1, double s2,
                                                   double s3, double mul)
     {
+        if constexpr (GUARD)
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %4, %8 row_newbcast:%9" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %5, %8 row_newbcast:%9" MK_DPPMASK
+                         "\n\tv_fmac_f64_dpp %2, %6, %8 row_newbcast:%9" MK_DPPMASK "\n\tv_fmac_f64_dpp %3, %7, %8 row_newbcast:%9" MK_DPPMASK
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                         : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(mul), "n"(J));
+        else
         asm volatile("v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9" MK_DPPMASK "\n\tv_fmac_f64_dpp %1, %5, %8 row_newbcast:%9" MK_DPPMASK
                      "\n\tv_fmac_f64_dpp %2, %6, %8 row_newbcast:%9" MK_DPPMASK "\n\tv_fmac_f64_dpp %3, %7, %8 row_newbcast:%9" MK_DPPMASK
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)

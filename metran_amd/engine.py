@@ -60,8 +60,8 @@ class BatchedKalman:
             raise ValueError("layout must be 'model_major' or 'time_major'")
         self.time_major = layout == "time_major"
         self.packed_sym = bool(packed_sym)
-        # simulate_smoothed of wide models: "auto" = the inverse-free tape path where it applies (MK_OUT_TAPE: 16 < n,
-        # N <= 32), else filtered records + RTS smoother; "tape" insists, "records" never uses it
+        # simulate_smoothed of wide models: "auto" = the inverse-free tape path where it applies (MK_OUT_TAPE: 16 < n
+        # <= 63), else filtered records + RTS smoother; "tape" insists, "records" never uses it
         self.projection_path = "auto"
         L = _lib.lib()  # raises MetranHipError when the HIP library is not built
         if not torch.cuda.is_available():
@@ -608,11 +608,12 @@ class BatchedKalman:
     def tape_path(self):
         """True when ``simulate_smoothed`` runs the inverse-free backward pass over the filter's tape (``MK_OUT_TAPE``:
         ``mk_split.hip`` OUT = 4 + ``mk_dk.hip``) instead of filtered records + the RTS smoother: wide models served by the
-        split filter (16 < n, N <= 32), full-square engine, ``projection_path`` not "records"."""
+        split filter -- with more than 32 series: by the lane-per-state filter, same tape -- (16 < n <= 63), full-square engine,
+        ``projection_path`` not "records"."""
         ok = (self.loadings is not None and not self.packed_sym and bool(self._L.mk_tape_supported(self.N, self.K))
               and self.get_variant("kernel_family") == "specialised")
         if self.projection_path == "tape" and not ok:
-            raise MetranHipError("projection_path='tape' needs a model with 16 < N + K, N <= 32 and a full-square engine "
+            raise MetranHipError("projection_path='tape' needs a model with 16 < N + K <= 63 and a full-square engine "
                                  "(got N=%s, K=%s)" % (self.N, getattr(self, "K", None)))
         return ok and self.projection_path != "records"
 

@@ -39,6 +39,7 @@ def kernels(a):
 
     N, K = (int(v) for v in a.shape.split(","))
     kf, d = _engine(N, K, a.T, a.batch, a.missing, a.layout)
+    kf.projection_path = a.path
     runs = {
         "full": lambda b: kf.filter_smooth(d["phi"], d["q"], buffers=b),
         "filter": lambda b: kf.filter(d["phi"], d["q"], buffers=b),
@@ -173,6 +174,7 @@ if __name__ == "__main__":
     p.add_argument("--what", nargs="+", default=["full"], choices=["full", "filter", "project", "state", "objective", "grad"])
     p.add_argument("--layout", default="time_major")
     p.add_argument("--reps", type=int, default=5)
+    p.add_argument("--path", default="auto", choices=["auto", "tape", "records"], help="projection / state outputs of wide models")
     p.add_argument("--ramp", type=int, default=0)
     p.add_argument("--check", type=int, default=0)
     p.set_defaults(fn=kernels)

@@ -176,7 +176,8 @@ def test_tape_geometry_without_a_gpu():
     assert L.mk_tape_stride(32, 4) == 32 * 40 == 1280 and L.mk_tape_stride(14, 3) == 14 * 21
     assert L.mk_tape_supported(32, 4) == 1 and L.mk_tape_supported(14, 3) == 1
     assert L.mk_tape_supported(8, 2) == 0            # n <= 16: the 16-lane kernels
-    assert L.mk_tape_supported(48, 3) == 0           # N > 32: not a shape of the split filter
+    assert L.mk_tape_supported(48, 3) == 0           # served (round 5: up to 63 states) once the shape's module is registered
+    assert L.mk_tape_supported(61, 3) == 0           # rows 0..n-1 and the r row: n + 1 <= 64
     # the STATE tape (ABI 6, MK_OUT_TAPE | MK_OUT_VAR_ONLY): K more entries per block
     assert L.mk_state_tape_stride(32, 4) == 36 * 40 and L.mk_state_tape_stride(14, 3) == 17 * 21
     blk = np.arange(14 * 21, dtype=float)

@@ -305,6 +305,18 @@ def test_runtime_specialised_shapes(kf, N, K, tmp_path_factory, monkeypatch):
     for k, tol in (("F", FILT_ATOL), ("Pf", FILT_ATOL), ("Xp", FILT_ATOL), ("Pp", FILT_ATOL), ("S", SMOOTH_ATOL),
                    ("Ps", SMOOTH_ATOL), ("sigmas", 1e-10), ("detfs", 1e-10)):
         np.testing.assert_allclose(_np(r[k]), ref[k], rtol=0, atol=tol, err_msg=k)
+    if N + K > 16:
+        # wide shapes, (48,3) included (round 5: more than 32 series): the projection and the state moments over the tape
+        assert kf.tape_path() and kf.state_tape_path()
+        p = kf.simulate_smoothed(d["phi"], d["q"])
+        assert p.get("_tape")
+        Z = np.concatenate([np.broadcast_to(np.eye(N), (B, N, N)), d["loadings"]], axis=2)
+        np.testing.assert_allclose(_np(p["sim_means"]), np.einsum("bjn,btn->btj", Z, ref["S"]), rtol=0, atol=SMOOTH_ATOL)
+        np.testing.assert_allclose(_np(p["sim_vars"]), np.maximum(np.einsum("bjn,btnm,bjm->btj", Z, ref["Ps"], Z), 0.0), rtol=0, atol=SMOOTH_ATOL)
+        v = kf.smooth_state_variances(d["phi"], d["q"])
+        assert v.get("_tape")
+        np.testing.assert_allclose(_np(v["S"]), ref["S"], rtol=0, atol=SMOOTH_ATOL)
+        np.testing.assert_allclose(_np(v["var"]), np.diagonal(ref["Ps"], axis1=2, axis2=3), rtol=0, atol=SMOOTH_ATOL)
 
 
 def test_fused_projection_epilogue(kf, g1):
