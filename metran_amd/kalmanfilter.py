@@ -347,15 +347,7 @@ class SPKalmanFilter:
         float64 ``observation_indices``, int64 ``observation_count``) built without the Python
         loop over time steps, plus the NaN-encoded device copy the kernels read."""
         self.oseries_index = getattr(oseries, "index", None)
-        y = np.asarray(getattr(oseries, "values", oseries), dtype=np.float64)
-        # masked where not finite (:657); "+1e10 then nonzero()" also drops exactly -1e10 (:666-667)
-        valid = np.isfinite(y) & ((y + 1e10) != 0.0)
-        n_timesteps, dimobs = y.shape
-        self.observation_count = valid.sum(axis=1).astype(np.int64)
-        self.observations = np.where(valid, y, 0.0)
-        order = np.argsort(~valid, axis=1, kind="stable")  # valid indices first, ascending
-        packed = np.where(np.arange(dimobs)[None, :] < self.observation_count[:, None], order, 0)
-        self.observation_indices = packed.astype(np.float64)
+        self.observations, self.observation_indices, self.observation_count, valid, y = _observation_arrays(oseries)
         self._obs_nan = np.where(valid, y, np.nan)
         self._obs_dev = None  # device copy, uploaded once per set_observations (not per run_filter)
 
@@ -427,6 +419,30 @@ class SPKalmanFilter:
 _PATCHED = {}
 
 
+def _observation_arrays(oseries):
+    """The three arrays of ``SPKalmanFilter.set_observations`` (kalmanfilter.py:646-674) without its Python loop over the time
+    steps: ``observations`` (missing -> 0), float64 ``observation_indices`` (the observed series of a step first, ascending,
+    zeros behind), int64 ``observation_count``; and the validity mask and the float64 input they were built from."""
+    y = np.asarray(getattr(oseries, "values", oseries), dtype=np.float64)
+    # masked where not finite (:657); "+1e10 then nonzero()" also drops exactly -1e10 (:666-667)
+    valid = np.isfinite(y) & ((y + 1e10) != 0.0)
+    n_timesteps, dimobs = y.shape
+    count = valid.sum(axis=1).astype(np.int64)
+    observations = np.where(valid, y, 0.0)
+    order = np.argsort(~valid, axis=1, kind="stable")  # valid indices first, ascending
+    indices = np.where(np.arange(dimobs)[None, :] < count[:, None], order, 0).astype(np.float64)
+    return observations, indices, count, valid, y
+
+
+def set_observations_hip(self, oseries):
+    """``SPKalmanFilter.set_observations`` of the reference class (row a1; kalmanfilter.py:646-674): the same attributes,
+    built without the loop over the time steps and its masked-array arithmetic -- on examples/data (T = 6255) that loop is
+    ~70 ms, as much as the 77 objective evaluations of ``Metran.solve()`` on the HIP engine take together
+    (scripts/profile_dropin.py).  ``install`` binds it to the reference class."""
+    self.oseries_index = oseries.index   # (the reference reads .index too: :656)
+    self.observations, self.observation_indices, self.observation_count, _, _ = _observation_arrays(oseries)
+
+
 def install(metran_module=None):
     """Patch an imported reference so that ``Metran.solve()/get_simulation()/...`` run on the GPU.
 
@@ -434,13 +450,14 @@ def install(metran_module=None):
     whose ``__init__`` binds ``filtermethod`` to the module globals ``seqkalmanfilter_np`` /
     ``seqkalmanfilter`` (:501-504) and whose ``run_smoother`` resolves ``kalmansmoother`` at call
     time (:685) -- so replacing those three globals is sufficient for the filter and the smoother.  Row a9's two projection
-    methods of the class (``simulate`` / ``decompose``: Python loops over the time steps) are bound at class level as well."""
+    methods of the class (``simulate`` / ``decompose``) and row a1's ``set_observations`` -- Python loops over the time steps --
+    are bound at class level as well."""
     if metran_module is None:
         import metran as metran_module  # the reference, if importable
     km = metran_module.kalmanfilter
     if km not in _PATCHED:
         _PATCHED[km] = (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother, km.SPKalmanFilter.simulate,
-                        km.SPKalmanFilter.decompose)
+                        km.SPKalmanFilter.decompose, km.SPKalmanFilter.set_observations)
     km.seqkalmanfilter = seqkalmanfilter_hip
     km.seqkalmanfilter_np = seqkalmanfilter_hip
     km.kalmansmoother = kalmansmoother_hip
@@ -448,6 +465,8 @@ def install(metran_module=None):
     # bound at class level they serve every SPKalmanFilter the reference constructs (Metran.solve builds fresh ones)
     km.SPKalmanFilter.simulate = simulate_hip
     km.SPKalmanFilter.decompose = decompose_hip
+    # row a1: the observation arrays of a data set / mask, built once per Metran.solve() (metran.py:228-244)
+    km.SPKalmanFilter.set_observations = set_observations_hip
     return km
 
 
@@ -457,4 +476,4 @@ def uninstall(metran_module=None):
     km = metran_module.kalmanfilter
     if km in _PATCHED:
         (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother, km.SPKalmanFilter.simulate,
-         km.SPKalmanFilter.decompose) = _PATCHED.pop(km)
+         km.SPKalmanFilter.decompose, km.SPKalmanFilter.set_observations) = _PATCHED.pop(km)

@@ -112,7 +112,7 @@ def test_observation_packing_property(metran):
     from hypothesis.extra import numpy as hnp
 
     import oracle
-    from metran_amd.kalmanfilter import SPKalmanFilter, observations_to_nan_encoded
+    from metran_amd.kalmanfilter import SPKalmanFilter, observations_to_nan_encoded, set_observations_hip
 
     special = st.sampled_from([np.nan, np.inf, -np.inf, -1e10, np.nextafter(-1e10, 0.0), np.nextafter(-1e10, -np.inf), 0.0, -0.0,
                                1e10, 1e-300])
@@ -126,7 +126,12 @@ def test_observation_packing_property(metran):
         ref.set_observations(pd.DataFrame(y))
         kf = SPKalmanFilter.__new__(SPKalmanFilter)
         kf.set_observations(pd.DataFrame(y))
-        for got in ((kf.observations, kf.observation_indices, kf.observation_count), oracle.set_observations(y)):
+        patched = metran.kalmanfilter.SPKalmanFilter(engine="numpy")   # what install() binds to the reference class itself
+        set_observations_hip(patched, pd.DataFrame(y))
+        assert patched.oseries_index.equals(ref.oseries_index)
+        for got in ((kf.observations, kf.observation_indices, kf.observation_count), oracle.set_observations(y),
+                    (patched.observations, patched.observation_indices, patched.observation_count)):
+            assert got[0].dtype == ref.observations.dtype and got[1].dtype == ref.observation_indices.dtype and got[2].dtype == ref.observation_count.dtype
             np.testing.assert_array_equal(got[0], ref.observations)
             np.testing.assert_array_equal(got[1], ref.observation_indices)
             np.testing.assert_array_equal(got[2], ref.observation_count)
@@ -343,8 +348,11 @@ def test_install_patches_the_plug_points(metran):
 
     km = metran.kalmanfilter
     orig = (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother)
+    orig_cls = (km.SPKalmanFilter.simulate, km.SPKalmanFilter.decompose, km.SPKalmanFilter.set_observations)
     hip.install(metran)
     try:
+        assert km.SPKalmanFilter.set_observations is hip.set_observations_hip     # rows a1 / a9: class-level methods
+        assert km.SPKalmanFilter.simulate is hip.simulate_hip and km.SPKalmanFilter.decompose is hip.decompose_hip
         assert km.seqkalmanfilter is hip.seqkalmanfilter_hip
         assert km.seqkalmanfilter_np is hip.seqkalmanfilter_hip
         assert km.kalmansmoother is hip.kalmansmoother_hip
@@ -352,6 +360,7 @@ def test_install_patches_the_plug_points(metran):
     finally:
         hip.uninstall(metran)
     assert (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother) == orig
+    assert (km.SPKalmanFilter.simulate, km.SPKalmanFilter.decompose, km.SPKalmanFilter.set_observations) == orig_cls
 
 
 def test_ingest_matches_reference_metran(metran):
