@@ -99,7 +99,7 @@ def test_secondary_factor_analysis_and_calibration(line):
     assert "error" not in f1w and f1w["converged_frac"] > 0.95 and f1w["models_per_s"] >= 100.0, f1w
     # (round 5: 3.9 s for 512 models TO CONVERGENCE, 200 iterations -- profiles/r05/ab_line_search.log; the round-3 figure of
     # 2.75 s was 60 iterations with a third of the models converged)
-    assert f1["models_per_s"] >= 10000.0, f1    # round 5: 12-14 k (0.58-0.68 s for 8192 models); round 4: 10.9 k on its lease
+    assert f1["models_per_s"] >= 10000.0, f1    # round 5: 12-17 k (0.48-0.68 s for 8192 models); round 4: 10.9 k on its lease
 
 
 def test_secondary_dropin_configs0(line):
@@ -115,8 +115,10 @@ def test_secondary_dropin_configs0(line):
     assert abs(c1["hip_engine_scipy_solver"]["nfev"] - 77) <= 14
     assert c1["hip_solver_adjoint"]["nfev"] < 40
     # round 5: the single-record route walks the observed steps only, simulate / decompose run on the device:
-    # 0.164 s / 0.016 s measured through the unmodified class (round 4: 0.374 / 0.049); floors with a wide margin for a slow host
-    assert c1["hip_engine_scipy_solver"]["solve_s"] < 0.30 and c1["hip_engine_scipy_solver"]["get_simulation_s"] < 0.035, c1
+    # 0.164 s / 0.016 s measured through the unmodified class (round 4: 0.374 / 0.049), 0.093 s with the class's set_observations
+    # vectorised; the bars asked for were 0.15 / 0.02 -- floors with a margin for a slow host
+    assert c1["hip_engine_scipy_solver"]["solve_s"] < 0.15 and c1["hip_engine_scipy_solver"]["get_simulation_s"] < 0.03, c1
+    assert c1["hip_solver_fd"]["solve_s"] < 0.05, c1     # 0.010 s: plug point A no longer pays the 70 ms loop either
 
 
 def test_secondary_factor_analysis_wide(line):
