@@ -19,7 +19,8 @@ import numpy as np
 
 PATTERNS = ("none", "iid", "heavy", "steps", "series", "single", "first", "last", "both")
 AOT_SHAPES = [(8, 2), (5, 1), (2, 1), (3, 1), (4, 1), (6, 2), (14, 3), (32, 4)]
-JIT_SHAPES = [(7, 2), (20, 2)]   # both are built anyway by tests/test_hip_parity.py::test_runtime_specialised_shapes
+JIT_SHAPES = [(7, 2), (20, 2), (48, 3)]   # all built anyway by tests/test_hip_parity.py::test_runtime_specialised_shapes; (48,3): the
+# tape of a model with more than 32 series (round 5) -- appended, so that the groups drawn before it stay what they were
 
 
 def draw_model(rng, N, K, T, pattern):
