@@ -1,6 +1,6 @@
 """GPU tier: the HIP kernels under the property sweep the CPU restatements got.
 
-tests/hard_models.py draws >= 300 seeded models over every ahead-of-time shape plus two run-time-specialised ones:
+tests/hard_models.py draws >= 300 seeded models over every ahead-of-time shape plus three run-time-specialised ones:
 missingness from none to 95 %, empty first / last steps, never-observed series, a single observation, persistence up to
 1 - 1e-9, communalities up to 0.999, observation variances, non-default initial moments, records of one step.  Every model
 goes through every entry point that serves its shape, each against the oracle (C restatement of the reference,
