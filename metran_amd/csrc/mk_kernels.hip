@@ -1564,11 +1564,10 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
     const double phi_r = a.phi[inst * n + r];
     const double q_r = a.q[inst * n + r];
     const double lphi_r = log(phi_r); // -inf when phi underflowed to 0 at the lower bound: exp(-inf) = 0 below
-    double pp[n], qd[n], lpp[n];
+    double pp[n], qd[n];
     sfor<0, n>(MK_LAMBDA(c) {
         constexpr int cc = decltype(c)::value;
         pp[cc] = phi_r * Gp::template bcast<cc>(phi_r);
-        lpp[cc] = lphi_r + Gp::template bcast<cc>(lphi_r);
         qd[cc] = (cc == r) ? q_r : 0.0;
     });
     const double inv_em = 1.0 / expm1(2.0 * lphi_r); // 1/(phi_r^2 - 1)
@@ -1591,15 +1590,35 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
     for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == r ? 1.0 : 0.0);
 
     const int cnt = a.tlist[0];
-    const double *obase = a.obs + jr;
     double sum_sig = 0.0, run_mant = 1.0, fmin_seen = 1.0;
     long run_exp = 0, nobs = 0, tprev = -1;
-    double ynext = cnt > 0 ? obase[(long)a.tlist[1] * a.ostep] : 0.0;
+    // The observed steps come through LDS, a tile of 256 at a time: every thread of the workgroup fetches ONE step (its time index
+    // from the list, then its N observations -- every instance shares the record) and all sixteen groups walk the tile.  Fetched
+    // per step inside the walk (rounds 3-5: the next step's index and observation one iteration ahead), the two dependent loads
+    // were the walk's critical path -- 1.1 us per observed step for ~0.4 us of arithmetic -- and, in the record-writing form,
+    // every consumed load waited for the older record stores (vmcnt retires in order).
+    constexpr int TSP = 256;
+    __shared__ int s_t[TSP];
+    __shared__ double s_y[TSP * N];
 
-    for (int i = 0; i < cnt; ++i) {
-        const long t = a.tlist[1 + i];
-        const double y = ynext;
-        if (i + 1 < cnt) ynext = obase[(long)a.tlist[2 + i] * a.ostep];
+    for (int i0 = 0; i0 < cnt; i0 += TSP) {
+    __syncthreads(); // the previous tile has been walked by every group
+    {
+        const int idx = i0 + (int)threadIdx.x;
+        if (idx < cnt) {
+            const int tt = a.tlist[1 + idx];
+            s_t[threadIdx.x] = tt;
+            const double *src = a.obs + (long)tt * a.ostep;
+#pragma unroll
+            for (int j = 0; j < N; ++j) s_y[threadIdx.x * N + j] = src[j];
+        }
+    }
+    __syncthreads();
+    const int iend = cnt - i0 < TSP ? cnt - i0 : TSP;
+    for (int s_ = 0; s_ < iend; ++s_) {
+        const int i = i0 + s_;
+        const long t = s_t[s_];
+        const double y = s_y[s_ * N + jr];
         const long gap = t - tprev;
         tprev = t;
         if (gap == 1) { // ordinary predict (:318-331)
@@ -1607,11 +1626,16 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
 #pragma unroll
             for (int c = 0; c < n; ++c) P[c] = fma(P[c], pp[c], qd[c]);
         } else { // gap - 1 empty steps and the predict of step t in one go
+            // (phi_r phi_c)^gap as the product of the two lanes' phi^gap: ONE exponential per lane and n broadcast products
+            // instead of n exponentials (an f64 exp is ~45 instructions; six of them were half of this walk's time per step)
             const double g = (double)gap;
-            x *= exp(g * lphi_r);
+            const double er = exp(g * lphi_r);
+            x *= er;
             const double qg = q_r * expm1(2.0 * g * lphi_r) * inv_em;
-#pragma unroll
-            for (int c = 0; c < n; ++c) P[c] = fma(P[c], exp(g * lpp[c]), c == r ? qg : 0.0);
+            sfor<0, n>(MK_LAMBDA(c) {
+                constexpr int cc = decltype(c)::value;
+                P[cc] = fma(P[cc], er * Gp::template bcast<cc>(er), cc == r ? qg : 0.0);
+            });
         }
         const unsigned long long ball = __ballot(lane < N && isfinite(y));
         const auto vm = Gp::group_bits(ball);
@@ -1670,6 +1694,7 @@ __global__ void __launch_bounds__(256) loglik_sparse_kernel(SparseArgs a)
             run_mant = __builtin_amdgcn_frexp_mant(run_mant);
         }
         if (t >= a.warmup) nobs += __popcll((unsigned long long)vm); // TIME index (:565)
+    }
     }
     if (lead) {
         const double sum_det = fma((double)run_exp, kLn2, log(run_mant));

@@ -26,7 +26,8 @@ def _sparse_record(N, K, T, seed, keep_every, first):
 
 
 @pytest.mark.parametrize("N,K,T,keep_every,first", [(5, 1, 900, 18, True), (5, 1, 400, 9, False), (8, 2, 600, 25, False),
-                                                    (2, 1, 300, 3, True), (8, 2, 200, 1, True), (3, 1, 50, 50, False)])
+                                                    (2, 1, 300, 3, True), (8, 2, 200, 1, True), (3, 1, 50, 50, False),
+                                                    (5, 1, 1400, 2, True), (8, 2, 600, 1, False)])   # 700 / 600 observed steps: several LDS tiles of 256
 def test_sparse_objective_equals_the_oracle(N, K, T, keep_every, first):
     from metran_amd.engine import BatchedKalman
 
@@ -102,7 +103,8 @@ def test_observed_step_list_is_cached_per_record_and_invalidated(g1):
     assert abs(fresh - ref) < 1e-8 and stale == first and abs(first - ref) > 1e-3
 
 
-@pytest.mark.parametrize("N,K,T,keep_every,first", [(5, 1, 400, 17, "observed"), (8, 2, 300, 5, "empty"), (3, 1, 120, 1, "observed"), (14, 2, 90, 7, "empty")])
+@pytest.mark.parametrize("N,K,T,keep_every,first", [(5, 1, 400, 17, "observed"), (8, 2, 300, 5, "empty"), (3, 1, 120, 1, "observed"), (14, 2, 90, 7, "empty"),
+                                                    (5, 1, 1300, 2, "observed"), (8, 2, 513, 1, "empty")])   # > 256 observed steps: several LDS tiles
 def test_single_record_filter_walks_the_observed_steps(N, K, T, keep_every, first):
     """The record-writing filter of ONE record (the engine route of Metran.solve: mk_filter, <= 16 instances, all four state
     arrays): observed steps walked one after the other, the records of the empty steps written in closed form by a second
