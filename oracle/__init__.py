@@ -124,27 +124,33 @@ def decompose(observation_matrix, means):
     return sdf, cdf
 
 
-def dfm_batch(obs, phi, q, loadings, obsvar=None, warmup=1, smooth=True, outputs="all", native=False):
+def dfm_batch(obs, phi, q, loadings, obsvar=None, warmup=1, smooth=True, outputs="all", native=False, out=None):
     """B independent Metran DFMs through the reference algorithm (see C ``oracle_dfm_batch``).
 
-    outputs: "all" | "means" | "mle".  Returns a dict.
+    outputs: "all" | "means" | "mle".  Returns a dict.  ``out``: the dict of an earlier call of the same size, written again
+    (bench.py's CPU leg times a pass that does not pay the page faults of fresh output memory).
     """
     obs, phi, q, loadings = _c(obs), _c(phi), _c(q), _c(loadings)
     B, T, N = obs.shape
     K = loadings.shape[2]
     n = N + K
-    res = dict(mle=np.empty(B), sigmas=np.empty((B, T)), detfs=np.empty((B, T)),
-               sigmacount=np.empty(B, dtype=np.int64))
+    shapes = dict(mle=(B,), sigmas=(B, T), detfs=(B, T), sigmacount=(B,))
     big = outputs == "all"
     mid = outputs in ("all", "means")
     if mid:
-        res.update(F=np.empty((B, T, n)), Xp=np.empty((B, T, n)))
+        shapes.update(F=(B, T, n), Xp=(B, T, n))
         if smooth:
-            res["S"] = np.empty((B, T, n))
+            shapes["S"] = (B, T, n)
     if big:
-        res.update(Pf=np.empty((B, T, n, n)), Pp=np.empty((B, T, n, n)))
+        shapes.update(Pf=(B, T, n, n), Pp=(B, T, n, n))
         if smooth:
-            res["Ps"] = np.empty((B, T, n, n))
+            shapes["Ps"] = (B, T, n, n)
+    if out is not None:
+        if any(k not in out or out[k].shape != sh or not out[k].flags.c_contiguous for k, sh in shapes.items()):
+            raise ValueError("out does not hold the arrays of this call")
+        res = {k: out[k] for k in shapes}
+    else:
+        res = {k: np.empty(sh, dtype=np.int64 if k == "sigmacount" else np.float64) for k, sh in shapes.items()}
     ov = None if obsvar is None else _c(obsvar)
     load(native).oracle_dfm_batch(
         i64(B), i64(T), i64(N), i64(K), _d(obs), _d(phi), _d(q), _d(loadings), _d(ov), i64(warmup),
@@ -156,6 +162,10 @@ def dfm_batch(obs, phi, q, loadings, obsvar=None, warmup=1, smooth=True, outputs
 
 def num_threads(native=False):
     return int(load(native).oracle_num_threads())
+
+
+def set_num_threads(t, native=False):
+    load(native).oracle_set_num_threads(ctypes.c_int(int(t)))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -177,21 +187,27 @@ def load_fast(native=False):
     return _FAST[native]
 
 
-def fast_dfm_batch(obs, phi, q, loadings, warmup=1, outputs="all", native=False):
+def fast_dfm_batch(obs, phi, q, loadings, warmup=1, outputs="all", native=False, out=None):
     """B models through oracle/kalman_fast.c.  outputs: "all" (six state arrays) | "means" (projected smoothed means /
     variances) | "mle".  Returns a dict (with ``bad`` = number of models the fast path cannot serve: a non-positive
-    innovation variance or a predicted covariance that is not positive definite)."""
+    innovation variance or a predicted covariance that is not positive definite).  ``out``: the dict of an earlier call of
+    the same size, whose arrays are written again (a timing that should not include the page faults of fresh output memory)."""
     obs, phi, q, loadings = _c(obs), _c(phi), _c(q), _c(loadings)
     B, T, N = obs.shape
     K = loadings.shape[2]
     n = N + K
-    res = dict(mle=np.empty(B))
     mode = {"mle": 0, "means": 1, "all": 2}[outputs]
+    shapes = dict(mle=(B,))
     if mode == 2:
-        res.update(F=np.empty((B, T, n)), Xp=np.empty((B, T, n)), S=np.empty((B, T, n)), Pf=np.empty((B, T, n, n)),
-                   Pp=np.empty((B, T, n, n)), Ps=np.empty((B, T, n, n)))
+        shapes.update(F=(B, T, n), Xp=(B, T, n), S=(B, T, n), Pf=(B, T, n, n), Pp=(B, T, n, n), Ps=(B, T, n, n))
     if mode == 1:
-        res.update(sim_means=np.empty((B, T, N)), sim_vars=np.empty((B, T, N)))
+        shapes.update(sim_means=(B, T, N), sim_vars=(B, T, N))
+    if out is not None:
+        if any(k not in out or out[k].shape != sh or not out[k].flags.c_contiguous for k, sh in shapes.items()):
+            raise ValueError("out does not hold the arrays of this call")
+        res = {k: out[k] for k in shapes}
+    else:
+        res = {k: np.empty(sh) for k, sh in shapes.items()}
     res["bad"] = int(load_fast(native).fast_dfm_batch(
         i64(B), i64(T), i64(N), i64(K), _d(obs), _d(phi), _d(q), _d(loadings), i64(warmup), ctypes.c_int(mode), _d(res["mle"]),
         _d(res.get("F")), _d(res.get("Pf")), _d(res.get("Xp")), _d(res.get("Pp")), _d(res.get("S")), _d(res.get("Ps")),
@@ -201,3 +217,7 @@ def fast_dfm_batch(obs, phi, q, loadings, warmup=1, outputs="all", native=False)
 
 def fast_num_threads(native=False):
     return int(load_fast(native).fast_num_threads())
+
+
+def fast_set_num_threads(t, native=False):
+    load_fast(native).fast_set_num_threads(ctypes.c_int(int(t)))

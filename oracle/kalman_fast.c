@@ -249,3 +249,10 @@ FAST_API int fast_num_threads(void)
     return 1;
 #endif
 }
+
+/* (bench.py: the thread count of the timed pass -- a box whose CPU quota is below its core count is timed per thread count) */
+FAST_API void fast_set_num_threads(int t)
+{
+    if (t > 0) omp_set_num_threads(t);
+}
+

@@ -338,6 +338,16 @@ ORACLE_API int oracle_num_threads(void)
 #endif
 }
 
+ORACLE_API void oracle_set_num_threads(int t)
+{
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
+
 ORACLE_API void oracle_dfm_batch(int64_t B, int64_t T, int64_t N, int64_t K,
                                  const double *obs,      /* [B,T,N] NaN = missing */
                                  const double *phi,      /* [B,n] */
