@@ -23,6 +23,25 @@ c_ip = ctypes.POINTER(ctypes.c_int64)
 i64 = ctypes.c_int64
 
 
+def usable_cpus():
+    """CPUs this process may use: its affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host with a
+    quota of 16 runs 128 OpenMP threads slower than 16: profiles/r05/cpu_leg_threads.log)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = min(n, max(1, int(round(float(q) / float(p)))))
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def build(native=False):
     subprocess.check_call(["make", "-C", _HERE] + (["native"] if native else []),
                           stdout=subprocess.DEVNULL)
@@ -39,6 +58,8 @@ def load(native=False):
     lib = ctypes.CDLL(path)
     lib.oracle_get_mle.restype = ctypes.c_double
     lib.oracle_num_threads.restype = ctypes.c_int
+    if lib.oracle_num_threads() > usable_cpus():   # (the checker's OpenMP loops: no more threads than CPUs it may use)
+        lib.oracle_set_num_threads(ctypes.c_int(usable_cpus()))
     if not native:
         _LIB = lib
     return lib
@@ -183,6 +204,8 @@ def load_fast(native=False):
         lib = ctypes.CDLL(path)
         lib.fast_dfm_batch.restype = ctypes.c_int64
         lib.fast_num_threads.restype = ctypes.c_int
+        if lib.fast_num_threads() > usable_cpus():
+            lib.fast_set_num_threads(ctypes.c_int(usable_cpus()))
         _FAST[native] = lib
     return _FAST[native]
 
