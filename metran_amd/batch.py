@@ -100,7 +100,10 @@ class MetranBatch:
 
     def solve(self, **kwargs):
         """``Metran.solve`` (metran.py:991-1045) for all models in lock-step (``calibrate_batch``);
-        the optimum becomes the default parameter set of the accessors.  Returns the CalibrationResult."""
+        the optimum becomes the default parameter set of the accessors.  Returns the CalibrationResult.
+        Keyword arguments go to ``calibrate_batch``; ``fd_below=4096`` (2048 for models of more than 16 states) lets the last
+        stragglers finish on differenced gradients -- what the reference's own solver uses throughout -- and is what
+        ``bench.py``'s calibration lines are measured with."""
         kwargs.setdefault("dt", self.dt)
         self.fit = calibrate_batch(self.kf, **kwargs)
         self.alpha = self.fit.alpha
