@@ -797,7 +797,15 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
     kf = BatchedKalman(local_rank, layout="time_major")
     try:
         kf.set_observations(d["obs"]).set_loadings(d["loadings"])
-        calibrate_batch(kf, maxiter=2)  # warm-up
+        calibrate_batch(kf, maxiter=2)  # warm-up: kernel load, allocator
+        # ... and the compaction path, which two iterations do not reach: the first gather / nonzero of a process loads those
+        # torch kernels (~100 ms, once per process -- not a cost of the calibration)
+        warm = kf.subset(torch.arange(B, device=dev)[torch.ones(B, dtype=torch.bool, device=dev)].nonzero().squeeze(1)[: max(2, B // 2)])
+        calibrate_batch(warm, maxiter=1)
+        warm.close()
+        warm = kf.subset(torch.arange(min(B, 8), device=dev))     # ... and the differenced tail's (several step lengths per launch)
+        calibrate_batch(warm, maxiter=2, fd_below=10 ** 9)
+        warm.close()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fd_below = 4096 if N + K <= 16 else 2048   # (differenced gradients for the last stragglers: one round of wavefronts)

@@ -336,6 +336,14 @@ class BatchedKalman:
         sub.set_loadings(self.loadings[index], None if self.obsvar is None else self.obsvar[index])
         if self.scale is not None:
             sub.scale, sub.offset = self.scale[index].contiguous(), self.offset[index].contiguous()
+        # the sub-engine takes over the parent's adjoint workspace (a subset never needs more of it; at 8192 x (8,2), T = 1000 it is
+        # 7.3 GB, and a fresh 3 GB allocation for the first compacted flight was the largest single item of a calibration's wall
+        # time).  The two are used one after the other (calibrate_batch returns to the parent when the flight has finished); a
+        # forward pass still waiting for its backward pass on the parent is void from here on.
+        work = getattr(self, "_grad_work", None)
+        if work is not None:
+            sub._grad_work = work
+            self._grad_pending = None
         return sub
 
     @property

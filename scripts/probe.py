@@ -102,6 +102,12 @@ def calibrate(a):
     N, K = (int(v) for v in a.shape.split(","))
     kf, d = _engine(N, K, a.T, a.batch, a.missing, "time_major", seed=5000)
     calibrate_batch(kf, maxiter=2)
+    warm = kf.subset(torch.ones(a.batch, dtype=torch.bool, device=kf.device).nonzero().squeeze(1)[: max(2, a.batch // 2)])   # the compaction path's torch kernels
+    calibrate_batch(warm, maxiter=1)
+    warm.close()
+    warm = kf.subset(torch.arange(min(a.batch, 8), device=kf.device))   # ... and the differenced tail's
+    calibrate_batch(warm, maxiter=2, fd_below=10 ** 9)
+    warm.close()
     if a.fd_below is None:
         a.fd_below = 4096 if N + K <= 16 else 2048
     stamps, real_print = [], builtins.print
@@ -119,7 +125,7 @@ def calibrate(a):
     f, fn, s, sn = kf.kernel_ms_totals()
     prev = t0
     for k, (t, line) in enumerate(stamps):
-        if k % 5 == 0 or k > len(stamps) - 5:
+        if a.trace_all or k % 5 == 0 or k > len(stamps) - 5:
             print("it %3d active %5s  %.2f ms" % (k + 1, line.split("active")[1].split()[0], 1e3 * (t - prev)))
         prev = t
     print(json.dumps({"models": a.batch, "shape": [N, K], "seconds": dt, "models_per_s": a.batch / dt, "nit": int(res.nit),
@@ -188,6 +194,7 @@ if __name__ == "__main__":
     p.add_argument("--maxiter", type=int, default=200)
     p.add_argument("--own-above", type=int, default=None, help="own line search per model above this flight size")
     p.add_argument("--trace", action="store_true")
+    p.add_argument("--trace-all", action="store_true", help="with --trace: every iteration's line, not every fifth")
     p.set_defaults(fn=calibrate)
     sub.add_parser("dropin").set_defaults(fn=dropin)
     p = sub.add_parser("factor")
