@@ -99,7 +99,7 @@ def test_secondary_factor_analysis_and_calibration(line):
     assert "error" not in f1w and f1w["converged_frac"] > 0.95 and f1w["models_per_s"] >= 100.0, f1w
     # (round 5: 3.9 s for 512 models TO CONVERGENCE, 200 iterations -- profiles/r05/ab_line_search.log; the round-3 figure of
     # 2.75 s was 60 iterations with a third of the models converged)
-    assert f1["models_per_s"] >= 10000.0, f1    # round 5: 12-17 k (0.48-0.68 s for 8192 models); round 4: 10.9 k on its lease
+    assert f1["models_per_s"] >= 10000.0, f1    # round 5: 12-18.6 k (0.44-0.68 s for 8192 models); round 4: 10.9 k on its lease
 
 
 def test_secondary_dropin_configs0(line):
