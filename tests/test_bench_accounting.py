@@ -92,3 +92,21 @@ def test_kernel_source_sha_covers_every_kernel_source():
             continue    # not filter / smoother kernels of a bench configuration (mk_generic: unspecialised shapes; mk_lbfgs: the calibration driver)
         assert ("metran_amd/csrc/" + name) in listed, name
     assert len(bench.kernel_source_sha()) == 16
+
+
+def test_cpu_legs_take_the_cpus_the_process_may_use():
+    """bench.py's CPU legs and the oracle's OpenMP loops start no more threads than the process may use -- its affinity mask,
+    capped by the cgroup CPU quota (the GPU boxes: 256 hardware threads, quota 16; 128 threads ran at 0.6 x the rate of 16,
+    profiles/r05/cpu_leg_threads.log)."""
+    import os
+
+    import bench
+    import oracle
+
+    logical, quota = bench.host_cpus()
+    assert logical >= 1 and (quota is None or quota > 0)
+    t = bench.cpu_leg_threads(128)
+    assert 1 <= t <= min(128, logical) and (quota is None or t <= max(1, round(quota)))
+    assert bench.cpu_leg_threads(1) == 1
+    assert 1 <= oracle.usable_cpus() <= (os.cpu_count() or 1)
+    assert oracle.num_threads() <= oracle.usable_cpus() and oracle.fast_num_threads() <= oracle.usable_cpus()
