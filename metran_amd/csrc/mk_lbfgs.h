@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define MK_LBFGS_MAX_N 64  /* parameters per model (= states: one alpha per state) */
+#define MK_LBFGS_MAX_N 128 /* parameters per model (= states: one alpha per state; the size-generic kernels serve 128) */
 #define MK_LBFGS_MAX_H 16  /* history pairs per model (ring slots) */
 
 namespace mk {
