@@ -361,6 +361,10 @@ def test_install_patches_the_plug_points(metran):
         hip.uninstall(metran)
     assert (km.seqkalmanfilter, km.seqkalmanfilter_np, km.kalmansmoother) == orig
     assert (km.SPKalmanFilter.simulate, km.SPKalmanFilter.decompose, km.SPKalmanFilter.set_observations) == orig_cls
+    # the bound set_observations fails where the reference's does: a bare array has no .index (kalmanfilter.py:656)
+    for fn in (km.SPKalmanFilter.set_observations, hip.set_observations_hip):
+        with pytest.raises(AttributeError):
+            fn(km.SPKalmanFilter(engine="numpy"), np.zeros((3, 2)))
 
 
 def test_ingest_matches_reference_metran(metran):
