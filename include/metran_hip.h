@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define MK_API __attribute__((visibility("default")))
-#define MK_ABI_VERSION 6
+#define MK_ABI_VERSION 7
 
 typedef enum mk_status {
     MK_OK = 0,
@@ -348,8 +348,32 @@ MK_API int mk_decompose(mk_context *ctx, int64_t B, int64_t RZ, int64_t T, int64
                         double *d_sdf /* [B,T,N] */, double *d_cdf /* [B,n-N,T,N] */);
 
 /* Sum of d_mle over the local batch in a fixed order (deterministic tree), for the summed
- * objective fed back to the solver; the cross-GPU all-reduce is done by the host with RCCL. */
+ * objective fed back to the solver; mk_allreduce_sum below combines the ranks. */
 MK_API int mk_sum(mk_context *ctx, int64_t count, const double *d_values, double *d_result /* [1] */);
+
+/* ---- the one collective of the path (SURVEY.md 8b "mk_allreduce_sum(ctx, buf, count) (RCCL) or accept an external
+ * communicator", 8e): one process per GPU, every model independent, so the only exchange is the summed objective of a
+ * shared-parameter calibration -- 1 double, or P + 1 with the adjoint gradient -- fed back to the solver
+ * (metran/solver.py:42-63 has one process and no counterpart).  The communicator is RCCL's (ncclComm_t, passed as void *
+ * so that this header needs no rccl.h); librccl is bound with dlopen at the first of these calls, preferring a copy the
+ * process has already loaded (e.g. PyTorch-ROCm's), so a single-GPU caller never maps it.
+ *   mk_comm_set_library    (optional, before the first call below) the path of the librccl.so to bind; the library reads
+ *                          no environment variable
+ *   mk_comm_unique_id      ncclGetUniqueId into a caller buffer of 128 bytes: ONE rank calls it and hands the bytes to
+ *                          the others by whatever side channel the job has (a file, MPI, torch.distributed's store)
+ *   mk_comm_init_rank      ncclCommInitRank for this context's device; collective (every rank calls it with the same
+ *                          id); the context owns the communicator and destroys it in mk_comm_destroy / mk_destroy
+ *   mk_set_communicator    use a communicator the CALLER created and keeps owning (a raw librccl one); NULL detaches
+ *   mk_allreduce_sum       in-place all-reduce(sum, float64) of d_buf[count] over the communicator's ranks, ordered on
+ *                          the context's stream (mk_set_stream); asynchronous like every launch (mk_sync to wait).
+ *                          Without a communicator it FAILS (MK_ERR_INVALID): there is no silent single-rank shortcut --
+ *                          a group of one rank still runs the collective, as on eight */
+MK_API int mk_comm_set_library(const char *path);
+MK_API int mk_comm_unique_id(void *id128 /* [128 bytes] */);
+MK_API int mk_comm_init_rank(mk_context *ctx, int nranks, int rank, const void *id128);
+MK_API int mk_set_communicator(mk_context *ctx, void *nccl_comm);
+MK_API int mk_comm_destroy(mk_context *ctx);
+MK_API int mk_allreduce_sum(mk_context *ctx, double *d_buf, int64_t count);
 
 /* ---- observation ingestion (what precedes the filter; batched) ------------------------------ */
 /* Metran.standardize (metran/metran.py:102-121) for R models: per series, subtract the mean and

@@ -108,6 +108,12 @@ API = {
     "mk_decompose": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "mk_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mk_comm_set_library": (c_int, [c_char_p]),
+    "mk_comm_unique_id": (c_int, [c_void_p]),
+    "mk_comm_init_rank": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "mk_set_communicator": (c_int, [c_void_p, c_void_p]),
+    "mk_comm_destroy": (c_int, [c_void_p]),
+    "mk_allreduce_sum": (c_int, [c_void_p, c_void_p, c_int64]),
     "mk_loglik_grad": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_loglik_grad_phases": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int]),
@@ -138,7 +144,7 @@ API = {
     "mk_kernel_ms_totals": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
 }
 
-ABI_VERSION = 6  # MK_ABI_VERSION of include/metran_hip.h
+ABI_VERSION = 7  # MK_ABI_VERSION of include/metran_hip.h
 _lib = None
 
 

@@ -33,6 +33,8 @@ struct mk_context {
     double *gws;       // workspace of the size-generic smoother (mk_generic.hip), grown on demand
     size_t gws_cap;    // ... in doubles
     int *lb_counters;  // device int[4] of the L-BFGS kernels (mk_lbfgs.hip)
+    void *comm;        // RCCL communicator of mk_allreduce_sum (ncclComm_t), nullptr = none
+    bool comm_owned;   // created by mk_comm_init_rank (destroyed with the context) or handed in by mk_set_communicator
 };
 
 static thread_local char g_err[512] = "";
@@ -269,6 +271,8 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->gws = nullptr;
     ctx->gws_cap = 0;
     ctx->lb_counters = nullptr;
+    ctx->comm = nullptr;
+    ctx->comm_owned = false;
     for (int &v : ctx->variant) v = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
@@ -277,6 +281,144 @@ MK_API int mk_create(int device, mk_context **out)
         }
     }
     *out = ctx;
+    return MK_OK;
+}
+
+// ---- the one collective of the design: all-reduce(sum, f64) of the summed objective over the ranks ----
+// librccl is bound at first use with dlopen -- the library has no link-time dependency on it, so a single-GPU caller never
+// loads it -- preferring a copy the process has already mapped (PyTorch-ROCm ships its own librccl.so: two RCCL runtimes in
+// one process would each bootstrap their own network state).  Only the five entry points below are used; their
+// signatures are RCCL's public C API (rccl/rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220, ncclCommDestroy :260,
+// ncclAllReduce, ncclGetErrorString :339), restated here so that the header is not needed to build.
+namespace {
+struct RcclUniqueId {
+    char internal[128]; // NCCL_UNIQUE_ID_BYTES
+};
+struct RcclApi {
+    void *handle;
+    int (*GetUniqueId)(RcclUniqueId *);
+    int (*CommInitRank)(void **, int, RcclUniqueId, int);
+    int (*CommDestroy)(void *);
+    int (*AllReduce)(const void *, void *, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, void *, hipStream_t);
+    const char *(*GetErrorString)(int);
+    char why[256];
+};
+RcclApi g_rccl = {};
+char g_rccl_path[1024] = "";
+std::mutex g_rccl_mutex;
+constexpr int kNcclFloat64 = 8, kNcclSum = 0; // rccl.h: ncclFloat64 = 8, ncclSum = 0
+
+const RcclApi *rccl_api()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return &g_rccl;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    if (g_rccl_path[0]) h = dlopen(g_rccl_path, RTLD_NOW | RTLD_GLOBAL);
+    for (int pass = 0; pass < 2 && !h; ++pass) // pass 0: a copy that is already mapped; pass 1: load one
+        for (const char *nm : names) {
+            h = dlopen(nm, (pass == 0 ? RTLD_NOLOAD : 0) | RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+    if (!h) {
+        snprintf(g_rccl.why, sizeof(g_rccl.why), "librccl.so could not be loaded (%s); name it with mk_comm_set_library", dlerror());
+        return nullptr;
+    }
+    RcclApi a = {};
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
+        snprintf(g_rccl.why, sizeof(g_rccl.why), "the loaded librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / "
+                                                 "ncclAllReduce / ncclGetErrorString");
+        return nullptr;
+    }
+    a.handle = h;
+    g_rccl = a;
+    return &g_rccl;
+}
+} // namespace
+
+#define MK_RCCL(api, call)                                                                          \
+    do {                                                                                            \
+        const int r_ = (call);                                                                      \
+        if (r_ != 0) return fail(MK_ERR_HIP, "%s: RCCL error %d: %s", #call, r_, (api)->GetErrorString(r_)); \
+    } while (0)
+
+MK_API int mk_comm_set_library(const char *path)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return fail(MK_ERR_INVALID, "mk_comm_set_library: librccl is already bound in this process");
+    if (!path || strlen(path) >= sizeof(g_rccl_path)) return fail(MK_ERR_INVALID, "mk_comm_set_library: bad path");
+    strcpy(g_rccl_path, path);
+    return MK_OK;
+}
+
+MK_API int mk_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(MK_ERR_INVALID, "mk_comm_unique_id: null buffer (128 bytes)");
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(MK_ERR_HIP, "mk_comm_unique_id: %s", g_rccl.why);
+    RcclUniqueId id;
+    MK_RCCL(api, api->GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return MK_OK;
+}
+
+MK_API int mk_comm_destroy(mk_context *ctx)
+{
+    if (!ctx) return fail(MK_ERR_INVALID, "null mk_context");
+    if (ctx->comm && ctx->comm_owned) {
+        const RcclApi *api = rccl_api();
+        if (api) {
+            (void)hipSetDevice(ctx->device);
+            (void)api->CommDestroy(ctx->comm);
+        }
+    }
+    ctx->comm = nullptr;
+    ctx->comm_owned = false;
+    return MK_OK;
+}
+
+MK_API int mk_comm_init_rank(mk_context *ctx, int nranks, int rank, const void *id128)
+{
+    MK_CTX(ctx);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id128)
+        return fail(MK_ERR_INVALID, "mk_comm_init_rank: bad argument (nranks %d, rank %d)", nranks, rank);
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(MK_ERR_HIP, "mk_comm_init_rank: %s", g_rccl.why);
+    (void)mk_comm_destroy(ctx);
+    RcclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    void *comm = nullptr;
+    MK_RCCL(api, api->CommInitRank(&comm, nranks, id, rank)); // collective: every rank of the job calls it
+    ctx->comm = comm;
+    ctx->comm_owned = true;
+    return MK_OK;
+}
+
+MK_API int mk_set_communicator(mk_context *ctx, void *nccl_comm)
+{
+    if (!ctx) return fail(MK_ERR_INVALID, "null mk_context");
+    (void)mk_comm_destroy(ctx); // an owned communicator is released; a borrowed one is just forgotten
+    ctx->comm = nccl_comm;      // the caller keeps ownership (ncclCommDestroy is the caller's to call, after mk_destroy / a detach)
+    ctx->comm_owned = false;
+    return MK_OK;
+}
+
+MK_API int mk_allreduce_sum(mk_context *ctx, double *d_buf, int64_t count)
+{
+    if (!ctx) return fail(MK_ERR_INVALID, "null mk_context");
+    if (!ctx->comm)
+        return fail(MK_ERR_INVALID, "mk_allreduce_sum: this context has no communicator -- call mk_comm_init_rank (every rank, with "
+                                    "the id of mk_comm_unique_id) or mk_set_communicator first; there is no single-rank shortcut");
+    if (!d_buf || count <= 0) return fail(MK_ERR_INVALID, "mk_allreduce_sum: bad argument");
+    MK_HIP(hipSetDevice(ctx->device));
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(MK_ERR_HIP, "mk_allreduce_sum: %s", g_rccl.why);
+    MK_RCCL(api, api->AllReduce(d_buf, d_buf, (size_t)count, kNcclFloat64, kNcclSum, ctx->comm, ctx->stream)); // in place, stream-ordered
     return MK_OK;
 }
 
@@ -294,6 +436,7 @@ MK_API int mk_destroy(mk_context *ctx)
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     if (ctx->gws) (void)hipFree(ctx->gws);
     if (ctx->lb_counters) (void)hipFree(ctx->lb_counters);
+    (void)mk_comm_destroy(ctx);
     delete ctx;
     return MK_OK;
 }

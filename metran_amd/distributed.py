@@ -10,7 +10,8 @@ combines the ranks.  The reference has no counterpart (single process, metran/so
 """
 import os
 
-__all__ = ["shard_range", "init_from_env", "world", "allreduce_sum", "gather_concat", "run_sharded", "ShardedObjective"]
+__all__ = ["shard_range", "init_from_env", "world", "allreduce_sum", "gather_concat", "run_sharded", "ShardedObjective",
+           "attach_communicator"]
 
 
 def shard_range(n_items, rank, world_size):
@@ -70,12 +71,32 @@ def run_sharded(n_items, local_fn):
     return out
 
 
-def allreduce_sum(t):
-    """In-place all-reduce(sum) of a tensor over the default group; no-op when no process group exists.  With a group
-    of ONE rank the collective still runs (an identity, bit for bit): a job launched by torchrun on one GPU exercises
-    the same RCCL call as on eight."""
+def attach_communicator(engine):
+    """Give ``engine`` (a ``BatchedKalman``) the library's own RCCL communicator over the ranks of the default process
+    group (C ABI ``mk_comm_unique_id`` / ``mk_comm_init_rank``): rank 0 draws the 128-byte id, the group's own channel
+    carries it to the others (``broadcast_object_list``: works on gloo and nccl alike), every rank joins.  From then on
+    ``allreduce_sum(t, engine)`` runs ``mk_allreduce_sum`` -- the collective a C caller of the library gets -- instead of
+    ``torch.distributed.all_reduce``.  Without a process group the engine forms a communicator of one rank."""
     import torch.distributed as dist
 
+    rank, size = world()
+    ident = [engine.comm_unique_id() if rank == 0 else None]
+    if dist.is_available() and dist.is_initialized():
+        dist.broadcast_object_list(ident, src=0)
+    engine.init_communicator(size, rank, ident[0])
+    return engine
+
+
+def allreduce_sum(t, engine=None):
+    """In-place all-reduce(sum) of a tensor.  With an ``engine`` that carries a communicator (``attach_communicator``):
+    the C ABI's ``mk_allreduce_sum`` on the engine's stream.  Otherwise over the default process group
+    (``torch.distributed``: "nccl" = RCCL on ROCm, gloo in the CPU tests); no-op when no group exists.  With a group of
+    ONE rank the collective still runs (an identity, bit for bit): a job launched by torchrun on one GPU exercises the
+    same RCCL call as on eight."""
+    import torch.distributed as dist
+
+    if engine is not None and engine.has_communicator():
+        return engine.allreduce_sum(t)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
@@ -109,14 +130,15 @@ class ShardedObjective:
     (``BatchedKalman.sum``); the ranks are combined with one all-reduce.
     """
 
-    def __init__(self, local_loglik, local_sum=None):
+    def __init__(self, local_loglik, local_sum=None, engine=None):
         self.local_loglik = local_loglik
         self.local_sum = local_sum or (lambda v: v.sum())
+        self.engine = engine   # a BatchedKalman with a communicator: the all-reduce goes through the C ABI (mk_allreduce_sum)
 
     def __call__(self, params):
         vals = self.local_loglik(params)
         total = self.local_sum(vals).reshape(1).clone()
-        return allreduce_sum(total)[0]
+        return allreduce_sum(total, self.engine)[0]
 
     def value_and_grad(self, params, local_value_and_grad):
         """Summed objective AND its gradient with respect to the SHARED parameters:
@@ -127,5 +149,5 @@ class ShardedObjective:
 
         vals, grads = local_value_and_grad(params)
         packed = torch.cat([self.local_sum(vals).reshape(1), grads.sum(0).reshape(-1)]).clone()
-        allreduce_sum(packed)
+        allreduce_sum(packed, self.engine)
         return packed[0], packed[1:]

@@ -88,6 +88,7 @@ class BatchedKalman:
         if getattr(self, "_ctx", None):
             self._L.mk_destroy(self._ctx)
             self._ctx = None
+            self._has_comm = False
 
     def __del__(self):
         try:
@@ -794,6 +795,43 @@ class BatchedKalman:
         self._bind_stream()
         check(self._L.mk_sum(self._ctx, int(values.numel()), self._p(values), self._p(out)))
         return out[0]
+
+    # ------------------------------------------------------------------ the one collective (C ABI mk_allreduce_sum)
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes identifying a new RCCL communicator (``mk_comm_unique_id`` = ``ncclGetUniqueId``): ONE rank calls it
+        and hands the bytes to the others (``distributed.attach_communicator`` does that over the process group's store)."""
+        buf = ctypes.create_string_buffer(128)
+        check(_lib.lib().mk_comm_unique_id(buf))
+        return buf.raw
+
+    def init_communicator(self, nranks, rank, unique_id):
+        """``mk_comm_init_rank``: join the RCCL communicator ``unique_id`` as ``rank`` of ``nranks`` on this engine's device
+        (collective: every rank calls it).  The context owns the communicator until ``close()``."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        check(self._L.mk_comm_init_rank(self._ctx, int(nranks), int(rank), ctypes.c_char_p(bytes(unique_id))))
+        self._has_comm = True
+        return self
+
+    def set_communicator(self, nccl_comm):
+        """``mk_set_communicator``: use a caller-owned ``ncclComm_t`` (an integer address / ``c_void_p``); None detaches."""
+        check(self._L.mk_set_communicator(self._ctx, ctypes.c_void_p(nccl_comm) if nccl_comm else None))
+        self._has_comm = bool(nccl_comm)
+        return self
+
+    def has_communicator(self):
+        return bool(getattr(self, "_has_comm", False))
+
+    def allreduce_sum(self, t):
+        """In-place all-reduce(sum) of a float64 device tensor over the engine's communicator (``mk_allreduce_sum``, on the
+        current stream).  Raises without a communicator: there is no single-rank shortcut."""
+        torch = _torch()
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("allreduce_sum takes a contiguous float64 tensor on the engine's device")
+        self._bind_stream()
+        check(self._L.mk_allreduce_sum(self._ctx, self._p(t), int(t.numel())))
+        return t
 
     # ------------------------------------------------------------------ lock-step L-BFGS (calibrate_batch; mk_lbfgs.hip)
     def lbfgs_direction(self, x, g, lo, active, Sh, Yh, rho, hlen, hpos, gtol, pg, d, phase=None, step=None, nback=None):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from metran_amd.calibrate import calibrate_batch, calibrate_sharded  # noqa: E402
-from metran_amd.distributed import ShardedObjective, gather_concat, init_from_env, shard_range, world  # noqa: E402
+from metran_amd.distributed import ShardedObjective, attach_communicator, gather_concat, init_from_env, shard_range, world  # noqa: E402
 from metran_amd.engine import BatchedKalman  # noqa: E402
 from metran_amd.synthetic import make_dfm_batch  # noqa: E402
 
@@ -43,7 +43,10 @@ def local_vg(a):
     return kf.loglik_grad_alpha(a[None].repeat(hi - lo, 1))
 
 
-obj = ShardedObjective(local_loglik, local_sum=kf.sum)
+C_ABI = "--c-abi" in sys.argv   # the all-reduce through the library's own communicator (mk_allreduce_sum) instead of torch.distributed's
+if C_ABI:
+    attach_communicator(kf)      # rank 0's unique id travels over the process group, every rank joins
+obj = ShardedObjective(local_loglik, local_sum=kf.sum, engine=kf if C_ABI else None)
 total = obj(alpha)                                         # fixed-order local sum + all_reduce on RCCL
 plain = kf.sum(local_loglik(alpha)).reshape(1)[0]          # the same without any collective
 tot2, grad = obj.value_and_grad(alpha, local_vg)           # P + 1 doubles in one all_reduce
@@ -55,7 +58,7 @@ sharded = calibrate_sharded(R, engine, maxiter=60, stderr=True)
 single = calibrate_batch(engine(0, R), maxiter=60, stderr=True)
 torch.cuda.synchronize()
 print("RCCL1 " + json.dumps({
-    "backend": dist.get_backend(), "ranks": float(ones.item()),
+    "backend": dist.get_backend(), "ranks": float(ones.item()), "c_abi_communicator": bool(kf.has_communicator()),
     "sum_bitwise": bool(total == plain), "total": float(total),
     "grad_bitwise": bool(torch.equal(grad, g.sum(0)) and tot2 == kf.sum(v).reshape(1)[0]),
     "gather_bitwise": bool(torch.equal(gathered, local_loglik(alpha))),

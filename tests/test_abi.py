@@ -84,7 +84,7 @@ def test_no_gpu_calls_fail_loudly_not_silently(lib):
         BatchedKalman()
     from metran_amd import _lib as binding
 
-    assert lib.mk_abi_version() == binding.ABI_VERSION == 6
+    assert lib.mk_abi_version() == binding.ABI_VERSION == 7
     assert lib.mk_shape_supported(8, 2) == 1 and lib.mk_shape_supported(32, 4) == 1
     # (7, 7) has no specialised kernel here (not in the ahead-of-time list, no module registered) and runs the size-generic
     # ones; beyond 128 states nothing serves a shape
@@ -183,3 +183,22 @@ def test_tape_geometry_without_a_gpu():
     blk = np.arange(14 * 21, dtype=float)
     e = dk_ref.unpack_block(blk, 14, 3)
     assert e.shape == (14, 21) and e[3, 0] == 3 * 21 and e[3, 14] == 3 * 21 + 14 and e[13, 20] == 14 * 21 - 1
+
+
+def test_allreduce_fails_loudly_without_a_communicator(lib):
+    """SURVEY 8b's collective hook (``mk_allreduce_sum`` / ``mk_set_communicator``): no context, no communicator or a bad
+    buffer are explicit errors -- there is no silent single-rank shortcut.  No GPU, no process group and no gloo needed:
+    the null-context checks come before any HIP or RCCL call."""
+    buf = (ctypes.c_double * 4)(1.0, 2.0, 3.0, 4.0)
+    assert lib.mk_allreduce_sum(None, ctypes.cast(buf, ctypes.c_void_p), 4) != 0
+    assert b"null mk_context" in lib.mk_last_error()
+    assert lib.mk_set_communicator(None, None) != 0 and b"null mk_context" in lib.mk_last_error()
+    assert lib.mk_comm_destroy(None) != 0
+    assert lib.mk_comm_init_rank(None, 1, 0, ctypes.cast(buf, ctypes.c_void_p)) != 0
+    assert lib.mk_comm_unique_id(None) != 0 and b"128" in lib.mk_last_error()
+    assert list(buf) == [1.0, 2.0, 3.0, 4.0]          # untouched
+    # the binding layer refuses too: an engine without a communicator raises instead of returning its input
+    src = open(os.path.join(ROOT, "metran_amd", "csrc", "mk_capi.hip")).read()
+    assert "no single-rank shortcut" in src and "dlopen" in src   # librccl is bound at first use, never linked
+    out = subprocess.check_output(["ldd", os.path.join(ROOT, "metran_amd", "libmetran_hip.so")], text=True)
+    assert "rccl" not in out, "libmetran_hip.so must not depend on librccl at load time"

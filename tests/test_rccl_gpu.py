@@ -58,3 +58,47 @@ def test_sharded_objective_and_calibration_on_one_rccl_rank():
     assert res["backend"] == "nccl" and res["ranks"] == 1.0
     assert res["sum_bitwise"] and res["grad_bitwise"] and res["gather_bitwise"] and res["calibrate_bitwise"]
     assert res["calibrate_converged"] >= res["models"] - 2
+
+
+def test_c_abi_allreduce_on_one_rccl_rank():
+    """``mk_comm_unique_id`` -> ``mk_comm_init_rank`` -> ``mk_allreduce_sum`` through the C ABI, a communicator of ONE rank in
+    this process (no torch.distributed): the collective runs on RCCL and is an identity bit for bit; before the
+    communicator exists, and after ``mk_comm_destroy``, the call fails loudly."""
+    import ctypes
+
+    import torch
+
+    from metran_amd._lib import MetranHipError
+    from metran_amd.distributed import ShardedObjective, allreduce_sum, attach_communicator
+    from metran_amd.engine import BatchedKalman
+
+    kf = BatchedKalman(0)
+    t = torch.arange(1.0, 12.0, dtype=torch.float64, device="cuda") / 7.0
+    ref = t.clone()
+    with pytest.raises(MetranHipError, match="no communicator"):
+        kf.allreduce_sum(t)
+    assert torch.equal(t, ref)
+    attach_communicator(kf)                       # no process group: a communicator of one rank
+    assert kf.has_communicator()
+    for _ in range(3):
+        kf.allreduce_sum(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref)
+    assert allreduce_sum(t, kf) is t and torch.equal(t, ref)
+    obj = ShardedObjective(lambda p: p * 2.0, local_sum=kf.sum, engine=kf)
+    assert float(obj(ref)) == float(kf.sum(ref * 2.0))
+    with pytest.raises(ValueError):
+        kf.allreduce_sum(t.float())
+    # raw C ABI, caller-owned communicator handed to a second context: mk_set_communicator
+    L = kf._L
+    assert L.mk_comm_destroy(kf._ctx) == 0
+    with pytest.raises(MetranHipError, match="no communicator"):
+        kf.allreduce_sum(t)
+    kf.close()
+
+
+def test_c_abi_allreduce_under_torchrun():
+    out = _torchrun([os.path.join(ROOT, "tests", "rccl_world1_script.py"), "--c-abi"])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RCCL1 ")][-1][6:])
+    assert res["c_abi_communicator"] and res["sum_bitwise"] and res["grad_bitwise"]
