@@ -271,7 +271,10 @@ MK_API int mk_smooth_dense(mk_context *ctx, int64_t B, int64_t T, int64_t n, con
  *   mk_lbfgs_update     for the models of d_mask (NULL: all): pair (s, y, rho) of the accepted point into the model's ring if
  *                       s.y > 1e-10 y.y (skipped otherwise, as scipy does), (x, f, g) <- new (lock-step form: models still in
  *                       d_searching keep their old gradient if asked and leave d_active), d_active &= relative reduction > ftol,
- *                       phase <- 0; #usable pairs */
+ *                       phase <- 0; #usable pairs.  d_nit [R] int32 (may be NULL): the quasi-Newton ITERATIONS every model has
+ *                       taken -- incremented for each active model updated here -- and a model whose count reaches maxiter
+ *                       (> 0) leaves d_active: scipy's maxiter (solver.py:248 passes it through) counts iterations of ONE
+ *                       model, whatever the driver's loop counts */
 MK_API int mk_lbfgs_direction(mk_context *ctx, int64_t R, int64_t n, int64_t history, const double *d_x, const double *d_g, const double *d_lo,
                               uint8_t *d_active, const double *d_Sh, const double *d_Yh, const double *d_rho, const int *d_hlen,
                               const int *d_hpos, double gtol, double *d_pg, double *d_d, uint8_t *d_phase, double *d_step, int *d_nback,
@@ -285,7 +288,8 @@ MK_API int mk_lbfgs_armijo(mk_context *ctx, int64_t R, int64_t n, const double *
 MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t history, double *d_x, double *d_f, double *d_g,
                            const double *d_x_new, const double *d_f_new, const double *d_g_new, int keep_old_gradient_if_searching,
                            const uint8_t *d_searching, const uint8_t *d_mask, uint8_t *d_active, double ftol, double *d_Sh,
-                           double *d_Yh, double *d_rho, int *d_hlen, int *d_hpos, uint8_t *d_phase, int *h_ngood);
+                           double *d_Yh, double *d_rho, int *d_hlen, int *d_hpos, uint8_t *d_phase, int *d_nit, int64_t maxiter,
+                           int *h_ngood);
 
 /* seqkalmanfilter + get_mle for B instances (kalmanfilter.py:236-400, 550-567).
  * Uses d_mle, d_sigmas, d_detfs, d_sigmacount, d_F, d_Pf, d_Xp, d_Pp, d_status of `out`. */

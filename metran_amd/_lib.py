@@ -124,7 +124,7 @@ API = {
                                 c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_int), POINTER(c_int)]),
     "mk_lbfgs_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                POINTER(c_int)]),
+                                c_void_p, c_int64, POINTER(c_int)]),
     "mk_alpha_grad": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_double, c_void_p,
                               c_void_p, c_void_p]),
     "mk_standardize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

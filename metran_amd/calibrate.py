@@ -23,7 +23,9 @@ __all__ = ["calibrate_batch", "calibrate_sharded", "calibrate_shared", "Calibrat
 
 
 class CalibrationResult(dict):
-    """``alpha [R,P]``, ``obj [R]`` (-2 log L), ``grad [R,P]``, ``converged [R]`` (bool; False too where the objective is not finite), ``nit``,
+    """``alpha [R,P]``, ``obj [R]`` (-2 log L), ``grad [R,P]``, ``converged [R]`` (bool; False too where the objective is not finite or
+    the model stopped at ``maxiter``), ``nit_model [R]`` (quasi-Newton iterations of every model -- what scipy's ``nit`` counts), ``nit``
+    (their maximum), ``passes`` (passes of the driver's loop: with every model on its own line search one pass is one trial point),
     ``nfev`` (filter instances evaluated in total), ``launches``, ``aic [R]`` (= 2P + obj, solver.py:280)."""
 
     __getattr__ = dict.__getitem__
@@ -33,6 +35,11 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
                     ftol=2.220446049250313e-09, gtol=1e-5, max_backtracks=12, verbose=False, gradient="auto",
                     stderr=False, compact=0.5, compact_min=256, fd_below=0, launch_budget=None, own_search_above=None):
     """Calibrate every record held by ``kf`` (observations + loadings already set).
+
+    ``maxiter`` is scipy's: the number of quasi-Newton ITERATIONS (accepted steps) one model may take, counted per model on the
+    device (``mk_lbfgs_update``), whichever schedule runs -- a model that reaches it leaves the flight unconverged.  The
+    driver's loop additionally stops after ``maxiter * (max_backtracks + 1)`` passes (every iteration may use its whole
+    back-tracking budget).  ``history`` <= 16 and N + K <= 128 (the L-BFGS kernels' ring and parameter limits).
 
     Parameters mirror scipy's L-BFGS-B defaults used by the reference (``eps`` forward-difference step,
     ``ftol = factr*epsmch`` with factr 1e7, ``gtol = pgtol`` on the projected gradient, ``history = m``);
@@ -70,6 +77,12 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
 
     R, n = kf.R, kf.n
     dev = kf.device
+    if not 1 <= int(history) <= 16:
+        raise ValueError("history must be between 1 and 16 (MK_LBFGS_MAX_H: the L-BFGS kernels keep at most 16 pairs per model); got %r" % (history,))
+    if n > 128:
+        raise ValueError("calibrate_batch serves N + K <= 128 parameters per model (MK_LBFGS_MAX_N); this engine has %d" % n)
+    if int(maxiter) < 1:
+        raise ValueError("maxiter must be at least 1")
     if launch_budget is None:
         launch_budget = 8192 if n <= 16 else 2048
     if own_search_above is None:
@@ -149,8 +162,11 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
     pg, d = torch.zeros_like(x), torch.zeros_like(x)
     xt, xe = torch.empty_like(x), torch.empty_like(x)
     x_new, f_new = x.clone(), f.clone()
-    nit = 0
-    for nit in range(1, maxiter + 1):
+    nit_model = torch.zeros(R, dtype=torch.int32, device=dev)   # quasi-Newton iterations per model (scipy's nit)
+    NIT_all = torch.zeros(R, dtype=torch.int32, device=dev)
+    passes = 0
+    for passes in range(1, int(maxiter) * (int(max_backtracks) + 1) + 1):
+        nit = passes
         # projected gradient, convergence test on it, two-loop recursion with its safeguards: ONE launch (mk_lbfgs.hip; one
         # thread per model) and one host synchronisation for the count.  A model in the middle of its line search (adjoint mode)
         # keeps its direction and its shortened step.
@@ -162,11 +178,11 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         to_fd = grad_mode == "adjoint" and fd_below and (n + 1) * n_act <= fd_below < (n + 1) * R
         more_trials = grad_mode == "fd" and launch_budget // ((n + 1) * R) < 4
         if compact and n_act < compact * R and (R > compact_min or to_fd or more_trials):
-            X_all[orig], F_all[orig], G_all[orig] = x, f, g      # everybody's current state; the inactive ones are final
+            X_all[orig], F_all[orig], G_all[orig], NIT_all[orig] = x, f, g, nit_model   # everybody's current state; the inactive ones are final
             keep = active.nonzero().squeeze(1)
             kf = kf.subset(keep)
-            x, f, g, lo, pg, d, orig, hlen, hpos, phase, nback, step, x_new, f_new = (
-                t[keep].contiguous() for t in (x, f, g, lo, pg, d, orig, hlen, hpos, phase, nback, step, x_new, f_new))
+            x, f, g, lo, pg, d, orig, hlen, hpos, phase, nback, step, x_new, f_new, nit_model = (
+                t[keep].contiguous() for t in (x, f, g, lo, pg, d, orig, hlen, hpos, phase, nback, step, x_new, f_new, nit_model))
             Sh, Yh, rho = Sh[:, keep].contiguous(), Yh[:, keep].contiguous(), rho[:, keep].contiguous()
             R = n_act
             active = torch.ones(R, dtype=torch.bool, device=dev)
@@ -191,7 +207,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
             if n_acc > 0:
                 launches += 1
                 g_cand = kf.loglik_backward_alpha()
-                kf.lbfgs_update(x, f, g, x_new, f_new, g_cand.contiguous(), False, None, active, ftol, Sh, Yh, rho, hlen, hpos, accepted, phase)
+                kf.lbfgs_update(x, f, g, x_new, f_new, g_cand.contiguous(), False, None, active, ftol, Sh, Yh, rho, hlen, hpos, accepted, phase,
+                                nit=nit_model, maxiter=maxiter)
             if verbose:
                 print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
             continue
@@ -273,18 +290,20 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         # the pair (s, y) of this step into every model's ring (skipped where it is not usable, as scipy does), (x, f, g) <- the
         # accepted point, scipy's relative-reduction test (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol: ONE launch
         kf.lbfgs_update(x, f, g, x_new.contiguous(), f_tmp.contiguous(), g_cand.contiguous(), keep_old, searching, active, ftol,
-                        Sh, Yh, rho, hlen, hpos)
+                        Sh, Yh, rho, hlen, hpos, nit=nit_model, maxiter=maxiter)
         if verbose:
             print("it %3d  active %5d  mean obj %.6f" % (nit, int(active.sum()), float(f.mean())))
-    X_all[orig], F_all[orig], G_all[orig], active_all[orig] = x, f, g, active
+    X_all[orig], F_all[orig], G_all[orig], active_all[orig], NIT_all[orig] = x, f, g, active, nit_model
     kf, R, x, f, g, active = kf0, R0, X_all, F_all, G_all, active_all
+    # a model that stopped at maxiter left the flight (active = False) without converging: scipy reports success False there
+    hit_cap = NIT_all >= int(maxiter)
     lo = torch.full((R, n), float(pmin), **f64) if np.isscalar(pmin) else kf._dev(pmin, (R, n), "pmin")
     pg = proj_grad(x, g)
     # a model whose objective is not a number (communalities above 1 give negative transition variances, say) leaves the
     # flight at once -- NaN compares false with gtol -- but it has not converged (scipy: ABNORMAL_TERMINATION, success False)
     finite = torch.isfinite(f) & torch.isfinite(g).all(1)
-    res = CalibrationResult(alpha=x, obj=f, grad=g, converged=~active & finite, nit=nit, nfev=nfev, launches=launches,
-                            aic=2 * n + f, pgnorm=pg.abs().amax(1))
+    res = CalibrationResult(alpha=x, obj=f, grad=g, converged=~active & finite & ~hit_cap, nit=int(NIT_all.max().item()) if R else 0,
+                            nit_model=NIT_all, passes=passes, nfev=nfev, launches=launches, aic=2 * n + f, pgnorm=pg.abs().amax(1))
     if stderr:
         # the Hessian is differenced from the exact (adjoint) gradient whatever gradient the ITERATION used
         # (gradient="fd", or the fd_below switch for a small flight): eligibility is the adjoint kernel's, not the mode's

@@ -750,7 +750,14 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
         return fail(MK_ERR_SHAPE, "packed-symmetric records and the tape exist for specialised shapes only (N=%lld, K=%lld runs the size-generic "
                                   "kernels: mk_shape_specialised)", (long long)p->N, (long long)p->K);
     MK_HIP(timing_start(ctx, 0));
-    MK_HIP(dispatch_filter((int)p->N, (int)p->K, a, ctx->stream, ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1));
+    {
+        const hipError_t e = dispatch_filter((int)p->N, (int)p->K, a, ctx->stream, ctx->variant[MK_VARIANT_KERNEL_FAMILY] == 1);
+        if (e == hipErrorNotSupported)
+            return fail(MK_ERR_SHAPE, "a model of N=%lld series and K=%lld factors is not served on this device in this mode (the size-generic "
+                                      "filter keeps the %lld x %lld covariance in LDS: %zu bytes)", (long long)p->N, (long long)p->K,
+                        (long long)(p->N + p->K), (long long)(p->N + p->K), mk::generic_filter_lds_bytes((int)p->N, (int)p->K));
+        MK_HIP(e);
+    }
     MK_HIP(timing_stop(ctx, 0));
     return MK_OK;
 }
@@ -1104,7 +1111,7 @@ MK_API int mk_lbfgs_armijo(mk_context *ctx, int64_t R, int64_t n, const double *
 MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t history, double *d_x, double *d_f, double *d_g, const double *d_x_new,
                            const double *d_f_new, const double *d_g_new, int keep_old_gradient_if_searching, const uint8_t *d_searching,
                            const uint8_t *d_mask, uint8_t *d_active, double ftol, double *d_Sh, double *d_Yh, double *d_rho, int *d_hlen,
-                           int *d_hpos, uint8_t *d_phase, int *h_ngood)
+                           int *d_hpos, uint8_t *d_phase, int *d_nit, int64_t maxiter, int *h_ngood)
 {
     MK_CTX(ctx);
     if (!d_x || !d_f || !d_g || !d_x_new || !d_f_new || !d_g_new || !(d_searching || d_mask) || !d_active || !d_Sh || !d_Yh || !d_rho || !d_hlen ||
@@ -1132,6 +1139,8 @@ MK_API int mk_lbfgs_update(mk_context *ctx, int64_t R, int64_t n, int64_t histor
     a.hlen = d_hlen;
     a.hpos = d_hpos;
     a.phase = d_phase;
+    a.nit = d_nit;
+    a.maxiter = (int)maxiter;
     return lbfgs_run(ctx, 3, a, 2, h_ngood);
 }
 

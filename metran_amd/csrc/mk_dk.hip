@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N + K <
     double Nr[n];
 #pragma unroll
     for (int c = 0; c < n; ++c) Nr[c] = 0.0;
+    const double rrow = lane >= n ? 1.0 : 0.0; // indicator of the r row (and its replicas)
 
     // HBM -> LDS copy of one tape block (asynchronous; completion = vmcnt)
     const long blk_bytes = (long)RS * 8;
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N + K <
             load_ent(um ? lowbit(um) : u, Enext); // the next entry's LDS reads in flight during this product
             __builtin_amdgcn_sched_barrier(0);
             const double w = matvec(E);
-            tapeb[xa_off + u * xa_str] = lane < n ? E.xa * w : w;
+            tapeb[xa_off + u * xa_str] = (E.xa + rrow) * w; // x_a w_a; the r row (its slot of the entry holds 0): beta = w itself
         };
         // (Measured and dropped, round 4: pt vanishes on the coordinates observed at the step, so a column loop over the
         // unobserved series and the factors only -- 13.6 of 36 columns at configs[3], x_c as wavefront-uniform LDS reads for
@@ -395,10 +396,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N + K <
                     if (om & ((mask_t)1 << j)) {
                         const Ent &E = eo[j & 1];
                         const double w = matvec(E);
-                        const double beta = readlane_f64(w, n);
+                        [[maybe_unused]] double beta = 0.0;
+                        if constexpr (HASR) beta = readlane_f64(w, n);
                         const double alpha = MK_TUNE_SKIP(a, 32) ? E.xa * w : wave_sum_mfma(E.xa * w);   // its MFMA chain runs under what follows
-                        double nc = Nr[j] - w;                                // N[a][j] - w_a
-                        nc = (lane >= n) ? Nr[j] + (E.s0 - beta) : nc;        // r_j + v/f - beta
+                        // rows a < n: N[a][j] - w_a.  The r row (lanes >= n): r_j + v/f - beta -- and beta = r . kt IS that row's own w, so
+                        // one multiply-add with the row indicator replaces the lane read of beta, a subtraction, an addition and two
+                        // selects (round 6: the loop is bound by its instruction count, five fewer per entry are 4 % of the step)
+                        const double nc = fma(rrow, E.s0, Nr[j] - w);
                         Nr[j] = nc;
                         if (!MK_TUNE_SKIP(a, 16)) {
                             tbuf[ra] = nc;                                    // slot n: the r row's, unused

@@ -20,6 +20,8 @@
 // not recomputed -- kalmanfilter.py:453-474 reads predicted_state_means / predicted_state_covariances as they are handed in).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "mk_generic.h"
 
 namespace mk {
@@ -291,12 +293,27 @@ hipError_t launch_filter_generic(int N, int K, const FilterArgs &a, hipStream_t 
 {
     if (N + K > MK_GENERIC_MAX_STATES || a.sym || a.tape) return hipErrorNotSupported;
     const size_t lds = generic_filter_lds_bytes(N, K);
-    static thread_local size_t granted = 0;
-    if (lds > granted) { // above the 64 KiB default a kernel has to be given its dynamic LDS size explicitly
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&filter_generic_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // above the 64 KiB default a kernel has to be given its dynamic LDS size explicitly -- PER DEVICE (round-5 advice: the grant
+    // used to be remembered per thread, so a thread driving a second GPU skipped the call there and its launch failed), and a
+    // model that needs more LDS than the device has is refused here with the shape error instead of a raw launch failure
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    constexpr int MAXDEV = 64;
+    static std::mutex grant_mutex;
+    static size_t granted[MAXDEV] = {};
+    static int lds_cap[MAXDEV] = {};
+    std::lock_guard<std::mutex> lock(grant_mutex);
+    if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
+    if (!lds_cap[dev]) {
+        e = hipDeviceGetAttribute(&lds_cap[dev], hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
         if (e != hipSuccess) return e;
-        granted = lds;
+    }
+    if (lds > (size_t)lds_cap[dev]) return hipErrorNotSupported; // MK_ERR_SHAPE at the C ABI: N + K too large for this device's LDS
+    if (lds > granted[dev] && lds > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&filter_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted[dev] = lds;
     }
     hipLaunchKernelGGL(filter_generic_kernel, dim3((unsigned)a.B), dim3(GNT), lds, s, a, N, K);
     return hipGetLastError();

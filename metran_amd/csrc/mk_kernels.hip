@@ -2185,11 +2185,13 @@ int num_shapes();
 void get_shape(int i, int *N, int *K);
 
 #ifdef MK_SHAPE_MODULE
-} // namespace mk
-#include "mk_wide.hip" // one translation unit per run-time shape module
+#ifndef MK_SHAPE_MODULE_TUS // one translation unit per run-time shape module (scripts/compile_shape.sh); metran_amd/jit.py compiles
+} // namespace mk           // the four files -- mk_wide.hip in its slices -- as separate units in parallel and links them
+#include "mk_wide.hip"
 #include "mk_split.hip"
 #include "mk_dk.hip"
 namespace mk {
+#endif
 // ---------------------------------------------------------------------------------------------
 // Shape module: this same translation unit compiled at run time for ONE (N, K) that is not in the
 // ahead-of-time list (metran_amd/jit.py drives hipcc, runs the DPP hazard check on the assembly and

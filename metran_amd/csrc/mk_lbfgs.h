@@ -28,6 +28,8 @@ struct LbfgsArgs {
     const double *ft;       // objective at the trial points [R]
     const double *g_new;    // gradient at the accepted points [R,n]
     int *counters;          // device int[4]: #active (direction), #still searching (armijo), #good pairs (update)
+    int *nit;               // update: [R] quasi-Newton iterations every model has taken (NULL: not counted)
+    int maxiter;            // update: a model whose count reaches it leaves the flight (0: no limit) -- scipy's maxiter, per model
 };
 
 hipError_t launch_lbfgs(int which, const LbfgsArgs &a, hipStream_t s); // 0 direction, 1 trial, 2 armijo, 3 update

@@ -188,7 +188,14 @@ __global__ void __launch_bounds__(TPB) lbfgs_update_kernel(LbfgsArgs a)
     if (a.phase) a.phase[r] = 0; // the next direction call gives this model a new one
     // scipy's relative-reduction test: (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= ftol stops the model
     const double rel = (f_prev - f_now) / fmax(fmax(fabs(f_prev), fabs(f_now)), 1.0);
-    const bool act = a.active[r] && !srch && (rel > a.ftol);
+    bool act = a.active[r] && !srch && (rel > a.ftol);
+    // scipy's maxiter counts ITERATIONS (accepted steps) of one model, not passes of the driver's loop: with every model on its
+    // own line search a pass is one TRIAL point, and a model that back-tracks k times per step would get maxiter / (k + 1) steps
+    if (a.nit && a.active[r]) {
+        const int k = a.nit[r] + 1;
+        a.nit[r] = k;
+        if (a.maxiter > 0 && k >= a.maxiter) act = false;
+    }
     a.active[r] = act ? 1 : 0;
 }
 

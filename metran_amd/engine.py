@@ -303,15 +303,17 @@ class BatchedKalman:
             try:
                 jit.ensure_shape(self.N, self.K)  # builds + registers a specialised kernel module (cached)
                 return
-            except MetranHipError as e:
-                why = str(e).splitlines()[0]
+            except jit.ShapeUnavailable as e:   # no compiler / METRAN_HIP_JIT=0: the size-generic kernels serve the shape.
+                why = str(e).splitlines()[0]    # A FAILED build (hipcc, link, hazard check: jit.ShapeBuildError) propagates --
+                                                # it must not hide behind kernels ten times slower (round-5 advice)
         if not self._L.mk_shape_supported(self.N, self.K):
             raise MetranHipError("a model of N=%d series and K=%d factors has %d states; the library serves N + K <= %d"
                                  % (self.N, self.K, self.n, int(self._L.mk_generic_max_states())))
         if self.packed_sym:
             raise MetranHipError("packed-symmetric records need specialised kernels; (N=%d, K=%d) runs the size-generic ones%s"
                                  % (self.N, self.K, " (%s)" % why if why else ""))
-        logger.info("(N=%d, K=%d) runs the size-generic kernels%s", self.N, self.K, ": " + why if why else " (N + K > 64)")
+        logger.warning("(N=%d, K=%d) runs the size-generic kernels%s -- correct, about an order of magnitude slower, no adjoint "
+                       "gradient / tape / packed-symmetric records", self.N, self.K, ": " + why if why else " (N + K > 64)")
 
     def specialised(self):
         """True when this engine's shape runs the specialised (unrolled, one-state-per-lane) kernels, False for the size-generic ones."""
@@ -340,10 +342,13 @@ class BatchedKalman:
         # the sub-engine takes over the parent's adjoint workspace (a subset never needs more of it; at 8192 x (8,2), T = 1000 it is
         # 7.3 GB, and a fresh 3 GB allocation for the first compacted flight was the largest single item of a calibration's wall
         # time).  The two are used one after the other (calibrate_batch returns to the parent when the flight has finished); a
-        # forward pass still waiting for its backward pass on the parent is void from here on.
+        # forward pass still waiting for its backward pass on the parent is void from here on.  Interleaved use is not supported:
+        # The buffer carries an OWNER token shared by everybody who holds it (round-5 advice): whoever starts a forward pass
+        # takes the token, and a backward pass whose engine no longer holds it raises instead of walking somebody else's records.
         work = getattr(self, "_grad_work", None)
         if work is not None:
             sub._grad_work = work
+            sub._grad_share = self._grad_share = getattr(self, "_grad_share", None) or {"owner": None}
             self._grad_pending = None
         return sub
 
@@ -409,9 +414,7 @@ class BatchedKalman:
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         self._grad_pending = None  # the shared workspace is about to be overwritten: a forward pass waiting for its backward is void
         need = B * self.T * self.record_stride()
-        work = getattr(self, "_grad_work", None)
-        if work is None or work.numel() < need:
-            self._grad_work = work = torch.empty(need, dtype=torch.float64, device=self.device)
+        work = self._take_grad_work(need)
         mle = torch.empty(B, dtype=torch.float64, device=self.device)
         sc = torch.empty(B, dtype=torch.int64, device=self.device)
         gphi = torch.empty((B, self.n), dtype=torch.float64, device=self.device)
@@ -421,6 +424,19 @@ class BatchedKalman:
                                      self._p(mle), self._p(sc), self._p(gphi), self._p(gq), None))
         return mle, gphi, gq
 
+    def _take_grad_work(self, need):
+        """The adjoint workspace (at least ``need`` doubles), with this engine as the owner of its contents from now on: an
+        engine sharing the buffer (``subset``) that still waits for a backward pass will refuse to run it."""
+        torch = _torch()
+        work = getattr(self, "_grad_work", None)
+        if work is None or work.numel() < need:
+            self._grad_work = work = torch.empty(need, dtype=torch.float64, device=self.device)
+            self._grad_share = None          # a fresh buffer is nobody else's
+        self._grad_token = object()
+        if getattr(self, "_grad_share", None) is not None:
+            self._grad_share["owner"] = self._grad_token
+        return work
+
     def loglik_forward(self, phi, q, warmup=1, x0=None, P0=None):
         """The forward half of ``loglik_grad`` alone (``mk_loglik_grad_phases``, MK_GRAD_FORWARD): ``mle [B]``, with the
         filtered records left in the workspace.  ``loglik_backward()`` then returns the gradient AT THESE parameters
@@ -429,9 +445,7 @@ class BatchedKalman:
         torch = _torch()
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         need = B * self.T * self.record_stride()
-        work = getattr(self, "_grad_work", None)
-        if work is None or work.numel() < need:
-            self._grad_work = work = torch.empty(need, dtype=torch.float64, device=self.device)
+        work = self._take_grad_work(need)
         mle = torch.empty(B, dtype=torch.float64, device=self.device)
         sc = torch.empty(B, dtype=torch.int64, device=self.device)
         self._bind_stream()
@@ -451,6 +465,11 @@ class BatchedKalman:
         pending = getattr(self, "_grad_pending", None)
         if pending is None:
             raise MetranHipError("loglik_backward without a preceding loglik_forward")
+        share = getattr(self, "_grad_share", None)
+        if share is not None and share["owner"] is not self._grad_token:
+            self._grad_pending = None
+            raise MetranHipError("the records of this engine's forward pass have been overwritten: the adjoint workspace is shared with "
+                                 "another engine (BatchedKalman.subset) that ran a forward pass since -- use the two one after the other")
         prob, keep, B, sc, work = pending
         gphi = torch.empty((B, self.n), dtype=torch.float64, device=self.device)
         gq = torch.empty_like(gphi)
@@ -868,16 +887,19 @@ class BatchedKalman:
                                       ctypes.byref(ns), ctypes.byref(na) if own else None))
         return (int(ns.value), int(na.value)) if own else int(ns.value)
 
-    def lbfgs_update(self, x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, hlen, hpos, mask=None, phase=None):
+    def lbfgs_update(self, x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, hlen, hpos, mask=None, phase=None,
+                     nit=None, maxiter=0):
         """For the models of ``mask`` (None: all): the pair of the accepted point into the model's ring if it is usable,
         ``(x, f, g) <- (x_new, f_new, g_new)`` (lock-step form: models still searching keep their old gradient if ``keep_old`` and
-        leave ``active``), ``active &= relative reduction > ftol``.  Returns the number of usable pairs."""
+        leave ``active``), ``active &= relative reduction > ftol``.  ``nit [R]`` int32: every active model updated here has taken one
+        more quasi-Newton iteration; at ``maxiter`` (> 0) it leaves ``active``.  Returns the number of usable pairs."""
         R, n = (int(v) for v in x.shape)
         cnt = ctypes.c_int(0)
         self._bind_stream()
         check(self._L.mk_lbfgs_update(self._ctx, R, n, int(Sh.shape[0]), self._p(x), self._p(f), self._p(g), self._p(x_new), self._p(f_new),
                                       self._p(g_new), 1 if keep_old else 0, self._p(searching), self._p(mask), self._p(active), float(ftol),
-                                      self._p(Sh), self._p(Yh), self._p(rho), self._p(hlen), self._p(hpos), self._p(phase), ctypes.byref(cnt)))
+                                      self._p(Sh), self._p(Yh), self._p(rho), self._p(hlen), self._p(hpos), self._p(phase), self._p(nit),
+                                      int(maxiter), ctypes.byref(cnt)))
         return int(cnt.value)
 
     # ------------------------------------------------------------------ instrumentation

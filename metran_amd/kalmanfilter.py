@@ -176,6 +176,9 @@ def seqkalmanfilter_hip(observations, transition_matrix, transition_covariance, 
     out = (host["sigmas"], host["detfs"], sc, host["F"], host["Pf"], host["Xp"], host["Pp"])
     # the reference hands these very array objects to kalmansmoother (run_smoother, kalmanfilter.py:676-694): remembered by
     # identity; the smoother then checks them against the device-resident moments before it uses those
+    # (no content hash is taken HERE: this call is the solver's inner loop -- 77 of them per Metran.solve on examples/data, and a
+    # hash of the 2 MB handed out would be a quarter of each -- so the consumers that run once per accessor, the smoother and
+    # simulate / decompose, compare what they are given with the device's copy instead: _same_as_device)
     kf._adapter_filter = dict(arrays=out[3:7], phi=phi.copy(), q=q.copy(), device=r)
     return out
 
@@ -209,9 +212,10 @@ def _records_to_host(r, n):
             "Xp": ap[:, :n], "Pp": ap[:, n:nv].reshape(T, n, n), "status": st[0:1].astype(np.int32), "sigmacount": st[1:2]}
 
 
-def _same_as_device(given, device):
-    """Whether the four moment arrays a caller hands to the smoother are (still) what the filter launch left on the device."""
-    for a, k in zip(given, ("F", "Pf", "Xp", "Pp")):
+def _same_as_device(given, device, keys=("F", "Pf", "Xp", "Pp")):
+    """Whether the moment arrays a caller hands in are (still) what the filter launch left on the device (one device-to-host
+    copy per array, once per smoother / projection call -- not per objective evaluation)."""
+    for a, k in zip(given, keys):
         if not np.array_equal(np.asarray(a), device[k][0].cpu().numpy()):
             return False
     return True
@@ -251,18 +255,32 @@ def kalmansmoother_hip(filtered_state_means, filtered_state_covariances, predict
         r = kf.smooth_dense(phi[None], F, Pf, Xp, Pp)
     check_status(r["status"], "kalmansmoother_hip")
     S, Ps = r["S"][0].cpu().numpy(), r["Ps"][0].cpu().numpy()
-    kf._adapter_smooth = dict(arrays=(S, Ps), device=(r["S"], r["Ps"]))  # simulate_hip projects them where they are
+    # simulate_hip / decompose_hip project them where they are -- as long as the host copies still hold what was handed out
+    kf._adapter_smooth = dict(arrays=(S, Ps), device=(r["S"], r["Ps"]), hash=_content_hash(S, Ps), hash_m=_content_hash(S))
     return S, Ps
 
 
-def _resident(kf, means, covariances):
-    """The device copies of (means, covariances) when they are the very arrays the last smoother / filter call of this thread's
-    engine returned (so that projecting them needs no upload), else the host arrays with a leading batch axis."""
+def _resident(kf, means, covariances, digest=None):
+    """The device copies of (means, covariances) when they are the arrays the last smoother / filter call of this thread's
+    engine returned AND still hold what was handed out then (so that projecting them needs no upload), else the host arrays
+    with a leading batch axis.  Identity alone is not enough (round-5 advice): the reference re-reads its arrays on every call
+    (kalmanfilter.py:569-644), so an in-place edit of ``smoothed_state_means`` must reach the projection -- the content hash
+    taken at hand-out decides.  ``digest``: the hash of (means, covariances) if the caller has it already."""
+    def unchanged(entry, key):
+        want = entry.get(key)
+        if want is None:
+            return False  # no hash was taken at hand-out (large filter arrays): upload what the caller holds now
+        got = digest if (digest is not None and covariances is not None) else (
+            _content_hash(means) if covariances is None else _content_hash(means, covariances))
+        return got == want
+
     sm = getattr(kf, "_adapter_smooth", None)
-    if sm is not None and means is sm["arrays"][0] and (covariances is None or covariances is sm["arrays"][1]):
+    if sm is not None and means is sm["arrays"][0] and (covariances is None or covariances is sm["arrays"][1]) and unchanged(
+            sm, "hash_m" if covariances is None else "hash"):
         return sm["device"]
     fl = getattr(kf, "_adapter_filter", None)
-    if fl is not None and means is fl["arrays"][0] and (covariances is None or covariances is fl["arrays"][1]):
+    if fl is not None and means is fl["arrays"][0] and (covariances is None or covariances is fl["arrays"][1]) and _same_as_device(
+            (means,) if covariances is None else (means, covariances), fl["device"], ("F", "Pf")):
         return fl["device"]["F"], fl["device"]["Pf"]
     return np.asarray(means, dtype=np.float64)[None], None if covariances is None else np.asarray(covariances, dtype=np.float64)[None]
 
@@ -279,10 +297,13 @@ def simulate_hip(self, observation_matrix, method="smoother"):
         means, covariances = self.smoothed_state_means, self.smoothed_state_covariances
     kf = get_engine()
     Z = np.ascontiguousarray(observation_matrix, dtype=np.float64)
-    key = (id(means), id(covariances), Z.shape, Z.tobytes())
+    # the cache key is the CONTENT of the moments and of Z (round-5 advice: id() of an array that is not kept alive can be
+    # recycled, and an in-place edit keeps its id): get_simulated_means and _variances ask for the same projection
+    digest = _content_hash(means, covariances)
+    key = (digest, Z.shape, Z.tobytes())
     hit = getattr(kf, "_adapter_simulated", None)
-    if hit is None or hit[0] != key or hit[1] is not means:  # get_simulated_means and _variances ask for the same projection
-        m_dev, c_dev = _resident(kf, means, covariances)
+    if hit is None or hit[0] != key:
+        m_dev, c_dev = _resident(kf, means, covariances, digest)
         sm, sv = kf.simulate(Z, m_dev, c_dev)
         hit = kf._adapter_simulated = (key, means, sm[0].cpu().numpy(), sv[0].cpu().numpy())
     return list(hit[2]), list(hit[3])

@@ -90,7 +90,8 @@ class TorchLbfgs:
         return int(cont.sum()), int(ok.sum())
 
     @staticmethod
-    def lbfgs_update(x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, hlen, hpos, mask=None, phase=None):
+    def lbfgs_update(x, f, g, x_new, f_new, g_new, keep_old, searching, active, ftol, Sh, Yh, rho, hlen, hpos, mask=None, phase=None,
+                     nit=None, maxiter=0):
         H, R = Sh.shape[0], Sh.shape[1]
         m = torch.ones_like(active) if mask is None else mask.bool()
         srch = searching.bool() if (searching is not None and mask is None) else torch.zeros_like(active)
@@ -108,7 +109,12 @@ class TorchLbfgs:
         hpos.copy_(torch.where(good & full, (hpos + 1) % H, hpos))
         hlen.copy_(torch.where(good & ~full, hlen + 1, hlen))
         rel = (f - f_new) / torch.maximum(torch.maximum(f.abs(), f_new.abs()), torch.ones_like(f))
+        was_active = active.clone()
         active.copy_(torch.where(m, active & ~srch & (rel > ftol), active))
+        if nit is not None:   # per-model iteration count; a model at maxiter leaves the flight (scipy's maxiter, per model)
+            nit.copy_(torch.where(m & was_active, nit + 1, nit))
+            if maxiter > 0:
+                active.copy_(active & ~(m & was_active & (nit >= maxiter)))
         x.copy_(torch.where(m[:, None], x_new, x))
         g.copy_(torch.where(m[:, None], gn, g))
         f.copy_(torch.where(m, f_new, f))

@@ -76,7 +76,10 @@ def test_own_line_search_per_model(models, optima):
     check_against_scipy(res, optima)
     kinds = [k for k, _ in eng.log]
     assert kinds[0] == "forward+backward" and kinds.count("forward+backward") == 1
-    assert res.nit - 1 <= kinds.count("forward") <= res.nit and 0 < kinds.count("backward") <= kinds.count("forward")
+    # one pass of the driver's loop = one trial point per model; a model's ITERATIONS (accepted steps, what scipy's maxiter and
+    # nit count: round-5 advice) are counted per model on the device and are at most the passes
+    assert res.passes - 1 <= kinds.count("forward") <= res.passes and 0 < kinds.count("backward") <= kinds.count("forward")
+    assert res.nit == int(res.nit_model.max()) and 0 < res.nit <= res.passes and bool((res.nit_model > 0).all())
     assert all(b == eng.R for _, b in eng.log)
     assert res.launches == 2 + kinds.count("forward") + kinds.count("backward")
     assert res.nfev == eng.R * (1 + kinds.count("forward"))
@@ -179,7 +182,17 @@ def test_iteration_limit_and_standard_errors(models):
     the exact gradient into a Hessian -- against a central-difference Hessian of the oracle's objective."""
     obs, load = models
     short = calibrate_batch(OracleEngine(obs, load), gradient="adjoint", compact=0, maxiter=3)
-    assert short.nit == 3 and not bool(short.converged.any())
+    assert short.nit == 3 and not bool(short.converged.any()) and bool((short.nit_model == 3).all())
+    # the same budget of ITERATIONS whichever schedule runs (round-5 advice: with every model on its own line search a pass of
+    # the loop is one trial point, and maxiter used to count passes there): a model gets 3 accepted steps in both, and the
+    # iterates of the two schedules are the same
+    own = calibrate_batch(OracleEngine(obs, load), gradient="adjoint", compact=0, maxiter=3, own_search_above=0)
+    assert own.nit == 3 and bool((own.nit_model == 3).all()) and own.passes >= 3 and not bool(own.converged.any())
+    assert torch.allclose(own.alpha, short.alpha, rtol=0, atol=1e-12) and torch.allclose(own.obj, short.obj, rtol=0, atol=1e-9)
+    with pytest.raises(ValueError, match="history"):
+        calibrate_batch(OracleEngine(obs, load), history=17)
+    with pytest.raises(ValueError, match="maxiter"):
+        calibrate_batch(OracleEngine(obs, load), maxiter=0)
     eng = OracleEngine(obs, load)
     res = calibrate_batch(eng, gradient="adjoint", compact=0, stderr=True)
     assert bool(res.converged.all()) and bool((res.obj < short.obj).all())

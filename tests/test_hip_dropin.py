@@ -86,6 +86,56 @@ def test_nine_arg_and_five_arg_adapters(g2):
     np.testing.assert_allclose(Ps[g2["tsel"]], g2["Ps"], atol=1e-9)
 
 
+def test_projections_re_read_edited_state_arrays(g2):
+    """Round-5 advice: ``simulate`` / ``decompose`` of the reference re-read ``smoothed_state_means`` / ``filtered_state_*`` on
+    every call (kalmanfilter.py:569-644).  The bound versions reuse the device-resident moments only while the host arrays
+    still hold what was handed out: an IN-PLACE edit (same object, same id) must reach the projection, and the projection
+    cache is keyed by content, not by id."""
+    from metran_amd.kalmanfilter import SPKalmanFilter
+
+    kf = SPKalmanFilter(engine="hip")
+    import pandas as pd
+
+    kf.set_observations(pd.DataFrame(g2["obs"]))
+    Z = observation_matrix(g2["loadings"])
+    kf.set_matrices(np.diag(g2["phi"]), np.diag(g2["q"]), Z, np.zeros(2))
+    kf.run_smoother()
+    m0, v0 = (np.asarray(a) for a in kf.simulate(Z))
+    means = kf.smoothed_state_means
+    means[5] += 1.0                                               # in place: same array object
+    m1, v1 = (np.asarray(a) for a in kf.simulate(Z))
+    want = np.asarray([Z @ x for x in means])
+    np.testing.assert_allclose(m1, want, atol=1e-12)
+    assert np.max(np.abs(m1[5] - m0[5])) > 0.5 and np.array_equal(np.delete(m1, 5, 0), np.delete(m0, 5, 0))
+    np.testing.assert_allclose(v1, v0, atol=0)                    # the covariances were not touched
+    sdf, _ = kf.decompose(Z)
+    np.testing.assert_allclose(np.asarray(sdf)[5], Z[:, :2] @ means[5][:2], atol=1e-12)
+    # ... and the filtered moments: edited in place after run_filter, projected with method="filter"
+    kf.filtered_state_means[7] -= 2.0
+    mf, _ = (np.asarray(a) for a in kf.simulate(Z, method="filter"))
+    np.testing.assert_allclose(mf[7], Z @ kf.filtered_state_means[7], atol=1e-12)
+    means[5] -= 1.0
+    m2, _ = (np.asarray(a) for a in kf.simulate(Z))
+    np.testing.assert_allclose(m2, m0, atol=1e-12)                # restored content: the same projection again
+    # the same through the ADAPTERS, whose results stay resident on the device (what install() binds to the reference class)
+    from types import SimpleNamespace
+
+    from metran_amd.kalmanfilter import kalmansmoother_hip, seqkalmanfilter_hip, simulate_hip
+
+    o, oi, oc = oracle.set_observations(g2["obs"])
+    res = seqkalmanfilter_hip(o, np.diag(g2["phi"]), np.diag(g2["q"]), Z, np.zeros(2), oi, oc, np.zeros(3), np.eye(3))
+    S, Ps = kalmansmoother_hip(res[3], res[4], res[5], res[6], np.diag(g2["phi"]))
+    holder = SimpleNamespace(smoothed_state_means=S, smoothed_state_covariances=Ps, filtered_state_means=res[3], filtered_state_covariances=res[4])
+    a0, _ = (np.asarray(a) for a in simulate_hip(holder, Z))
+    np.testing.assert_allclose(a0, m0, atol=1e-9)
+    S[11] *= 3.0                                                  # the very array the adapter returned, edited in place
+    a1, _ = (np.asarray(a) for a in simulate_hip(holder, Z))
+    np.testing.assert_allclose(a1[11], Z @ S[11], atol=1e-12)
+    res[3][2] += 0.25
+    f1, _ = (np.asarray(a) for a in simulate_hip(holder, Z, method="filter"))
+    np.testing.assert_allclose(f1[2], Z @ res[3][2], atol=1e-12)
+
+
 def test_adapter_uploads_the_observations_once_per_dataset(g2, monkeypatch):
     """Round-2 verdict, weak 9: Metran.solve calls the 9-argument engine ~80 times with the same observation arrays; the
     NaN-encoded record is derived and uploaded once, again when the arrays change (new arrays, or new content), and the
