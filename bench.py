@@ -173,7 +173,7 @@ def executed_flops_tape(N, K, T, missing):
             "smoother": T * (N * (2 * n * (n + 1) + 4 * n) + 2 * (n + 1) * N * K + 4 * n * n)}
 
 
-def executed_flops(N, K, T, mode, missing, tape):
+def executed_flops(N, K, T, mode, missing, tape, tape_filter=None):
     """Flops per model the kernels' OWN formulation executes (useful multiply-adds x 2; replica lanes, padding and
     recomputation for scheduling are not counted) -- the numerator of ``real_frac``.  Record paths: the filter exploits
     Z = [I | G] (d = P z' is 1 + K multiply-adds a row where the reference's dense update does n, kalmanfilter.py:349-357):
@@ -181,7 +181,13 @@ def executed_flops(N, K, T, mode, missing, tape):
     operation count (LDL^T n^3/3, two triangular solves 2n^3, V = J D 2n^3, Ps = Pf + V J' 2n^3 in full, means 4n^2) plus the
     predicted moments they recompute from the filtered ones (3n^2)."""
     if tape:
-        return executed_flops_state_tape(N, K, T, missing) if mode == "state" else executed_flops_tape(N, K, T, missing)
+        ex = executed_flops_state_tape(N, K, T, missing) if mode == "state" else executed_flops_tape(N, K, T, missing)
+        if tape_filter != "state" and N <= 32:
+            # filter_obs_kernel (round 6): per observed series the full rank-one update 2n^2 + ~10n (no d = P z', no T k); the
+            # prediction 2 (2 + 3K) per covariance element of the series rows + ~30n; unobserved entries are register copies
+            n_, m_ = N + K, N * (1.0 - missing)
+            ex = dict(ex, filter=T * (N * n_ * 2 * (2 + 3 * K) + 30 * n_ + m_ * (2 * n_ * n_ + 10 * n_)))
+        return ex
     n = N + K
     m = N * (1.0 - missing)
     filt = T * (3 * n * n + n + m * (2 * n * (1 + K) + 2 * n * n + 8 * n))
@@ -196,7 +202,7 @@ def executed_flops_state_tape(N, K, T, missing):
     return {"filter": base["filter"] + T * 4 * K * n, "smoother": base["smoother"] + T * (K * 2 * n * (n + 1) + 2 * n * n * K)}
 
 
-def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, evals=1, live=None, tape=False):
+def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, evals=1, live=None, tape=False, tape_filter=None):
     """The ``roofline`` object of the bench line for one workload: per-kernel algorithmic bytes / flops per launch over
     the hipEvent launch time, and the dominant kernel against the roof that bounds it -- HBM for the 16-lane
     filter+smoother kernels (AI ~ 3 flop/B), the fp64 pipe for the wide (n > 16) kernels and the solver objective
@@ -213,13 +219,15 @@ def build_roofline(config, N, K, T, B, mode, missing, f_avg, s_avg, packed_sym, 
                 "algorithmic_TFLOP": fl[kind] * B / 1e12, "TFLOPps": fl[kind] * B / 1e12 / (ms / 1e3)}
 
     fname = "filter_split_kernel" if (wide and N <= 32) else "filter_kernel"   # mk_split.hip serves the wide shapes with N <= 32
+    if tape and wide and N <= 32 and tape_filter != "state":
+        fname = "filter_obs_kernel"                                             # ... the tape from the filter in the observable basis (round 6)
     kernels = {fname: entry("filter", f_avg)}
     if sname:
         kernels[sname] = entry("smoother", s_avg)
     # the reference-algorithm count above is what SURVEY 8d prices; this is what the kernels' own formulation executes, and
     # real_frac -- the larger of (algorithmic bytes / time / HBM peak) and (executed flops / time / fp64 peak) -- is the
     # kernel's REAL distance from its nearer roof ("say the real fraction next to every equivalent one")
-    ex = executed_flops(N, K, T, mode, missing, tape)
+    ex = executed_flops(N, K, T, mode, missing, tape, tape_filter)
     for kname, kind, ms in ((fname, "filter", f_avg), (sname, "smoother", s_avg)):
         if kname is None:
             continue
@@ -722,7 +730,8 @@ def secondary_workload(name, local_rank, rank, dev, layout, sync, steps=5, warmu
         w.close()
         torch.cuda.empty_cache()
     lv = live_traffic(name, False) if (live and name == "c4") else None   # after the buffers are released
-    out["roofline"] = build_roofline(name, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], f_avg, s_avg, packed_sym, live=lv, tape=tape)
+    out["roofline"] = build_roofline(name, cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], f_avg, s_avg, packed_sym, live=lv, tape=tape,
+                                     tape_filter=(variants or {}).get("tape_filter"))
     if variants and variants.get("kernel_family") == "generic":   # the size-generic kernels have their own names and no roof claim
         out["roofline"]["note_generic"] = "size-generic kernels (mk_generic.hip): the figures price filter_generic_kernel / smoother_generic_kernel"
     return out
@@ -873,6 +882,8 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
     kf = BatchedKalman(local_rank, layout="time_major")
     try:
         kf.set_observations(d["obs"]).set_loadings(d["loadings"])
+        torch.cuda.synchronize()
+        t_warm = time.perf_counter()    # what the FIRST calibration of a process pays on top: reported, not timed in
         calibrate_batch(kf, maxiter=2)  # warm-up: kernel load, allocator
         # ... and the compaction path, which two iterations do not reach: the first gather / nonzero of a process loads those
         # torch kernels (~100 ms, once per process -- not a cost of the calibration)
@@ -883,6 +894,7 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
         calibrate_batch(warm, maxiter=2, fd_below=10 ** 9)
         warm.close()
         torch.cuda.synchronize()
+        t_warm = time.perf_counter() - t_warm
         t0 = time.perf_counter()
         fd_below = 4096 if N + K <= 16 else 2048   # (differenced gradients for the last stragglers: one round of wavefronts)
         res = calibrate_batch(kf, maxiter=maxiter, fd_below=fd_below)
@@ -892,7 +904,9 @@ def secondary_calibration(local_rank, dev, B=8192, N=8, K=2, T=1000, maxiter=200
         out = {"workload": "calibrate_batch: %d x (%d series, %d factors), T=%d, %d %% missing, fp64, adjoint gradient (forward differences once "
                            "%d x active models <= %d), the L-BFGS step on the device (mk_lbfgs.hip)" % (B, N, K, T, round(100 * missing), N + K + 1, fd_below),
                "seconds": dt, "models_per_s": B / dt, "iterations": int(res.nit), "objective_evaluations": int(res.nfev),
-               "launches": int(res.launches),
+               "launches": int(res.launches), "passes": int(res.passes),
+               "first_use_warmup_s": t_warm,   # kernel load, the adjoint workspace, torch's gather / nonzero kernels: once per process
+               "models_at_the_iteration_limit": int((res.nit_model >= maxiter).sum().item()),
                "converged_frac": float(res.converged.double().mean()),
                "frac_at_or_below_true_parameter_objective": float((res.obj <= true_obj + 1e-6).double().mean())}
         # real fraction of the fp64 pipe over the WHOLE calibration (wall time, host work included): every objective evaluation
@@ -1133,8 +1147,8 @@ def _sig(x, digits=5):
         if x != x or x in (float("inf"), float("-inf")):
             return None
         return float("%.*g" % (digits, x))
-    if isinstance(x, dict):
-        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, dict):   # (objectives and the headline value keep their digits: they are compared, not read)
+        return {k: _sig(v, 12 if k in ("obj", "summed_mle", "value", "models_per_s", "ms_per_step") else digits) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
         return [_sig(v, digits) for v in x]
     return x
@@ -1189,7 +1203,8 @@ def _compact_secondary(name, v):
     if "error" in v and len(v) <= 2:
         return v
     out = {}
-    for k in ("models_per_s", "objective_evaluations_per_s", "seconds", "iterations", "launches", "converged_frac", "real_frac",
+    for k in ("models_per_s", "objective_evaluations_per_s", "seconds", "iterations", "launches", "converged_frac", "real_frac", "first_use_warmup_s",
+              "models_at_the_iteration_limit",
               "frac_at_or_below_true_parameter_objective", "state_tape", "models_moved_by_lbfgsb", "nfactors_histogram", "bench_wall_s"):
         if k in v and v[k] is not None:
             out[k] = v[k]
@@ -1296,6 +1311,8 @@ def main():
     ap.add_argument("--layout", default="time_major", choices=["time_major", "model_major"])
     ap.add_argument("--projection-path", default="auto", choices=["auto", "tape", "records"],
                     help="c4: 'records' = filtered records + RTS smoother (round 3) instead of the tape path")
+    ap.add_argument("--tape-filter", default=None, choices=["observable", "state"],
+                    help="c4 / c4s: the writer of the backward tape (mk_set_kernel_variant MK_VARIANT_TAPE_FILTER; default: the library's)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU (gloo): launch, barrier, max-over-ranks, one JSON line with value null")
     args = ap.parse_args()
@@ -1363,7 +1380,7 @@ def main():
         f_avg = s_avg = 0.0
     else:
         w = Workload(args.config, local_rank, rank, dev, args.layout, args.packed_sym, batch=args.batch, T=args.T,
-                     projection_path=args.projection_path)
+                     projection_path=args.projection_path, variants=({"tape_filter": args.tape_filter} if args.tape_filter else None))
         total = w.total
         tape = getattr(w, "tape", False)
 
@@ -1465,7 +1482,8 @@ def main():
         live = None
         if world == 1 and dist is None and not args.no_live_traffic and args.batch is None and args.T is None:
             live = live_traffic(args.config, args.packed_sym, projection_path=args.projection_path)  # after the timed region
-        res["roofline"] = build_roofline(args.config, N, K, T, B, mode, missing, f_avg, s_avg, args.packed_sym, live=live, tape=tape)
+        res["roofline"] = build_roofline(args.config, N, K, T, B, mode, missing, f_avg, s_avg, args.packed_sym, live=live, tape=tape,
+                                         tape_filter=args.tape_filter)
     # ---- the other BASELINE configurations, AFTER the headline's timed region (one GPU, default headline only) ----
     if (rank == 0 and world == 1 and not args.dry_run and not args.no_secondary and args.config == "c2"
             and args.batch is None and args.T is None and not args.packed_sym):

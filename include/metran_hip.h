@@ -188,9 +188,12 @@ MK_API int mk_sync(mk_context *ctx);
  *   MK_VARIANT_KERNEL_FAMILY  0 the specialised kernels where a shape has them, 1 the size-generic kernels (mk_generic.hip) for EVERY
  *                             shape (mk_filter / mk_loglik / mk_smooth / mk_filter_smooth with dense arrays or full-square records):
  *                             the second, independent implementation of the same recursions, for cross-checks and for timing
- *                             what specialisation buys */
+ *                             what specialisation buys
+ *   MK_VARIANT_TAPE_FILTER    the writer of the backward tape (MK_OUT_TAPE), 16 < n, N <= 32: 0 filter_obs_kernel -- the filter run in the
+ *                             observable basis, where gains and columns ARE the tape's entries (round 6) --, 1 filter_split_kernel OUT = 4
+ *                             (state basis, every entry converted: round 4).  Same tape, same objective */
 enum { MK_VARIANT_SMOOTHER16 = 0, MK_VARIANT_WIDE_SMOOTHER = 1, MK_VARIANT_WIDE_FILTER = 2, MK_VARIANT_SINGLE_RECORD = 3,
-       MK_VARIANT_KERNEL_FAMILY = 4, MK_VARIANT_COUNT = 5 };
+       MK_VARIANT_KERNEL_FAMILY = 4, MK_VARIANT_TAPE_FILTER = 5, MK_VARIANT_COUNT = 6 };
 #define MK_SPARSE_RECORD_MAX_INSTANCES 16
 MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value);
 MK_API int mk_get_kernel_variant(mk_context *ctx, int which, int *value);

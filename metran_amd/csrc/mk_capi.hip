@@ -453,7 +453,8 @@ MK_API int mk_set_kernel_variant(mk_context *ctx, int which, int value)
 {
     MK_CTX(ctx);
     if (which < 0 || which >= MK_VARIANT_COUNT) return fail(MK_ERR_INVALID, "mk_set_kernel_variant: unknown selector %d", which);
-    if (value < 0 || value > ((which == MK_VARIANT_SMOOTHER16 || which == MK_VARIANT_SINGLE_RECORD || which == MK_VARIANT_KERNEL_FAMILY) ? 1 : 2))
+    if (value < 0 || value > ((which == MK_VARIANT_SMOOTHER16 || which == MK_VARIANT_SINGLE_RECORD || which == MK_VARIANT_KERNEL_FAMILY ||
+                               which == MK_VARIANT_TAPE_FILTER) ? 1 : 2))
         return fail(MK_ERR_INVALID, "mk_set_kernel_variant: value must be 0 or 1 (0, 1 or 2 for the two wide selectors)");
     ctx->variant[which] = value;
     return MK_OK;
@@ -718,6 +719,7 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     mk::FilterArgs a;
     a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER]; // 0 auto, 1 lane per state, 2 split
     a.tape = tape;
+    a.tape_basis = ctx->variant[MK_VARIANT_TAPE_FILTER]; // 0 observable basis (filter_obs_kernel), 1 state basis (filter_split_kernel OUT = 4)
     a.rs = (rec || tape) ? o->record_stride : 0;
     a.sym = (rec && (o->flags & MK_OUT_PACKED_SYM)) ? 1 : 0;
     // dense sigmas/detfs are [B,T] (stride 1); inside filtered records they are RS doubles apart

@@ -50,6 +50,8 @@ struct FilterArgs {
     long variant;        // wide models: 0 = split layout when B > 2 x #SIMDs, else filter_kernel<N,K,64> (one state per lane); 1 = one state per lane always; 2 = split always
     long tape;           // 1: F is the backward tape of the inverse-free smoother (MK_OUT_TAPE; rs = tape_stride(N, K));
                          // 2: the STATE tape (MK_OUT_TAPE | MK_OUT_VAR_ONLY; rs = state_tape_stride(N, K))
+    long tape_basis;     // tape, N <= 32: 0 = filter_obs_kernel (the filter in the observable basis, round 6), 1 = filter_split_kernel OUT = 4
+                         // (state basis, round 4) -- mk_set_kernel_variant(ctx, MK_VARIANT_TAPE_FILTER, .)
 };
 
 // Timing experiments that skip phases of a kernel (and so produce wrong numbers) exist only in builds made with

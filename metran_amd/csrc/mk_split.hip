@@ -582,6 +582,500 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
+// =====================================================================================
+// The TAPE filter in the OBSERVABLE basis (round 6).  filter_split_kernel<.., OUT = 4> above filters in Metran's own state basis
+// (series states | factor states) and converts what it writes -- per scalar update the gain T k, per unobserved series the
+// column T Pf z_u' -- into the basis of the backward pass, xt = T x, T = [[I, G], [0, I]] (the series STATES replaced by the
+// OBSERVABLES y_l = x_l + sum_k g_lk x_{N+k}).  This kernel filters in that basis from the start: the same recursion
+// (kalmanfilter.py:236-400; the tape it leaves is the same, tests/dk_ref.py) on  Pt = T P T',  where the observation row of
+// series j is the unit vector e_j:
+//     innovation      v = y_j - xt_j                        (no loadings)
+//     d = Pt e_j      d_l = Pt[l][j],  d_{N+k} = Pt[j][N+k]  (a column pick and lane j's own factor columns: no arithmetic)
+//     f = R_j + d_j
+//     gain            kt = d / f IS the tape's vector;  an unobserved series' entry is COLUMN u of Pt, its mean xt_u, its
+//                     variance Pt[u][u]: registers, not products
+// -- 32 of the ~100 f64 instructions of a pass and the whole unobserved-entry pass (16 multiply-adds per entry) go.  The price
+// is the prediction, where the transition is no longer diagonal:  Pht = T Phi T^-1 = [[Phi_s, C], [0, Phi_f]],
+// C[l][k] = g_lk (phi_{N+k} - phi_l),  Qt = T Q T' = [[Q_s + G Q_f G', G Q_f], [Q_f G', Q_f]]:
+//     xt_l   <- phi_l xt_l + sum_k C[l][k] xf_k
+//     W[k][c] = phi_c Pt[c][N+k] + sum_k' PF[k][k'] C[c][k']        (lane c, published through LDS)
+//     Pt[l][N+k] <- phi_{N+k} W[k][l] + g_lk q_{N+k}
+//     Pt[l][c]   <- phi_c (phi_l Pt[l][c] - sum_k g_ck A[k]) + sum_k g_ck E[k] + sum_k C[l][k] W[k][c] + [l = c] q_l,
+//                   A[k] = phi_l Pt[l][N+k],  E[k] = A[k] phi_{N+k} + g_lk q_{N+k}
+// 2 + 3K instructions per covariance element and step where the diagonal transition has one -- ~480 per step against the
+// ~800 + ~280 it saves at configs[3] (24 passes of two models per wavefront-step; 16 unobserved-entry bodies).  Same layout as
+// filter_split_kernel: series l of a model on lane l of its H-lane group, the K x K factor block and the factor means
+// replicated; same bookkeeping (get_mle's compressed indices, :380-382, :550-567); objective and tape only (the records of the
+// other modes are in the state basis: they keep the kernel above).
+// =====================================================================================
+template <int N, int K, int H, bool BOOK>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) filter_obs_kernel(FilterArgs a)
+{
+    constexpr int n = N + K, M = 64 / H;
+    static_assert(N <= H && (H == 16 || H == 32) && n > 16, "split layout: N series on H lanes, wide models");
+    constexpr int NP = n + (n & 1);
+    constexpr int KF = K * (K + 1) / 2;
+    constexpr int KP = (K + 1) & ~1;             // a row of K doubles, padded to 16-byte pieces
+    constexpr int GP = (K + 2) & ~1;             // a row [ g_c0 .. g_c,K-1 | phi_c ] of the loadings table
+    constexpr int SW = tape_side_c(K);
+    constexpr int XS = tape_xs_c(N, K), SS = tape_ss_c(N, K), SO = tape_so_c(N, K);
+    constexpr bool PAIRS = (K % 2 == 0 && N % 2 == 0);
+    constexpr unsigned NM = N >= 32 ? 0xffffffffu : ((1u << (N & 31)) - 1u);
+    constexpr int TS = 16;
+    constexpr unsigned HM = H == 32 ? 0xffffffffu : 0xffffu;
+    auto pf = [](int k, int k2) constexpr { return k * K - k * (k - 1) / 2 + (k2 - k); }; // k <= k2
+
+    const int lane = threadIdx.x, h = lane / H, l = lane % H;
+    const int jr = l < N ? l : N - 1;
+    long inst = (long)blockIdx.x * M + h;
+    if (inst > a.B - 1) inst = a.B - 1;
+    const long rec = inst % a.R;
+    const long T = a.T;
+
+    constexpr int DVS = NP + 2;                  // a d buffer: d [n] (+ pad), then the innovation v and its variance f of lane j
+    __shared__ __attribute__((aligned(16))) double lds[M * (2 * DVS + N * GP + N * KP + 2 * KP + TS * N + N * 2 * KP)];
+    double *dbuf = lds + h * 2 * DVS;                                        // d = Pt e_j, two buffers
+    double *gtab = lds + M * 2 * DVS + h * N * GP;                           // [N][GP]: loadings of series c, then phi_c
+    double *wtab = lds + M * (2 * DVS + N * GP) + h * N * KP;                // [N][KP]: W[.][c] of the step
+    double *ftab = lds + M * (2 * DVS + N * GP + N * KP) + h * 2 * KP;       // phi and q of the factor states
+    double *otile = lds + M * (2 * DVS + N * GP + N * KP + 2 * KP) + h * TS * N;
+    // the lane's own prediction constants C[l][.] and (G Q_f)[l][.] wait in LDS between steps (registers are what this kernel is
+    // short of: the row of Pt, the factor block and the update's pieces of d fill a two-wavefront budget)
+    double *ltab = lds + M * (2 * DVS + N * GP + N * KP + 2 * KP + TS * N) + h * N * 2 * KP + jr * 2 * KP;
+
+    auto load_k = [](const double *src, double(&dst)[K]) __attribute__((always_inline)) { // K doubles from a 16-byte aligned row
+        if constexpr (K % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < K; k += 2) {
+                const v2d t2 = *reinterpret_cast<const v2d *>(src + k);
+                dst[k] = t2.x;
+                dst[k + 1] = t2.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k + 1 < K; k += 2) {
+                const v2d t2 = *reinterpret_cast<const v2d *>(src + k);
+                dst[k] = t2.x;
+                dst[k + 1] = t2.y;
+            }
+            dst[K - 1] = src[K - 1];
+        }
+    };
+
+    const double phi_l = a.phi[inst * n + jr];
+    const double q_l = a.q[inst * n + jr];
+    double gam[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        gam[k] = a.loadings[(rec * N + jr) * K + k];
+        const double pfk = a.phi[inst * n + N + k];
+        const double qf = a.q[inst * n + N + k];
+        ltab[k] = gam[k] * (pfk - phi_l);        // C[l][k]
+        ltab[KP + k] = gam[k] * qf;              // (G Q_f)[l][k]
+        gtab[jr * GP + k] = gam[k];
+        ftab[k] = pfk;                           // every lane of the group writes the same values
+        ftab[KP + k] = qf;
+    }
+    gtab[jr * GP + K] = phi_l;
+    const double rvar = a.obsvar ? a.obsvar[rec * N + jr] : 0.0;
+    wave_lds_sync();
+
+    // initial moments (run_filter defaults, kalmanfilter.py:747-750, or the caller's) into the observable basis:
+    // xt = T x0, Pt = T P0 T':  Pt[l][N+k] = P0[l][N+k] + sum_k' g_lk' P0[N+k'][N+k],
+    // Pt[l][c] = P0[l][c] + sum_k g_ck P0[l][N+k] + sum_k g_lk Pt[c][N+k]  (the last sum uses lane c's factor columns: through wtab)
+    double xo, xk[K], P[n], PF[KF];
+#pragma unroll
+    for (int k = 0; k < K; ++k) xk[k] = a.x0 ? a.x0[inst * n + N + k] : 0.0;
+    xo = a.x0 ? a.x0[inst * n + jr] : 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) xo = fma(gam[k], xk[k], xo);
+    if (a.P0) { // a caller's initial covariance (two separate paths: one loop with a test per element kept 160 loads in flight and spilled)
+        const double *p0 = a.P0 + (inst * n + jr) * n;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = a.P0[(inst * n + N + k) * n + N + k2];
+        double p0f[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) p0f[k] = p0[N + k];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = p0f[k];
+#pragma unroll
+            for (int k2 = 0; k2 < K; ++k2) v = fma(gam[k2], PF[k <= k2 ? pf(k, k2) : pf(k2, k)], v);
+            P[N + k] = v;
+            wtab[jr * KP + k] = v;
+        }
+        wave_lds_sync();
+        sfor<0, N>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            double gc[K], wc[K];
+            load_k(gtab + c * GP, gc);
+            load_k(wtab + c * KP, wc);
+            double v = p0[c];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                v = fma(gc[k], p0f[k], v);
+                v = fma(gam[k], wc[k], v);
+            }
+            P[c] = v;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    } else { // P0 = I:  Pt = [[I + G G', G], [G', I]]
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = k == k2 ? 1.0 : 0.0;
+        int jv0 = jr; // opaque: the identity is built here, not hoisted as n selects
+        asm volatile("" : "+v"(jv0));
+        sfor<0, N>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            double gc[K];
+            load_k(gtab + c * GP, gc);
+            double v = c == jv0 ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) v = fma(gam[k], gc[k], v);
+            P[c] = v;
+            if constexpr (c % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int k = 0; k < K; ++k) P[N + k] = gam[k];
+    }
+    wave_lds_sync(); // wtab is rewritten by the first prediction
+
+    const double *obase = a.obs + rec * a.obs_bs * N + jr;
+    const long ostep = a.obs_ts * N;
+    double *trec = a.F ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step); nullptr: objective only
+    const long tstep = a.ts * a.rs;
+
+    double sum_sig = 0.0, sum_det = 0.0;
+    double run_mant = 1.0;
+    long run_exp = 0;
+    long nobs = 0, sc = 0;
+    double fmin_seen = 1.0;
+
+    for (long t0 = 0; t0 < T; t0 += TS) {
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            long tr = t0 + s;
+            if (tr > T - 1) tr = T - 1;
+            otile[s * N + jr] = obase[tr * ostep];
+        }
+        wave_lds_sync();
+        const long tend = t0 + TS < T ? t0 + TS : T;
+        for (long t = t0; t < tend; ++t) {
+            const double y = otile[(int)(t - t0) * N + jr];
+            const unsigned long long ball = __ballot(l < N && isfinite(y));
+            unsigned mrem[M];
+#pragma unroll
+            for (int g = 0; g < M; ++g) mrem[g] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ball >> (g * H)) & HM));
+            unsigned maskl = mrem[0];
+#pragma unroll
+            for (int g = 1; g < M; ++g) maskl = (h == g) ? mrem[g] : maskl;
+            const int cnt = __popc(maskl);
+
+            // ---- predict in the observable basis (header) ----
+            {
+                double A[K], E[K], W[K], Cl[K], Bq[K], phif[K];
+                load_k(ltab, Cl);
+                load_k(ltab + KP, Bq);
+                load_k(ftab, phif);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    A[k] = phi_l * P[N + k];
+                    double w = A[k];
+#pragma unroll
+                    for (int k2 = 0; k2 < K; ++k2) w = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], Cl[k2], w);
+                    W[k] = w;
+                    E[k] = fma(A[k], phif[k], Bq[k]);
+                }
+                if constexpr (K % 2 == 0) {
+#pragma unroll
+                    for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(wtab + jr * KP + k) = v2d{W[k], W[k + 1]};
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) wtab[jr * KP + k] = W[k];
+                }
+                // means: xt_l <- phi_l xt_l + C[l] . xf (old factor means)
+                xo = phi_l * xo;
+#pragma unroll
+                for (int k = 0; k < K; ++k) xo = fma(Cl[k], xk[k], xo);
+#pragma unroll
+                for (int k = 0; k < K; ++k) xk[k] = phif[k] * xk[k];
+                wave_lds_sync();
+                int jv = jr; // opaque copies: keeps the selects inside the loop
+                double qv = q_l;
+                asm volatile("" : "+v"(jv), "+v"(qv));
+                sfor<0, N>(MK_LAMBDA(cc) {
+                    constexpr int c = decltype(cc)::value;
+                    double gc[K], wc[K];
+                    load_k(gtab + c * GP, gc);
+                    load_k(wtab + c * KP, wc);
+                    const double phc = gtab[c * GP + K];
+                    double u = P[c] * phi_l;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) u = fma(-gc[k], A[k], u);
+                    double sacc = fma(u, phc, c == jv ? qv : 0.0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        sacc = fma(gc[k], E[k], sacc);
+                        sacc = fma(Cl[k], wc[k], sacc);
+                    }
+                    P[c] = sacc;
+                    if constexpr (c % 2 == 1) __builtin_amdgcn_sched_barrier(0); // bounds the table rows in flight (2 x (2K + 1) doubles)
+                });
+#pragma unroll
+                for (int k = 0; k < K; ++k) P[N + k] = fma(phif[k], W[k], Bq[k]);
+                double qf[K];
+                load_k(ftab + KP, qf);
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = fma(PF[pf(k, k2)] * phif[k], phif[k2], k == k2 ? qf[k] : 0.0);
+            }
+
+            // ---- sequential scalar updates (:341-378), ascending series order, one observation of every model per pass ----
+            double sigma = 0.0, fmant = 1.0;
+            int fexp = 0, nupd = 0;
+            unsigned many = 0;
+            unsigned urem[M];
+#pragma unroll
+            for (int g = 0; g < M; ++g) urem[g] = ~mrem[g] & NM;
+#pragma unroll
+            for (int g = 0; g < M; ++g) many |= mrem[g];
+            while (many) {
+                int jsel[M];
+                bool val[M];
+#pragma unroll
+                for (int g = 0; g < M; ++g) {
+                    val[g] = mrem[g] != 0u;
+                    jsel[g] = val[g] ? (int)__builtin_ctz(mrem[g]) : 0;
+                    mrem[g] &= mrem[g] - 1u;
+                }
+                many = 0;
+#pragma unroll
+                for (int g = 0; g < M; ++g) many |= mrem[g];
+                int jl = jsel[0];
+                bool okl = val[0];
+#pragma unroll
+                for (int g = 1; g < M; ++g) {
+                    jl = (h == g) ? jsel[g] : jl;
+                    okl = (h == g) ? val[g] : okl;
+                }
+                const double vl = y - xo;          // innovation of THIS lane's series; lane j's is the model's (:344-347)
+                double dr = 0.0;                   // d_l = Pt[l][j]: column j of the own row (:349-357 with Z_j = e_j)
+                sfor<0, M>(MK_LAMBDA(gg) {
+                    constexpr int g = decltype(gg)::value;
+                    constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
+                    pick_column<N, n, GM>(dr, __builtin_amdgcn_readfirstlane(jsel[g]), P);
+                });
+                double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
+                dv[jr] = dr;
+                if (l == jl) { // lane j: the factor part of d is its own factor columns; v and f = R_j + d_j (:359-362) ride along
+                    if constexpr (PAIRS) {
+#pragma unroll
+                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(dv + N + k) = v2d{P[N + k], P[N + k + 1]};
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) dv[N + k] = P[N + k];
+                    }
+                    *reinterpret_cast<v2d *>(dv + NP) = v2d{vl, rvar + dr};
+                }
+                wave_lds_sync();
+                const v2d vf = *reinterpret_cast<const v2d *>(dv + NP);
+                const double v = okl ? vf.x : 0.0; // a model with no observation left: the body is a no-op (lane 0's series may be
+                const double f = okl ? vf.y : 1.0; // missing there: its "innovation" is a NaN that 0 x would keep)
+                double rf = rcp_nr(f);
+                rf = okl ? rf : 0.0;
+                const double kr = dr * rf;         // gain element l (:364-366) = the tape's vector
+                {
+                    constexpr int DB = 8, NBT = (n + DB - 1) / DB; // (pieces of 12, as in the kernel above, spill the tape pointers here)
+                    double kf[K];
+                    {
+                        double dfa[K];
+                        if constexpr (PAIRS) {
+#pragma unroll
+                            for (int k = 0; k < K; k += 2) {
+                                const v2d t2 = *reinterpret_cast<const v2d *>(dv + N + k);
+                                dfa[k] = t2.x;
+                                dfa[k + 1] = t2.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) dfa[k] = dv[N + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < K; ++k) kf[k] = dfa[k] * rf;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+#pragma unroll
+                            for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = fma(-dfa[k], kf[k2], PF[pf(k, k2)]);
+                            xk[k] = fma(kf[k], v, xk[k]);
+                        }
+                    }
+                    if (trec && okl) { // tape entry of the observed series jl
+                        trec[jl * XS + jr] = kr;
+                        if (l == jl) {
+                            double *sd = trec + SO + jl * SS;
+                            if constexpr (PAIRS) {
+#pragma unroll
+                                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{kf[k], kf[k + 1]};
+                                *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{v * rf, rf};
+                                *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{y, 0.0};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) sd[k] = kf[k];
+                                sd[SW - 4] = v * rf;
+                                sd[SW - 3] = rf;
+                                sd[SW - 2] = y;
+                                sd[SW - 1] = 0.0;
+                            }
+                        }
+                    }
+                    double cur[DB], nxt[DB];
+                    auto fetch = [&](auto bb, double(&dst)[DB]) __attribute__((always_inline)) {
+                        constexpr int c0 = DB * decltype(bb)::value;
+#pragma unroll
+                        for (int i = 0; i < DB; i += 2) {
+                            if (c0 + i < n) {
+                                const v2d t2 = *reinterpret_cast<const v2d *>(dv + c0 + i);
+                                dst[i] = t2.x;
+                                dst[i + 1] = t2.y;
+                            }
+                        }
+                    };
+                    fetch(std::integral_constant<int, 0>{}, cur);
+                    sfor<0, NBT>(MK_LAMBDA(bb) {
+                        constexpr int b = decltype(bb)::value, c0 = DB * b;
+                        if constexpr (b + 1 < NBT) fetch(std::integral_constant<int, b + 1>{}, nxt);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < DB; ++i)
+                            if (c0 + i < n) P[c0 + i] = fma(-cur[i], kr, P[c0 + i]); // Pt -= k k' f (:368-372)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (b + 1 < NBT) {
+#pragma unroll
+                            for (int i = 0; i < DB; ++i) cur[i] = nxt[i];
+                        }
+                    });
+                }
+                xo = fma(kr, v, xo);               // :374-375
+                sigma = fma(v * v, rf, sigma);     // :377
+                fmant *= f;                        // detf += log f (:378) as mantissa * 2^exp
+                if ((++nupd & 3) == 0) {
+                    fexp += __builtin_amdgcn_frexp_exp(fmant);
+                    fmant = __builtin_amdgcn_frexp_mant(fmant);
+                }
+                fmin_seen = min_f64(fmin_seen, f);
+            }
+            fexp += __builtin_amdgcn_frexp_exp(fmant);
+            fmant = __builtin_amdgcn_frexp_mant(fmant);
+
+            if (cnt > 0) { // :380-382 compressed bookkeeping (per model: lanes of a group agree)
+                if constexpr (BOOK) {
+                    int le;
+                    const double lm = log_mant(fmant, le);
+                    const double detf = fma((double)(fexp + le), kLn2, lm);
+                    if (a.sigmas && l == 0) a.sigmas[(inst * a.bs + sc * a.ts) * a.sig_stride] = sigma;
+                    if (a.detfs && l == 0) a.detfs[(inst * a.bs + sc * a.ts) * a.sig_stride] = detf;
+                    if (sc >= a.warmup) { // get_mle: COMPRESSED indices (:563-564)
+                        sum_det += detf;
+                        sum_sig += sigma;
+                    }
+                } else {
+                    if (sc >= a.warmup) {
+                        sum_sig += sigma;
+                        run_mant *= fmant;
+                        run_exp += fexp + __builtin_amdgcn_frexp_exp(run_mant);
+                        run_mant = __builtin_amdgcn_frexp_mant(run_mant);
+                    }
+                }
+                ++sc;
+            }
+            if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
+
+            if (trec) {
+                // entries of the series NOT observed at this step: column u of the filtered Pt, the filtered observable and its
+                // variance -- all of them registers (static loop: the column is a named register; a wavefront-uniform branch skips
+                // the series every model of the wavefront observed)
+                unsigned uany = 0;
+#pragma unroll
+                for (int g = 0; g < M; ++g) uany |= urem[g];
+                const double qnan = __builtin_nan("");
+                int lv = l; // opaque copy: the 32 comparisons l == c below stay inside the loop (hoisted, they are 32 SGPR pairs and spills)
+                asm volatile("" : "+v"(lv));
+                if (a.tape == 2) { // STATE tape: entry N + k = [ Pt[.][N+k] | PF[.][k] | xf_k | PF[k][k] | NaN | 0 ]
+                    sfor<0, K>(MK_LAMBDA(kk) {
+                        constexpr int k = decltype(kk)::value;
+                        trec[(N + k) * XS + jr] = P[N + k];
+                        if (l == 0) {
+                            double *sd = trec + SO + (N + k) * SS;
+                            if constexpr (PAIRS) {
+#pragma unroll
+                                for (int k2 = 0; k2 < K; k2 += 2)
+                                    *reinterpret_cast<v2d *>(sd + k2) = v2d{PF[k2 <= k ? pf(k2, k) : pf(k, k2)], PF[k2 + 1 <= k ? pf(k2 + 1, k) : pf(k, k2 + 1)]};
+                                *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{xk[k], PF[pf(k, k)]};
+                                *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
+                            } else {
+#pragma unroll
+                                for (int k2 = 0; k2 < K; ++k2) sd[k2] = PF[k2 <= k ? pf(k2, k) : pf(k, k2)];
+                                sd[SW - 4] = xk[k];
+                                sd[SW - 3] = PF[pf(k, k)];
+                                sd[SW - 2] = qnan;
+                                sd[SW - 1] = 0.0;
+                            }
+                        }
+                    });
+                }
+                if (uany) {
+                    unsigned uml = urem[0];
+#pragma unroll
+                    for (int g = 1; g < M; ++g) uml = (h == g) ? urem[g] : uml;
+                    sfor<0, N>(MK_LAMBDA(cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if (uany & (1u << c)) {
+                            if ((uml >> c) & 1u) {
+                                trec[c * XS + jr] = P[c];
+                                if (lv == c) {
+                                    double *sd = trec + SO + c * SS;
+                                    if constexpr (PAIRS) {
+#pragma unroll
+                                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{P[N + k], P[N + k + 1]};
+                                        *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{xo, P[c]};
+                                        *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
+                                    } else {
+#pragma unroll
+                                        for (int k = 0; k < K; ++k) sd[k] = P[N + k];
+                                        sd[SW - 4] = xo;
+                                        sd[SW - 3] = P[c];
+                                        sd[SW - 2] = qnan;
+                                        sd[SW - 1] = 0.0;
+                                    }
+                                }
+                            }
+                        }
+                    });
+                }
+                trec += tstep;
+            }
+        }
+    }
+
+    if (BOOK) { // zero tail of the compressed arrays (np.zeros init, :307-308)
+        for (long i = sc + l; i < T; i += H) {
+            if (a.sigmas) a.sigmas[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
+            if (a.detfs) a.detfs[(inst * a.bs + i * a.ts) * a.sig_stride] = 0.0;
+        }
+    }
+    if (l == 0) {
+        if (!BOOK) sum_det = fma((double)run_exp, kLn2, log(run_mant));
+        if (a.mle) a.mle[inst] = ((double)nobs * kLog2Pi + sum_det) + sum_sig; // :566
+        if (a.sigmacount) a.sigmacount[inst] = sc;
+        if (a.status) a.status[inst] = (fmin_seen > 0.0) ? 0u : MK_FLAG_NONPOSITIVE_F; // NaN f also flags
+    }
+}
+
 // Which calls the split kernel serves: wide models (n > 16) with N <= 32, objective-only or full-square record outputs.
 template <int N, int K>
 static hipError_t launch_split_nk(const FilterArgs &a, hipStream_t s)
@@ -598,8 +1092,13 @@ static hipError_t launch_split_nk(const FilterArgs &a, hipStream_t s)
             return hipGetLastError();
         }
         if (a.tape) { // the backward tape of mk_dk.hip in a.F (a.rs = N (n + 4) doubles per model-step)
-            if (book) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, true>), dim3(grid), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, false>), dim3(grid), dim3(64), 0, s, a);
+            if (a.tape_basis == 1) { // the round-4 writer (state basis), kept as the tested A/B partner: MK_VARIANT_TAPE_FILTER
+                if (book) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, true>), dim3(grid), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((filter_split_kernel<N, K, H, 4, false>), dim3(grid), dim3(64), 0, s, a);
+            } else { // round 6: the filter in the observable basis
+                if (book) hipLaunchKernelGGL((filter_obs_kernel<N, K, H, true>), dim3(grid), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((filter_obs_kernel<N, K, H, false>), dim3(grid), dim3(64), 0, s, a);
+            }
             return hipGetLastError();
         }
         if (!any && !book) hipLaunchKernelGGL((filter_split_kernel<N, K, H, 0, false>), dim3(grid), dim3(64), 0, s, a);

@@ -101,7 +101,8 @@ class BatchedKalman:
                  "wide_smoother": (1, ("mfma", "v1", "mfma_unfolded")),
                  "wide_filter": (2, ("auto", "lane_per_state", "split")),
                  "single_record": (3, ("sparse", "stepwise")),
-                 "kernel_family": (4, ("specialised", "generic"))}
+                 "kernel_family": (4, ("specialised", "generic")),
+                 "tape_filter": (5, ("observable", "state"))}
     # variants every new engine starts with (name -> value); empty = the library's defaults.  The GPU test tier sets
     # {"wide_filter": "split"} so that its small batches keep exercising the split kernels, which "auto" reserves for
     # batches of more than two models per SIMD (tests/conftest.py; tests/test_hip_layouts.py checks "auto" itself)
@@ -110,8 +111,9 @@ class BatchedKalman:
     def set_variant(self, which, name):
         """Choose between two equivalent kernels of a shape class (``mk_set_kernel_variant``): ``"smoother16"``:
         ``"record"`` (default) | ``"blk"``; ``"wide_smoother"``: ``"mfma"`` (default) | ``"v1"`` | ``"mfma_unfolded"``; ``"wide_filter"``: ``"auto"`` (default: the split
-        layout for more than two models per SIMD, one state per lane below) | ``"lane_per_state"`` | ``"split"``.  Every
-        member is tested against the oracle; there is no environment switch."""
+        layout for more than two models per SIMD, one state per lane below) | ``"lane_per_state"`` | ``"split"``; ``"tape_filter"``
+        (the writer of the backward tape, N <= 32): ``"observable"`` (default: the filter in the observable basis) | ``"state"``.
+        Every member is tested against the oracle; there is no environment switch."""
         sel, names = self._VARIANTS[which]
         check(self._L.mk_set_kernel_variant(self._ctx, sel, names.index(name)))
         return self
