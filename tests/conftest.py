@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# a test that calls __graft_entry__.build() must not spend minutes prebuilding the shape grid (the driver's build() does that)
+os.environ.setdefault("METRAN_BUILD_SHAPES", "none")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The wide filter's default ("auto") keeps the split-layout kernels for batches of more than two models per SIMD; the

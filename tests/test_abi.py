@@ -121,15 +121,17 @@ def test_shape_module_builds_and_passes_hazard_check(tmp_path, monkeypatch):
     monkeypatch.setenv("METRAN_HIP_CACHE", str(tmp_path))
     from metran_amd import jit
 
-    path = jit.build_shape_module(7, 3)
-    assert os.path.exists(path) and path == jit.module_path(7, 3)
+    path = jit.build_shape_module(7, 3, out=jit.module_path(7, 3))   # (out=: build it HERE even where build() has prebuilt the shape)
+    assert os.path.exists(path) and path == jit.module_path(7, 3) and str(tmp_path) in path
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     for sym in ("mkmod_abi", "mkmod_shape", "mkmod_launch_filter", "mkmod_launch_smoother"):
         assert sym in out
     assert "filter_kernelILi7ELi3ELi16" in out and "smoother_record_kernelILi7ELi3ELi16" in out
     monkeypatch.setenv("METRAN_HIP_JIT", "0")
-    with pytest.raises(jit.MetranHipError):
-        jit.build_shape_module(6, 3)
+    with pytest.raises(jit.ShapeUnavailable):      # not an error of anything: the engine falls back to the size-generic kernels
+        jit.build_shape_module(63, 1, out=str(tmp_path / "never.so"))
+    # ... while a build that FAILS raises ShapeBuildError and is never a reason to fall back (round-5 advice)
+    assert issubclass(jit.ShapeBuildError, jit.MetranHipError) and not issubclass(jit.ShapeBuildError, jit.ShapeUnavailable)
 
 
 def test_generated_sweeps_header_is_current():

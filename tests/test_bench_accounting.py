@@ -63,7 +63,16 @@ def test_roofline_record_is_consistent(cfg, monkeypatch):
         assert r["algorithmic_bytes"] == pytest.approx(B * 8 * T * 2 * 110)
     else:
         assert r["bound"] == "fp64" and r["peak"] == 78.6 and r["kernel"] == "smoother_dk_kernel"
-        assert "filter_split_kernel" in r["kernels"]
+        assert "filter_obs_kernel" in r["kernels"]          # round 6: the tape's default writer (the filter in the observable basis)
+        r_state = bench.build_roofline(cfg, N, K, T, B, mode, missing, f_ms, s_ms, False, tape=tape, tape_filter="state")
+        assert "filter_split_kernel" in r_state["kernels"]  # ... and the round-4 writer behind --tape-filter state
+        # real_frac: the utilisation of the NEARER roof from what the kernels execute; never above the work-equivalent frac here
+        for rr in (r, r_state):
+            d = rr["kernels"][rr["kernel"]]
+            assert rr["real_frac"] == pytest.approx(max(d["GBps"] / 8000.0, d["executed_TFLOPps"] / 78.6)) and 0 < rr["real_frac"] < rr["frac"]
+        # (the observable-basis writer executes MORE useful flops -- its prediction is 2 + 3K multiply-adds per covariance element --
+        # in FEWER instructions: the state-basis writer's per-update work is replicated on every lane and counted once)
+        assert r["kernels"]["filter_obs_kernel"]["executed_TFLOP"] > r_state["kernels"]["filter_split_kernel"]["executed_TFLOP"]
         assert r["algorithmic_flops"] == pytest.approx(B * bench.algorithmic_flops(N, K, T, mode, missing)["smoother"])
     fs = r["survey_8d_full_output_accounting"]
     assert fs["bytes_per_model"] == (3_584_000 if cfg == "c2" else 85_760_000)
