@@ -20,6 +20,10 @@ def no_jit(monkeypatch, tmp_path):
     """A machine without hipcc: shapes outside the ahead-of-time list fall back to the generic kernels."""
     monkeypatch.setenv("METRAN_HIP_JIT", "0")
     monkeypatch.setenv("METRAN_HIP_CACHE", str(tmp_path))
+    # ... and without the modules build() prebuilds next to the library (round 6: the grid N = 2..16 x K = 1..3 ships there)
+    from metran_amd import jit
+
+    monkeypatch.setattr(jit, "PREBUILT_DIR", str(tmp_path / "no_prebuilt_modules"))
 
 
 def _check_all(kf, d, ref, obsvar=None, x0=None, P0=None):
