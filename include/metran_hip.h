@@ -325,6 +325,18 @@ enum { MK_GRAD_FORWARD = 1, MK_GRAD_BACKWARD = 2 };
 MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *prob, double *d_work, int time_major,
                                  double *d_mle, int64_t *d_sigmacount, double *d_gphi, double *d_gq,
                                  uint32_t *d_status, int phases);
+
+/* Wide models (16 < N + K <= 64), optional: an UPDATE TAPE for the adjoint gradient (round 6).  mk_adjoint_update_stride(N, K)
+ * doubles per (model, step) -- N slots [ d = P z_j' (n) | pad | 1/f, v ], one per scalar update of the step -- or 0 where the
+ * shape has none (n <= 16: the 16-lane kernel recomputes).  With a caller-owned buffer of at least n_instances * T * stride
+ * doubles on the context (mk_set_adjoint_updates; NULL detaches), the recording forward pass of mk_loglik_grad /
+ * mk_loglik_grad_phases writes the slots (one model per wavefront, whatever the batch size) and the backward walk READS them
+ * instead of recomputing every step from the filtered record of the step before -- 38 % of its instructions, and the walk is
+ * one wavefront's dependent chain (512 x (32,4), T = 500: backward pass 12.8 -> see DESIGN.md section 6).  Same gradient to
+ * rounding.  The buffer must stay valid and unchanged between the two phases of a gradient; too small a buffer for a call
+ * is simply not used. */
+MK_API int64_t mk_adjoint_update_stride(int64_t N, int64_t K);
+MK_API int mk_set_adjoint_updates(mk_context *ctx, double *d_buf, int64_t capacity_doubles);
 /* Chain rule of mk_params_from_alpha: d/dalpha = (gphi - 2 phi c gq) phi dt / alpha^2, c = 1 - sum_k
  * loadings^2 for the series, 1 for the factors (metran/metran.py:246-322). */
 MK_API int mk_alpha_grad(mk_context *ctx, int64_t B, int64_t R, int64_t N, int64_t K,

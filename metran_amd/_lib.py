@@ -117,6 +117,8 @@ API = {
     "mk_loglik_grad": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mk_loglik_grad_phases": (c_int, [c_void_p, POINTER(Problem), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int]),
+    "mk_adjoint_update_stride": (c_int64, [c_int64, c_int64]),
+    "mk_set_adjoint_updates": (c_int, [c_void_p, c_void_p, c_int64]),
     "mk_lbfgs_direction": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "mk_lbfgs_trial": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -33,6 +33,9 @@ struct mk_context {
     double *gws;       // workspace of the size-generic smoother (mk_generic.hip), grown on demand
     size_t gws_cap;    // ... in doubles
     int *lb_counters;  // device int[4] of the L-BFGS kernels (mk_lbfgs.hip)
+    double *adj_upd;   // update tape of the wide adjoint gradient (mk_set_adjoint_updates; caller-owned), nullptr = recompute
+    size_t adj_upd_cap; // ... its capacity in doubles
+    double *cur_upd;   // the tape of the recording forward pass in progress (set around do_filter by mk_loglik_grad_phases)
     void *comm;        // RCCL communicator of mk_allreduce_sum (ncclComm_t), nullptr = none
     bool comm_owned;   // created by mk_comm_init_rank (destroyed with the context) or handed in by mk_set_communicator
 };
@@ -273,6 +276,8 @@ MK_API int mk_create(int device, mk_context **out)
     ctx->lb_counters = nullptr;
     ctx->comm = nullptr;
     ctx->comm_owned = false;
+    ctx->adj_upd = ctx->cur_upd = nullptr;
+    ctx->adj_upd_cap = 0;
     for (int &v : ctx->variant) v = 0;
     for (auto &e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
@@ -720,6 +725,9 @@ static int do_filter(mk_context *ctx, const mk_problem *p, const mk_outputs *o)
     a.variant = ctx->variant[MK_VARIANT_WIDE_FILTER]; // 0 auto, 1 lane per state, 2 split
     a.tape = tape;
     a.tape_basis = ctx->variant[MK_VARIANT_TAPE_FILTER]; // 0 observable basis (filter_obs_kernel), 1 state basis (filter_split_kernel OUT = 4)
+    a.upd = ctx->cur_upd;                                // recording pass of the wide adjoint gradient: the update tape (or NULL)
+    a.us = a.upd ? mk::adjoint_update_stride_c((int)p->N, (int)p->K) : 0;
+    if (a.upd) a.variant = 1;                            // ... is written by the one-model-per-wavefront filter, whatever the batch size
     a.rs = (rec || tape) ? o->record_stride : 0;
     a.sym = (rec && (o->flags & MK_OUT_PACKED_SYM)) ? 1 : 0;
     // dense sigmas/detfs are [B,T] (stride 1); inside filtered records they are RS doubles apart
@@ -942,6 +950,21 @@ MK_API int mk_sum(mk_context *ctx, int64_t count, const double *v, double *out)
     return MK_OK;
 }
 
+MK_API int64_t mk_adjoint_update_stride(int64_t N, int64_t K)
+{
+    if (N < 1 || K < 1 || N + K <= 16 || N + K > 64) return 0; // the 16-lane adjoint kernel recomputes (n <= 16)
+    return mk::adjoint_update_stride_c((int)N, (int)K);
+}
+
+MK_API int mk_set_adjoint_updates(mk_context *ctx, double *d_buf, int64_t capacity_doubles)
+{
+    if (!ctx) return fail(MK_ERR_INVALID, "null mk_context");
+    if ((d_buf && capacity_doubles <= 0) || ((uintptr_t)d_buf & 15)) return fail(MK_ERR_INVALID, "mk_set_adjoint_updates: need a 16-byte aligned buffer and its capacity");
+    ctx->adj_upd = d_buf;
+    ctx->adj_upd_cap = d_buf ? (size_t)capacity_doubles : 0;
+    return MK_OK;
+}
+
 MK_API int mk_loglik_grad(mk_context *ctx, const mk_problem *p, double *d_work, int time_major, double *d_mle,
                           int64_t *d_sigmacount, double *d_gphi, double *d_gq, uint32_t *d_status)
 {
@@ -975,10 +998,22 @@ MK_API int mk_loglik_grad_phases(mk_context *ctx, const mk_problem *p, double *d
     o.d_detfs = o.d_sigmas + 1;
     o.time_major = time_major;
     o.record_stride = mk::record_stride((int)n);
-    if (phases & MK_GRAD_FORWARD)
-        if (int rc = do_filter(ctx, p, &o)) return rc;
+    // wide models (16 < N + K): with an update tape on the context that holds this call (mk_set_adjoint_updates), the forward pass
+    // records (d, 1/f, v) of every scalar update and the backward walk reads them instead of recomputing the step (round 6).
+    // The decision depends on the tape, the shape and the sizes only: the two phases of one gradient agree.
+    double *upd = nullptr;
+    const int64_t us = mk_adjoint_update_stride(p->N, p->K);
+    if (us > 0 && ctx->adj_upd && (size_t)(p->n_instances * p->T * us) <= ctx->adj_upd_cap) upd = ctx->adj_upd;
+    if (phases & MK_GRAD_FORWARD) {
+        ctx->cur_upd = upd;
+        const int rc = do_filter(ctx, p, &o);
+        ctx->cur_upd = nullptr;
+        if (rc) return rc;
+    }
     if (!(phases & MK_GRAD_BACKWARD)) return MK_OK;
     mk::AdjointArgs a;
+    a.upd = upd;
+    a.us = upd ? us : 0;
     a.B = p->n_instances;
     a.R = p->n_records;
     a.T = p->T;

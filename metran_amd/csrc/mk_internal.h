@@ -34,6 +34,9 @@ constexpr int tape_stride_c(int N, int K) { return N * tape_xs_c(N, K); }
 // covariance in the observable basis -- entry N + k = [ T Pf e_{N+k} (n) | x_f[N+k] | Pf[N+k][N+k] | NaN | 0 ] -- from which the
 // backward pass also gets the smoothed STATE means and variances (mk_dk.hip, STATE = true)
 constexpr int state_tape_stride_c(int N, int K) { return (N + K) * tape_xs_c(N, K); }
+// update tape of the wide adjoint gradient (round 6): N slots of (n rounded up to even) + 2 doubles per (model, step)
+constexpr int adjoint_update_slot_c(int N, int K) { return ((N + K + 1) & ~1) + 2; }
+constexpr int adjoint_update_stride_c(int N, int K) { return N * adjoint_update_slot_c(N, K); }
 
 struct FilterArgs {
     long B, R, T, warmup;
@@ -50,6 +53,10 @@ struct FilterArgs {
     long variant;        // wide models: 0 = split layout when B > 2 x #SIMDs, else filter_kernel<N,K,64> (one state per lane); 1 = one state per lane always; 2 = split always
     long tape;           // 1: F is the backward tape of the inverse-free smoother (MK_OUT_TAPE; rs = tape_stride(N, K));
                          // 2: the STATE tape (MK_OUT_TAPE | MK_OUT_VAR_ONLY; rs = state_tape_stride(N, K))
+    double *upd;         // OUT = 3, one model per wavefront (16 < n): the UPDATE TAPE of the adjoint gradient (round 6), or NULL.  Per
+    long us;             // (model, step) a block of us = adjoint_update_stride_c(N, K) doubles at (b*bs + t*ts)*us: slot u = the u-th scalar
+                         // update of the step in ascending series order, [ d = P z_j' (n) | pad | 1/f, v ] -- what adjoint_wide_kernel
+                         // otherwise recomputes from the filtered record of step t - 1
     long tape_basis;     // tape, N <= 32: 0 = filter_obs_kernel (the filter in the observable basis, round 6), 1 = filter_split_kernel OUT = 4
                          // (state basis, round 4) -- mk_set_kernel_variant(ctx, MK_VARIANT_TAPE_FILTER, .)
 };
@@ -91,6 +98,8 @@ struct AdjointArgs {
     const double *F;                 // filtered record array written by the forward filter
     const long long *sigmacount;     // [B] observed steps per instance (forward filter)
     double *gphi, *gq;               // [B,n] gradient of -2 log L w.r.t. diag(Phi), diag(Q)
+    const double *upd;               // update tape written by the recording forward pass (FilterArgs.upd), or NULL: recompute
+    long us;                         // its stride per (model, step), adjoint_update_stride_c(N, K)
 };
 
 struct SparseArgs { // objective of ONE record (all instances share it), observed steps only

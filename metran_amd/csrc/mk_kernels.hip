@@ -394,6 +394,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 6
                 const double f = readlane_f64(fl, j);
                 const double rf = rcp_nr(f);
                 const double kr = dr * rf;
+                if constexpr (OUT == 3 && !SYM) {
+                    // the recording pass of the adjoint gradient: (d, 1/f, v) of this update into slot nupd of the step's block of the
+                    // update tape -- what the backward walk would otherwise recompute from the filtered record of step t - 1 (round 6)
+                    if (a.upd) {
+                        double *ub = a.upd + (inst * a.bs + t * a.ts) * a.us + (long)nupd * adjoint_update_slot_c(N, K);
+                        ub[r] = dr;                                  // one 8 n-byte run per update
+                        if (lead) *reinterpret_cast<v2d *>(ub + NP) = v2d{rf, v};
+                    }
+                }
                 wave_lds_sync();
                 {
                     double dc[n];

@@ -1135,7 +1135,15 @@ namespace mk {
 //   step t-1, needed again by the prediction adjoint, waits in LDS.  The reference has no counterpart: scipy differences
 //   n + 1 filter runs (metran/solver.py:248-255) -- 37 of them at configs[3]'s shape.
 // =====================================================================================
-template <int N, int K>
+// UPD (round 6): the (d, 1/f, v) of every update are not recomputed but READ from the update tape the recording forward pass wrote
+// (FilterArgs.upd: filter_kernel<N,K,64,OUT=3>, one block of N slots per (model, step)) -- the forward half of a step was 38 % of this
+// kernel's instructions, and the walk is one wavefront's dependent chain.  The step's block is copied HBM -> LDS by the wavefront
+// itself (global_load_lds, asynchronous, no registers), issued when the previous block's last slot has been consumed.
+typedef __attribute__((address_space(3))) void adj_lds_void_t;
+typedef __attribute__((address_space(3))) char adj_lds_char_t;
+typedef __attribute__((address_space(1))) const void adj_global_cvoid_t;
+
+template <int N, int K, bool UPD>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) adjoint_wide_kernel(AdjointArgs a)
 {
     constexpr int n = N + K;
@@ -1143,8 +1151,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     using Gp = Group<64>;
     constexpr int NP = n + (n & 1);
     constexpr int DS = NP + 2;                  // one update: d [n] (+ pad), 1/f, v
+    static_assert(DS == adjoint_update_slot_c(N, K), "slot layout of the update tape");
     constexpr int GT = (N * K + 1) & ~1;
     constexpr int DB = 12, NBT = (n + DB - 1) / DB; // uniform LDS vectors are read in pieces of DB doubles
+    constexpr int UB = N * DS * 8, CHUNK = 64 * 16, NCH = (UB + CHUNK - 1) / CHUNK; // the block copy: 16 bytes a lane and instruction
+    constexpr int DSB = UPD ? NCH * CHUNK / 8 : N * DS;                             // (+ what its last chunk over-reads)
     const int lane = threadIdx.x;
     long inst = (long)blockIdx.x;
     const bool live = inst < a.B;
@@ -1154,11 +1165,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const double lmask = lane < n ? 1.0 : 0.0;
     const long T = a.T;
 
-    __shared__ __attribute__((aligned(16))) double lds[NP + GT + N * DS + n * NP + NP];
-    double *phim = lds;                         // diag(Phi)
+    __shared__ __attribute__((aligned(16))) double lds[DSB + NP + GT + n * NP + NP];
+    double *dS = lds;                           // per-update table of the current step (first: its LDS address is the array's own)
+    [[maybe_unused]] adj_lds_char_t *const dS3 = (adj_lds_char_t *)lds;
+    double *phim = dS + DSB;                    // diag(Phi)
     double *gtab = phim + NP;                   // loadings [N][K]
-    double *dS = gtab + GT;                     // per-update table of the current step
-    double *PL = dS + N * DS;                   // filtered covariance of step t-1, row r at PL + r NP
+    double *PL = gtab + GT;                     // filtered covariance of step t-1, row r at PL + r NP
     double *dbv = PL + n * NP;                  // db of the current update
 
     const double phi_r = a.phi[inst * n + r];
@@ -1228,17 +1240,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + r) * n + c] : (c == rv0 ? 1.0 : 0.0);
         }
     };
+    [[maybe_unused]] auto fetch_updates = [&](long t) __attribute__((always_inline)) { // HBM -> LDS, completion = vmcnt
+        const char *g = reinterpret_cast<const char *>(a.upd + (inst * a.bs + t * a.ts) * a.us);
+        sfor<0, NCH>(MK_LAMBDA(cc) {
+            constexpr int c = decltype(cc)::value;
+            long off = (long)c * CHUNK + (long)lane * 16;
+            if constexpr ((c + 1) * CHUNK > UB) off = off < (long)UB - 16 ? off : (long)UB - 16; // stay inside the block
+            __builtin_amdgcn_global_load_lds((adj_global_cvoid_t *)(g + off), (adj_lds_void_t *)(dS3 + c * CHUNK), 16, 0, 0);
+        });
+    };
+    if constexpr (UPD) fetch_updates(T - 1);
     load_prev(T - 1);
 
     for (long t = T - 1; t >= 0; --t) {
         const double xprev = xn;
         const double y = obase[t * ostep];
+        if constexpr (UPD) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this step's block of the update tape has landed in LDS
         wave_lds_sync(); // the previous step's reads of PL are complete
         store_row<n>(PL + r * NP, P);
         const unsigned long long vm = __ballot(lane < N && isfinite(y));
         if (vm != 0) {
             const double w = (sctot - rem - 1 >= a.warmup) ? 1.0 : 0.0; // compressed index of this step (:563-564)
             ++rem;
+            int cnt = 0;
+            if constexpr (UPD) {
+                cnt = __popcll(vm);             // the slots of this step are in dS already
+            } else {
             // ---- forward: prediction and scalar updates of step t, as the filter ----
             double x = phi_r * xprev;
             {
@@ -1250,7 +1277,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     P[c] = fma(P[c] * phi_r, ph, c == rv ? qv : 0.0);
                 });
             }
-            int cnt = 0;
             for (unsigned long long m = vm; m; m &= m - 1) {
                 const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m));
                 double vl = y - x;
@@ -1276,6 +1302,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 x = fma(kr, v, x);
                 ++cnt;
             }
+            } // !UPD
             // ---- reverse: adjoints back through the updates, last observation first ----
             unsigned long long mm = vm;
             for (int u = cnt - 1; u >= 0; --u) {
@@ -1292,8 +1319,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     else b1 = fma(Pb[c], dcv, b1);
                 });
                 const double b = b0 + b1;
-                const double asum = wave_sum_f64(lmask * (xb * dr)); // a = xb . d
-                const double csum = wave_sum_f64(lmask * (dr * b));  // c = d . b
+                // (round 6: the two wavefront sums on the matrix pipe -- 2 MFMA + 2 rotate-adds each, as in mk_dk.hip, instead of 8
+                // permutes, 8 lane reads and 11 additions: this walk is ONE wavefront's dependent chain, 26 us per step at configs[3]'s shape)
+                const double asum = wave_sum_mfma(lmask * (xb * dr)); // a = xb . d
+                const double csum = wave_sum_mfma(lmask * (dr * b));  // c = d . b
                 const double vrf = v * rf;
                 const double vbar = fma(2.0 * w, v, asum) * rf;
                 const double fbar = (fma(-w * v, vrf, w) - asum * vrf + csum * rf) * rf;
@@ -1314,6 +1343,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     Pb[c] = fma(hz, dbc, Pb[c]);
                 });
                 wave_lds_sync(); // dbv is rewritten by the next update
+            }
+        }
+        if constexpr (UPD) {
+            if (t > 0) {
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): no LDS read of this step's slots is still in flight
+                fetch_updates(t - 1);               // the next block on its way under the prediction adjoint
             }
         }
         // next record into the (now dead) P row: in flight during the prediction adjoint; this loop stores nothing
@@ -1378,7 +1413,12 @@ template <int N, int K>
 static hipError_t launch_adjoint_wide_nk(const AdjointArgs &a, hipStream_t s)
 {
     if constexpr (N + K > 16) {
-        hipLaunchKernelGGL((adjoint_wide_kernel<N, K>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        if (a.upd) {
+            if (a.us != adjoint_update_stride_c(N, K)) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((adjoint_wide_kernel<N, K, true>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((adjoint_wide_kernel<N, K, false>), dim3((unsigned)a.B), dim3(64), 0, s, a);
+        }
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

@@ -352,6 +352,9 @@ class BatchedKalman:
             sub._grad_work = work
             sub._grad_share = self._grad_share = getattr(self, "_grad_share", None) or {"owner": None}
             self._grad_pending = None
+        sub.adjoint_updates = self.adjoint_updates
+        if getattr(self, "_grad_upd", None) is not None:   # ... and so does the update tape of the wide adjoint gradient
+            sub._grad_upd = self._grad_upd
         return sub
 
     @property
@@ -417,6 +420,7 @@ class BatchedKalman:
         self._grad_pending = None  # the shared workspace is about to be overwritten: a forward pass waiting for its backward is void
         need = B * self.T * self.record_stride()
         work = self._take_grad_work(need)
+        self._ensure_grad_updates(B)
         mle = torch.empty(B, dtype=torch.float64, device=self.device)
         sc = torch.empty(B, dtype=torch.int64, device=self.device)
         gphi = torch.empty((B, self.n), dtype=torch.float64, device=self.device)
@@ -425,6 +429,27 @@ class BatchedKalman:
         check(self._L.mk_loglik_grad(self._ctx, ctypes.byref(prob), self._p(work), 1 if self.time_major else 0,
                                      self._p(mle), self._p(sc), self._p(gphi), self._p(gq), None))
         return mle, gphi, gq
+
+    # the update tape of the wide adjoint gradient (C ABI mk_set_adjoint_updates; round 6): True = allocate and use it where the
+    # shape has one (16 < N + K <= 64) and it fits in 40 % of the free memory, False = the backward walk recomputes every step
+    adjoint_updates = True
+
+    def _ensure_grad_updates(self, B):
+        torch = _torch()
+        us = int(self._L.mk_adjoint_update_stride(self.N, self.K)) if self.adjoint_updates else 0
+        buf = getattr(self, "_grad_upd", None)
+        need = B * self.T * us
+        if us and (buf is None or buf.numel() < need):
+            free = float(torch.cuda.mem_get_info(self.device)[0])
+            buf = torch.empty(need, dtype=torch.float64, device=self.device) if 8.0 * need <= 0.4 * free else None
+            self._grad_upd = buf
+            self._grad_upd_set = None
+        if not us:
+            buf = None
+        key = None if buf is None else (buf.data_ptr(), buf.numel())
+        if getattr(self, "_grad_upd_set", "unset") != key:   # (the context keeps the pointer: tell it only when it changes)
+            check(self._L.mk_set_adjoint_updates(self._ctx, self._p(buf), 0 if buf is None else int(buf.numel())))
+            self._grad_upd_set = key
 
     def _take_grad_work(self, need):
         """The adjoint workspace (at least ``need`` doubles), with this engine as the owner of its contents from now on: an
@@ -448,6 +473,7 @@ class BatchedKalman:
         prob, keep, B = self._problem(phi, q, warmup, x0, P0)
         need = B * self.T * self.record_stride()
         work = self._take_grad_work(need)
+        self._ensure_grad_updates(B)
         mle = torch.empty(B, dtype=torch.float64, device=self.device)
         sc = torch.empty(B, dtype=torch.int64, device=self.device)
         self._bind_stream()
