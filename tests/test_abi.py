@@ -204,3 +204,12 @@ def test_allreduce_fails_loudly_without_a_communicator(lib):
     assert "no single-rank shortcut" in src and "dlopen" in src   # librccl is bound at first use, never linked
     out = subprocess.check_output(["ldd", os.path.join(ROOT, "metran_amd", "libmetran_hip.so")], text=True)
     assert "rccl" not in out, "libmetran_hip.so must not depend on librccl at load time"
+
+
+def test_adjoint_update_tape_geometry_without_a_gpu(lib):
+    """mk_adjoint_update_stride is a pure function (round 6: N slots of n rounded up to even + 2 doubles per model-step for the wide
+    shapes, 0 for the 16-lane ones); attaching a tape to no context fails loudly."""
+    assert lib.mk_adjoint_update_stride(32, 4) == 32 * 38 and lib.mk_adjoint_update_stride(14, 3) == 14 * 20
+    assert lib.mk_adjoint_update_stride(48, 3) == 48 * 54 and lib.mk_adjoint_update_stride(8, 2) == 0
+    assert lib.mk_adjoint_update_stride(64, 1) == 0 and lib.mk_adjoint_update_stride(0, 4) == 0
+    assert lib.mk_set_adjoint_updates(None, None, 0) != 0 and b"null mk_context" in lib.mk_last_error()
