@@ -230,7 +230,52 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
         ratios = torch.tensor([0.35 ** k for k in range(S_tr)], **f64)   # 1, 0.35, 0.12, 0.04, ...: twelve of them reach 1e-5
         # the same budget of trial POINTS per model either way (max_backtracks): a straggler whose differenced gradient no longer
         # yields an acceptable step uses all of it before it is declared done, and on a small flight every round is a launch
-        for _ in range(-(-max_backtracks // S_tr)):
+        trials_left, first_round, sub, sub_idx = int(max_backtracks), True, None, None
+        while trials_left > 0:
+            if speculate and not first_round:
+                # After the first round only a few models still search (a straggler whose differenced gradient no longer yields an
+                # acceptable step uses its whole budget of trial points before it is declared done), and every further round used
+                # to be a launch over the WHOLE flight -- 11 more latency-bound launches for one or two models (round 6 trace of
+                # 512 wide models: five such iterations cost 85 ms each, a fifth of the calibration).  Those models alone, as a
+                # sub-engine, get every remaining step length that fits one launch.
+                idx = searching.nonzero().squeeze(1)
+                m = int(idx.numel())
+                S2 = min(trials_left, launch_budget // ((n + 1) * m)) if m else 0
+                if S2 > S_tr and 2 * m <= R:
+                    if sub is None or sub_idx.numel() != m or not bool(torch.equal(sub_idx, idx)):
+                        if sub is not None:
+                            sub.close()
+                        sub, sub_idx = kf.subset(idx), idx
+                    ratios2 = torch.tensor([0.35 ** k for k in range(S2)], **f64)
+                    xs, ds, los, pgs, fs, st = x[idx], d[idx], lo[idx], pg[idx], f[idx], step[idx]
+                    steps_s = st[None, :] * ratios2[:, None]                                    # [S2,m]
+                    xt_s = torch.maximum(xs[None] + steps_s[:, :, None] * ds[None], los[None])  # [S2,m,n]
+                    pts = torch.cat([xt_s[:, None], xt_s[:, None] + eye[None, :, None, :]], 1)  # [S2, n+1, m, n]
+                    phi_t, q_t = sub.params_from_alpha(pts.reshape(S2 * (n + 1) * m, n), dt=dt)
+                    fv = sub.loglik(phi_t, q_t, warmup=warmup).reshape(S2, n + 1, m)
+                    nfev += S2 * (n + 1) * m
+                    launches += 1
+                    ft_s = fv[:, 0]
+                    gd_s = (pgs[None] * (xt_s - xs[None])).sum(2)
+                    ok_s = (ft_s <= fs[None] + 1e-4 * gd_s) & torch.isfinite(ft_s)
+                    ok = ok_s.any(0)
+                    first = torch.argmax(ok_s.to(torch.int8), 0)                                # largest passing step of each model
+                    xt1 = torch.gather(xt_s, 0, first[None, :, None].expand(1, m, n))[0]
+                    ft = torch.gather(ft_s, 0, first[None])[0]
+                    gt = ((torch.gather(fv[:, 1:], 0, first[None, None, :].expand(1, n, m))[0] - ft[None]) / eps).transpose(0, 1)
+                    acc = idx[ok]
+                    x_new[acc], f_new[acc], g_acc[acc] = xt1[ok], ft[ok], gt[ok]
+                    searching[acc] = False
+                    trials_left -= S2
+                    if not bool(searching.any()):
+                        break
+                    ft_l, gd_l = ft_s[-1], gd_s[-1]                                             # go on below the shortest one
+                    curv = ft_l - fs - gd_l
+                    theta = torch.where(torch.isfinite(ft_l) & (curv > 0), -gd_l / (2.0 * curv), torch.full_like(ft_l, 0.1))
+                    step[idx] = torch.where(ok, st, st * float(ratios2[-1]) * theta.clamp(0.1, 0.5))
+                    continue
+            first_round = False
+            trials_left -= S_tr
             if S_tr > 1:
                 steps_s = step[None, :] * ratios[:, None]                                   # [S,R]
                 xt_s = torch.maximum(x[None] + steps_s[:, :, None] * d[None], lo[None])     # [S,R,n]
@@ -277,6 +322,8 @@ def calibrate_batch(kf, alpha0=10.0, pmin=1e-5, dt=1.0, warmup=1, maxiter=200, h
                 g_acc = torch.where((before & ~searching)[:, None], gt, g_acc)
             if n_search == 0:
                 break
+        if sub is not None:
+            sub.close()
         # a model still searching found no acceptable step: it is done (at numerical precision) and keeps its old gradient
         if grad_mode == "adjoint":
             # the last trial launch evaluated every model AT x_new (a model that found no step: at a rejected point)
