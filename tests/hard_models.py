@@ -131,6 +131,15 @@ def conditioning(g, b, ref):
     return 2.0 * np.finfo(float).eps * scale / float(g["q"][b].min())
 
 
+def mle_tolerance(g, b, ref, value=None):
+    """Absolute tolerance on -2 log L of model b (``value``: the objective under another warm-up, default ref["mle"]): the
+    north-star bar (1e-9 relative) plus the reference algorithm's own conditioning -- the objective is a sum of sigmas, so
+    it inherits their eps * scale / min(q) (seed 23 of the sweep holds two models whose fp64 oracle is 0.7e-9 / 1.9e-9 from
+    the extended-precision objective)."""
+    value = ref["mle"] if value is None else value
+    return (1e-9 + conditioning(g, b, ref)) * max(1.0, abs(float(value)))
+
+
 def filter_tolerances(g, b, ref):
     """(rtol of the per-step sigmas, atol of the filtered / predicted moments) for model b: the repository's bars (1e-9
     relative, 1e-10 on the scale of the moments) plus the reference algorithm's own conditioning (``conditioning``)."""

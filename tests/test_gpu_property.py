@@ -12,10 +12,12 @@ kalmanfilter.py:236-476, 550-603) or, for the gradient, the numpy adjoint restat
   loglik                   dense (one record per instance) and sparse (several parameter sets on ONE record, n <= 16)
   loglik_grad              adjoint kernels against tests/adjoint_ref.py
 
-Tolerances (fp64): -2 log L 1e-9 relative (north-star bar); per-step sigmas 1e-9 relative and filtered / predicted moments 1e-10
+Tolerances (fp64): -2 log L 1e-9 relative (north-star bar), per-step sigmas 1e-9 relative and filtered / predicted moments 1e-10
 on the scale of the moments, each plus the reference algorithm's own conditioning 2 eps scale / min(q) (hard_models.conditioning:
 ~1e-15 for an ordinary model, ~1e-7 for a persistence of 1 - 1e-9, where the oracle itself is that far from an extended-precision
-run -- found by sweeping three more seeds, METRAN_SWEEP_SEED); smoothed moments hard_models.smoother_tolerance (1e-9 + eps * cond(Pp));
+run -- found by sweeping more seeds, METRAN_SWEEP_SEED: the per-step quantities in round 5, -2 log L itself in round 6 on two
+models of seed 23 whose objective is ~1e7-1e8 because noisy data meets q ~ 1e-9: kernels 2.5e-9 / 5e-9 from the oracle, the oracle
+1.9e-9 from the extended-precision run, tests/test_property_generator.py::test_reference_algorithm_conditioning); smoothed moments hard_models.smoother_tolerance (1e-9 + eps * cond(Pp));
 gradient 1e-7 relative to its largest component (tests/test_adjoint.py's bar)."""
 import numpy as np
 import pytest
@@ -74,7 +76,7 @@ def test_filter_smooth_property(key, g, jit_cache):
         sc = ref["sigmacount"]
         what = "model %d (%s)" % (b, g["patterns"][b])
         assert int(_np(r["sigmacount"])[b]) == sc, what
-        assert abs(_np(r["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+        assert abs(_np(r["mle"])[b] - ref["mle"]) <= hard_models.mle_tolerance(g, b, ref), what
         # an innovation variance that is a ~q-sized difference of O(1) covariances carries eps / q of relative error -- in the
         # reference's own arithmetic too (hard_models.conditioning): sigma = v^2 / f, log f and the gain inherit it
         rtol_sig, atol_mom = hard_models.filter_tolerances(g, b, ref)
@@ -96,7 +98,7 @@ def test_filter_smooth_property(key, g, jit_cache):
         for b in range(B):
             ref = hard_models.oracle_model(oracle, g, b)
             what = "model %d (%s), one state per lane" % (b, g["patterns"][b])
-            assert abs(_np(r2["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+            assert abs(_np(r2["mle"])[b] - ref["mle"]) <= hard_models.mle_tolerance(g, b, ref), what
             for k in ("F", "Pf", "Xp", "Pp"):
                 np.testing.assert_allclose(_np(r2[k])[b], ref[k], rtol=0, atol=hard_models.filter_tolerances(g, b, ref)[1], err_msg=what + " " + k)
             tol = hard_models.smoother_tolerance(g, b, ref)
@@ -133,7 +135,7 @@ def test_projection_and_state_variances_property(key, g, jit_cache):
             np.testing.assert_allclose(_np(s["var"])[b], np.diagonal(ref["Ps"], axis1=1, axis2=2), rtol=0, atol=tol,
                                        err_msg=what + " state variances")
             for out in (p, s):
-                assert abs(_np(out["mle"])[b] - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+                assert abs(_np(out["mle"])[b] - ref["mle"]) <= hard_models.mle_tolerance(g, b, ref), what
     kf.close()
 
 
@@ -146,18 +148,19 @@ def test_objective_and_gradient_property(key, g, jit_cache):
     want = np.array([r["mle"] for r in refs])
     # dense objective, every warm-up the reference's indexing quirk distinguishes (compressed vs time index, :550-567)
     mle = _np(kf.loglik(g["phi"], g["q"], x0=g["x0"], P0=g["P0"]))
-    np.testing.assert_allclose(mle, want, rtol=1e-9, atol=1e-9)
+    tol = np.array([hard_models.mle_tolerance(g, b, refs[b]) for b in range(B)])
+    assert (np.abs(mle - want) <= tol).all(), (np.abs(mle - want) / tol).max()
     for warm in (0, 2):
         got = _np(kf.loglik(g["phi"], g["q"], warmup=warm, x0=g["x0"], P0=g["P0"]))
         for b in range(0, B, 3):
             o, oi, oc = oracle.set_observations(g["obs"][b])
             sc = refs[b]["sigmacount"]
             ref = oracle.get_mle(refs[b]["sigmas"][:sc], refs[b]["detfs"][:sc], oc, warmup=warm)
-            assert abs(got[b] - ref) <= 1e-9 * max(1.0, abs(ref)), (b, warm, g["patterns"][b])
+            assert abs(got[b] - ref) <= hard_models.mle_tolerance(g, b, refs[b], ref), (b, warm, g["patterns"][b])
     # adjoint gradient on a few models (the numpy restatement is a Python loop over the updates)
     if kf.has_adjoint():
         f, gphi, gq = kf.loglik_grad(g["phi"], g["q"], x0=g["x0"], P0=g["P0"])
-        np.testing.assert_allclose(_np(f), want, rtol=1e-9, atol=1e-9)
+        assert (np.abs(_np(f) - want) <= tol).all(), (np.abs(_np(f) - want) / tol).max()
         for b in range(0, B, max(1, B // 3)):
             if g["phi"][b].max() > 1.0 - 1e-6:
                 continue   # d/dq of a model with q ~ 1e-9 is ~1e9: covered by the objective itself
@@ -185,8 +188,8 @@ def test_objective_and_gradient_property(key, g, jit_cache):
                 gs = dict(g, phi=phi[s][None], q=q[s][None], obs=g["obs"][b:b + 1], loadings=g["loadings"][b:b + 1],
                           obsvar=None if g["obsvar"] is None else g["obsvar"][b:b + 1],
                           x0=None if g["x0"] is None else g["x0"][b:b + 1], P0=None if g["P0"] is None else g["P0"][b:b + 1])
-                ref = hard_models.oracle_model(oracle, gs, 0, smooth=False)["mle"]
-                assert abs(got[s] - ref) <= 1e-9 * max(1.0, abs(ref)), (b, s, g["patterns"][b])
+                ref = hard_models.oracle_model(oracle, gs, 0, smooth=False)
+                assert abs(got[s] - ref["mle"]) <= hard_models.mle_tolerance(gs, 0, ref), (b, s, g["patterns"][b])
             kf.close()
 
 
@@ -210,7 +213,7 @@ def test_generic_kernel_family_property(key, g, jit_cache):
         what = "model %d (%s)" % (b, g["patterns"][b])
         assert int(_np(r["sigmacount"])[b]) == sc, what
         for val in (_np(r["mle"])[b], mle[b], _np(s["mle"])[b], _np(p["mle"])[b]):
-            assert abs(val - ref["mle"]) <= 1e-9 * max(1.0, abs(ref["mle"])), what
+            assert abs(val - ref["mle"]) <= hard_models.mle_tolerance(g, b, ref), what
         rtol_sig, atol_mom = hard_models.filter_tolerances(g, b, ref)
         np.testing.assert_allclose(_np(r["sigmas"])[b, :sc], ref["sigmas"][:sc], rtol=rtol_sig, atol=1e-10, err_msg=what)
         np.testing.assert_allclose(_np(r["detfs"])[b, :sc], ref["detfs"][:sc], rtol=0, atol=1e-10 + 1e-15 / float(g["q"][b].min()), err_msg=what)
