@@ -45,9 +45,13 @@ CONFIGS = {
     # configs[3]'s batch with ALL six reference outputs (Xp, Pp, F, Pf, S, Ps: kalmanfilter.py:392-400, 453-474) as
     # packed-symmetric records -- 3 x 46 GB = 138 GB resident; split filter (SYM) + the RTS MFMA smoother (SYM)
     "c4f": (4096, 32, 4, 2000, 0.3, "full"),
+    # a model BEYOND the specialised envelope (100 states > 64): what only the size-generic kernels serve (mk_generic.hip) -- the
+    # reference's loops take any size (kalmanfilter.py:315-390, 453-474); all six outputs, full-square records
+    "g100": (256, 96, 4, 300, 0.3, "full"),
 }
 BASELINE_NAME = {"c2": "configs[1]", "c3": "configs[2] (per-GPU share)", "c4": "configs[3]", "c5": "configs[4] (fp64)",
-                 "c4s": "configs[3]'s batch, state outputs", "c4f": "configs[3]'s batch, all six outputs as packed-symmetric records"}
+                 "c4s": "configs[3]'s batch, state outputs", "c4f": "configs[3]'s batch, all six outputs as packed-symmetric records",
+                 "g100": "no BASELINE configuration: 96 series + 4 factors (100 states), size-generic kernels"}
 EVALS_PER_STEP = 50  # c5: "50 parameter evaluations x batch=8192"
 
 
@@ -1501,6 +1505,8 @@ def main():
                    # the size-generic kernel family -- what a shape without a specialised module runs
                    ("generic_c2", sw("c2", variants=generic, steps=3, warmup=1, live=False, cpu=False)),
                    ("generic_c4", sw("c4", variants=generic, batch=512, steps=2, warmup=1, live=False, cpu=False, n_proj=8)),
+                   # ... and a shape ONLY that family serves: 100 states, all six outputs, with the CPU beside it
+                   ("generic_96x4", sw("g100", steps=2, warmup=1, live=False, n_proj=4)),
                    ("f4_factor_analysis", lambda: secondary_factor_analysis(dev)),
                    ("f4_factor_analysis_32x4", lambda: secondary_factor_analysis(dev, N=32, K=4, reps=2, scipy_subset=256)),
                    ("f1_calibration", lambda: secondary_calibration(local_rank, dev, cpu=cpu)),

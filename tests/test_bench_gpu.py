@@ -159,7 +159,7 @@ def test_secondary_generic_kernels(line):
     assert "error" not in g2 and "error" not in g4, (g2, g4)
     assert g2["parity"]["mle"] < 1e-9 and g2["parity"]["S"] < 1e-9 and g2["parity"]["Ps"] < 1e-9, g2["parity"]
     assert g4["parity"]["mle"] < 1e-9 and g4["parity"]["sim_means"] < 1e-9 and g4["parity"]["sim_vars"] < 1e-9, g4["parity"]
-    assert g2["models_per_s"] > 15000.0 and g4["models_per_s"] > 300.0, (g2, g4)   # floors (19.8 k / 700 measured); the ratio to the specialised rate is in INTEGRATION.md
+    assert g2["models_per_s"] > 120000.0 and g4["models_per_s"] > 1800.0, (g2, g4)   # floors (round 6, second form of the family: 180 k / 2.7 k measured; the first: 19.8 k / 700); the ratio to the specialised rate is in INTEGRATION.md
     assert g2["models_per_s"] < line["models_per_s"] and g4["models_per_s"] < line["secondary"]["c4"]["models_per_s"]
 
 
