@@ -21,7 +21,7 @@ STATE_VARIANCES_FLOOR = 0.96 * BAR_C4
 # (round 6: 36.6-37.1 k measured over the round's boxes -- 1-2 % UNDER the bar: the beta / observable-basis-filter gains of the round
 # were 1.3 % and 2.4 %; the floor is the bar less the box-to-box spread, so a regression of either kernel by
 # more than that turns the tier red.  The line itself prints the bar beside the figure: bar_models_per_s.)
-SECONDARIES = ("c4", "c5", "c4_state_variances", "c4_full_sym", "generic_c2", "generic_c4", "f4_factor_analysis", "f4_factor_analysis_32x4",
+SECONDARIES = ("c4", "c5", "c4_state_variances", "c4_full_sym", "generic_c2", "generic_c4", "generic_96x4", "f4_factor_analysis", "f4_factor_analysis_32x4",
                "f1_calibration", "f1_calibration_32x4", "c1_dropin", "c1w_dropin")
 
 
@@ -161,6 +161,12 @@ def test_secondary_generic_kernels(line):
     assert g4["parity"]["mle"] < 1e-9 and g4["parity"]["sim_means"] < 1e-9 and g4["parity"]["sim_vars"] < 1e-9, g4["parity"]
     assert g2["models_per_s"] > 120000.0 and g4["models_per_s"] > 1800.0, (g2, g4)   # floors (round 6, second form of the family: 180 k / 2.7 k measured; the first: 19.8 k / 700); the ratio to the specialised rate is in INTEGRATION.md
     assert g2["models_per_s"] < line["models_per_s"] and g4["models_per_s"] < line["secondary"]["c4"]["models_per_s"]
+    # a shape ONLY this family serves (100 states): all six outputs against the oracle, and the host's cores beside it
+    g9 = line["secondary"]["generic_96x4"]
+    assert "error" not in g9, g9
+    assert g9["parity"]["mle"] < 1e-9 and g9["parity"]["S"] < 1e-9 and g9["parity"]["Ps"] < 1e-9 and g9["parity"]["Pf"] < 1e-9, g9["parity"]
+    assert g9["models_per_s"] > 700.0, g9                         # floor (1 060 measured; the first form of the family: 250)
+    assert g9["cpu"]["cores"] >= 1 and g9["models_per_s"] > 3.0 * g9["cpu"]["models_per_s"], g9   # 9.5 x 16 cores measured
 
 
 def test_secondary_configs4_solver_loop(line, full):
