@@ -48,6 +48,37 @@ struct RowOf {
     __device__ __forceinline__ int operator()(int e) const { return m ? (int)__umulhi((unsigned)e, m) : e; }
 };
 
+// 1 / x to ~1 ulp for the O(1) variances and pivots met here (the fast kernels' contract, mk_prims.h: v_rcp_f64 -- relative error
+// < 2^-25 -- and one cubically convergent step; the IEEE division is ~35 dependent-ish instructions on this chip, and an update's
+// chain waits on it)
+__device__ __forceinline__ double gen_rcp(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    return fma(r0, fma(e, e, e), r0);
+}
+
+// log of a mantissa m in [1/2, 1) (the running product of a step's innovation variances): 2 atanh((m - 1) / (m + 1)) after moving
+// m into [1/sqrt 2, sqrt 2), ten terms (truncation 2e-17); anything else (a NaN product) goes to libm
+__device__ __forceinline__ double gen_log_mant(double m)
+{
+    if (!(m >= 0.5 && m < 1.0)) return log(m);
+    const bool low = m < 0.70710678118654752440;
+    const double m2 = low ? m + m : m;
+    const double t = (m2 - 1.0) * gen_rcp(m2 + 1.0), w = t * t;
+    double p = 1.0 / 19.0;
+    p = fma(p, w, 1.0 / 17.0);
+    p = fma(p, w, 1.0 / 15.0);
+    p = fma(p, w, 1.0 / 13.0);
+    p = fma(p, w, 1.0 / 11.0);
+    p = fma(p, w, 1.0 / 9.0);
+    p = fma(p, w, 1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0);
+    p = fma(p, w, 1.0 / 3.0);
+    p = fma(p, w, 1.0);
+    return fma(t + t, p, low ? -kGenLn2 : 0.0);
+}
+
 // threads of a model's workgroup: one wavefront while a lane has at most ~16 covariance elements to carry, else four
 #ifndef MK_GEN_FT
 #define MK_GEN_FT 32
@@ -143,7 +174,7 @@ __global__ void __launch_bounds__(NT) filter_generic_kernel(FilterArgs a, int N,
             __syncthreads();
             double f = Rs[j] + d[j];                   // :359-362
             for (int k = 0; k < K; ++k) f = fma(G(j, k), d[N + k], f);
-            const double rf = 1.0 / f;
+            const double rf = gen_rcp(f);
             for (int i = tid; i < n; i += NT) x[i] = fma(d[i] * rf, v, x[i]);      // :374-375
             for (int e = tid; e < nn; e += NT) {       // P -= k k' f (:368-372)
                 const int r = row(e), c = e - r * n;
@@ -161,7 +192,7 @@ __global__ void __launch_bounds__(NT) filter_generic_kernel(FilterArgs a, int N,
             __syncthreads();
         }
         if (cnt > 0) {                                 // :380-382, compressed index sc
-            const double detf = fma((double)fexp, kGenLn2, log(fmant)) + poison;
+            const double detf = fma((double)fexp, kGenLn2, gen_log_mant(fmant)) + poison;
             if (tid == 0) {
                 if (a.sigmas) a.sigmas[blk_index(inst, sc, a.bs, a.ts) * a.sig_stride] = sigma;
                 if (a.detfs) a.detfs[blk_index(inst, sc, a.bs, a.ts) * a.sig_stride] = detf;
@@ -288,7 +319,7 @@ __global__ void __launch_bounds__(NT) smoother_generic_kernel(GenericSmootherArg
         for (int k = 0; k < n; ++k) {
             const double piv = A[k * sa + k];
             double di = 0.0;
-            if (piv > 0.0) di = 1.0 / piv;
+            if (piv > 0.0) di = gen_rcp(piv);
             else {
                 flags |= MK_FLAG_RANK_DEFICIENT;       // null direction dropped (the reference's pinv, :455)
                 if (piv < -1e-8 || !(piv == piv)) flags |= MK_FLAG_NOT_SPD;
