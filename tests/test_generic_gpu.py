@@ -54,9 +54,12 @@ def _check_all(kf, d, ref, obsvar=None, x0=None, P0=None):
 
 
 @pytest.mark.parametrize("layout", ["model_major", "time_major"])
-@pytest.mark.parametrize("N,K,T,B,missing", [(70, 3, 30, 3, 0.3), (100, 28, 12, 2, 0.5), (61, 4, 25, 2, 0.0)])
+@pytest.mark.parametrize("N,K,T,B,missing", [(70, 3, 30, 3, 0.3), (100, 28, 12, 2, 0.5), (61, 4, 25, 2, 0.0), (64, 64, 8, 2, 0.3), (92, 3, 10, 5, 0.2)])
 def test_models_beyond_64_states(N, K, T, B, missing, layout):
-    """n = 73, 128 (the limit) and 65: refused before round 5."""
+    """n = 73, 128 (the limit) and 65: refused before round 5.  Round 6 (the family's second form): (64, 64) is the limit with a
+    loadings table too large for LDS next to the covariance (the kernels' GL = false instantiation), (92, 3) the band where the
+    smoother keeps ONE of its work matrices in LDS (LW = 1; 73 and 65 states: two, LW = 2; 128: one); the small shapes below and
+    the property sweep's generic pass cover the one- and four-wavefront forms with every matrix in LDS."""
     from metran_amd.engine import BatchedKalman
 
     d = make_dfm_batch(B, N, K, T, seed=900 + N, missing=missing, first_step="random")
