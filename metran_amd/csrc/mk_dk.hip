@@ -266,7 +266,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N + K <
                 WFk[k] = fbuf[k * NP + N + (i16 < K ? i16 : K - 1)];
             }
             constexpr int CH = 8; // columns per piece: the row is read a piece ahead of its multiply-adds
-            if (!MK_TUNE_SKIP(a, 256)) // (timing builds only: what this product costs -- 3.7 of 59.7 ms at configs[3], profiles/HISTORY.md)
             sfor<0, (n + CH - 1) / CH>(MK_LAMBDA(pp) {
                 constexpr int c0 = CH * decltype(pp)::value, c1 = c0 + CH < n ? c0 + CH : n;
                 double rowp[CH];
