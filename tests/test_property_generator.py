@@ -60,12 +60,17 @@ def test_reference_algorithm_conditioning():
     implementation: on the sweep's extreme models (persistence up to 1 - 1e-9, i.e. q down to ~2e-9) the oracle -- the
     reference's algorithm in fp64 -- is itself up to ~1e-8 away from an extended-precision run of the same recursion, inside
     hard_models.conditioning's bound 2 eps scale / min(q) and (on the worst models) outside the flat bars.  The GPU tier adds
-    that bound to its tolerances (tests/test_gpu_property.py); five sweeps: the default seed, the three the bound was
-    found with, and seed 23, where -2 log L itself (a sum of sigmas of ~1e7-1e8: noisy data on a model with q ~ 1e-9) is
-    1.9e-9 from the extended-precision sum -- the 1e-9 bar on the objective carries the same bound (hard_models.mle_tolerance)."""
-    worst_sig = worst_mom = worst_obj = 0.0
+    that bound to its tolerances (tests/test_gpu_property.py); nine sweeps: the default seed, the three the bound was
+    found with, seed 23, where -2 log L itself (a sum of sigmas of ~1e7-1e8: noisy data on a model with q ~ 1e-9) is
+    1.9e-9 from the extended-precision sum -- the 1e-9 bar on the objective carries the same bound (hard_models.mle_tolerance)
+    -- and seeds 62, 68, 88, 122 (round 6: sweeps 41 .. 70 on the GPU left both kernel families 1.1e-6 / 1.5e-7 from the
+    oracle on ONE sigma each), where a sigma that is tiny beside the model's largest (5e-6 beside 8e6) is up to 29 times the
+    bound from the truth RELATIVE TO ITSELF in the oracle's own arithmetic and inside a quarter of it on the scale of the
+    largest: the conditioning term of the sigmas is absolute on that scale (hard_models.filter_tolerances), which is what
+    their only consumer, the sum, sees."""
+    worst_sig = worst_mom = worst_obj = worst_rel = 0.0
     checked = 0
-    for seed in (None, 7, 11, 2024, 23):
+    for seed in (None, 7, 11, 2024, 23, 62, 68, 88, 122):
         for (N, K, T, B), g in hard_models.groups(seed=seed):
             if N + K > 8:
                 continue            # (plain Python loops in extended precision: the small shapes hold the same extremes)
@@ -78,12 +83,19 @@ def test_reference_algorithm_conditioning():
                     continue
                 sig, F = hard_models.extended_precision_filter(g, b)
                 bound = hard_models.conditioning(g, b, ref)
-                rel = float(np.max(np.abs(ref["sigmas"][:sc] - sig.astype(float)) / np.maximum(np.abs(sig.astype(float)), 1e-300)))
+                truth = sig.astype(float)
+                diff = np.abs(ref["sigmas"][:sc] - truth)
+                atol_sig, atol_mom = hard_models.filter_tolerances(g, b, ref)
+                assert (diff <= 1e-9 * np.abs(truth) + atol_sig).all(), (seed, N, K, T, b)
+                top = max(1.0, float(np.abs(truth).max()))
+                rel = float(diff.max()) / top
                 mom = float(np.abs(ref["F"] - F.astype(float)).max())
-                assert rel <= 1e-12 + bound and mom <= 1e-12 + bound, (seed, N, K, T, b, rel, mom, bound)
+                assert rel <= 1e-12 + 0.5 * bound and mom <= 1e-12 + bound, (seed, N, K, T, b, rel, mom, bound)
                 obj = abs(float(ref["sigmas"][:sc].sum() - float(sig.sum()))) / max(1.0, abs(float(sig.sum())))
                 assert obj <= 1e-12 + bound, (seed, N, K, T, b, obj, bound)
+                worst_rel = max(worst_rel, float(np.max(diff / np.maximum(np.abs(truth), 1e-300))) / bound)
                 worst_sig, worst_mom, worst_obj = max(worst_sig, rel), max(worst_mom, mom), max(worst_obj, obj)
                 checked += 1
-    assert checked >= 20
+    assert checked >= 40
     assert worst_sig > 1e-9 and worst_mom > 1e-10 and worst_obj > 1e-9     # the flat bars are not attainable on these models
+    assert worst_rel > 10.0          # ... and neither is "relative to the sigma itself + the bound": the oracle misses it by > 10 x
