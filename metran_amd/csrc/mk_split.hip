@@ -42,6 +42,88 @@
 
 namespace mk {
 
+// LaneRow: a lane's row of the covariance in the split-layout kernels -- the N <= 32 series columns as two 16-double VECTOR values
+// pinned to v[0:31] and v[32:63] at the pick (the register allocator then keeps them there for the whole kernel: no copies in the
+// generated code), the K factor columns as scalars.  The run-time column j of a scalar update (d = P z_j', kalmanfilter.py:349-357)
+// is then ONE move under the VGPR index mode -- s_set_gpr_idx_on / v_mov_b64 v[0:1] + 2 j / s_set_gpr_idx_off, the models of the
+// wavefront one after the other under their lanes' exec masks: 14 scalar / vector instructions a pass for two models and no
+// branch.  Until the end of round 6 the column came through the jump tables of mk_jump.h (pick_column: 14 + 3 scalar
+// instructions and three taken branches per model and pick -- 12 % of filter_obs_kernel's time by a timing build without the
+// picks; hiding them under the LDS round trip bought nothing, the kernel pays per ISSUED instruction:
+// profiles/r06/ab_filter_pick_*.log).  hipcc's own lowering of a uniform index into a vector (two idx_on / idx_off sections,
+// four moves and four selects per model) got a third of the gain; an ARRAY of vectors, or the indexed read inside a lambda,
+// sends the row to scratch memory.
+typedef double v16d __attribute__((ext_vector_type(16)));
+template <int N, int K>
+struct LaneRow {
+    static constexpr int n = N + K;
+    static_assert(N <= 32, "two 16-double tuples");
+    v16d s0, s1; // columns 0 .. 15, 16 .. 31 (two MEMBERS: an array of vectors is an alloca hipcc leaves in scratch memory)
+    double f[K];
+    __device__ __forceinline__ double get(int c) const { return c < N ? (c < 16 ? s0[c & 15] : s1[c & 15]) : f[c - N]; }
+    __device__ __forceinline__ void set(int c, double v)
+    {
+        if (c < N) {
+            if (c < 16) s0[c & 15] = v;
+            else s1[c & 15] = v;
+        } else {
+            f[c - N] = v;
+        }
+    }
+    // dst (lanes of model g) = column j[g] of the own row; j[g] wavefront-uniform, < N.  H lanes per model, 64 / H models.
+    template <int H>
+    __device__ __forceinline__ void pick(double &dst, const int (&j)[64 / H]) const
+    {
+        int t;
+        unsigned long long sv;
+        if constexpr (H == 32) {
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_lshl_b32 %[t], %[j0], 1\n\t"
+                         "s_mov_b32 exec_lo, -1\n\t"
+                         "s_mov_b32 exec_hi, 0\n\t"
+                         "s_set_gpr_idx_on %[t], gpr_idx(SRC0)\n\t"
+                         "v_mov_b64 %[d], v[0:1]\n\t"
+                         "s_lshl_b32 %[t], %[j1], 1\n\t"
+                         "s_set_gpr_idx_idx %[t]\n\t"
+                         "s_mov_b32 exec_lo, 0\n\t"
+                         "s_mov_b32 exec_hi, -1\n\t"
+                         "v_mov_b64 %[d], v[0:1]\n\t"
+                         "s_set_gpr_idx_off\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [d] "+v"(dst), [t] "=&s"(t), [sv] "=&s"(sv)
+                         : [j0] "s"(j[0]), [j1] "s"(j[1]), "{v[0:31]}"(s0), "{v[32:63]}"(s1)
+                         : "scc");
+        } else {
+            static_assert(H == 16 && N <= 16, "four models of at most 16 series");
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_lshl_b32 %[t], %[j0], 1\n\t"
+                         "s_mov_b32 exec_lo, 0xffff\n\t"
+                         "s_mov_b32 exec_hi, 0\n\t"
+                         "s_set_gpr_idx_on %[t], gpr_idx(SRC0)\n\t"
+                         "v_mov_b64 %[d], v[0:1]\n\t"
+                         "s_lshl_b32 %[t], %[j1], 1\n\t"
+                         "s_set_gpr_idx_idx %[t]\n\t"
+                         "s_mov_b32 exec_lo, 0xffff0000\n\t"
+                         "v_mov_b64 %[d], v[0:1]\n\t"
+                         "s_lshl_b32 %[t], %[j2], 1\n\t"
+                         "s_set_gpr_idx_idx %[t]\n\t"
+                         "s_mov_b32 exec_lo, 0\n\t"
+                         "s_mov_b32 exec_hi, 0xffff\n\t"
+                         "v_mov_b64 %[d], v[0:1]\n\t"
+                         "s_lshl_b32 %[t], %[j3], 1\n\t"
+                         "s_set_gpr_idx_idx %[t]\n\t"
+                         "s_mov_b32 exec_hi, 0xffff0000\n\t"
+                         "v_mov_b64 %[d], v[0:1]\n\t"
+                         "s_set_gpr_idx_off\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [d] "+v"(dst), [t] "=&s"(t), [sv] "=&s"(sv)
+                         : [j0] "s"(j[0]), [j1] "s"(j[1]), [j2] "s"(j[2]), [j3] "s"(j[3]), "{v[0:31]}"(s0)
+                         : "scc");
+        }
+    }
+};
+
+
 template <int N, int K, int H, int OUT, bool BOOK, bool SYM = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) filter_split_kernel(FilterArgs a)
 {
@@ -100,11 +182,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // initial state (run_filter defaults, kalmanfilter.py:747-750)
     double x = a.x0 ? a.x0[inst * n + jr] : 0.0;
-    double xk[K], P[n], PF[KF];
+    double xk[K], PF[KF];
+    LaneRow<N, K> P;
 #pragma unroll
     for (int k = 0; k < K; ++k) xk[k] = a.x0 ? a.x0[inst * n + N + k] : 0.0;
 #pragma unroll
-    for (int c = 0; c < n; ++c) P[c] = a.P0 ? a.P0[(inst * n + jr) * n + c] : (c == jr ? 1.0 : 0.0);
+    for (int c = 0; c < n; ++c) P.set(c, a.P0 ? a.P0[(inst * n + jr) * n + c] : (c == jr ? 1.0 : 0.0));
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -121,7 +204,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int fl16 = l < K * K ? l : K * K - 1;  // factor-block element this lane writes
 
     // one (model, step) record: [ mean | covariance, row-major | p0, p1, zeros ]
-    auto emit = [&](double *r, double xv, const double(&xf)[K], const double(&Pr)[n], const double(&PFv)[KF], double p0, double p1)
+    auto emit = [&](double *r, double xv, const double(&xf)[K], const LaneRow<N, K> &Pr, const double(&PFv)[KF], double p0, double p1)
                     __attribute__((always_inline)) {
         r[jr] = xv;
         double xm = xf[0];
@@ -135,10 +218,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // P[l][N+k] as the tail of row l; the factor block comes from the replicated copy
 #pragma unroll
             for (int c = 0; c < N; ++c)
-                if (jr >= c) cov[sym_row_offset(n, c) + (jr - c)] = Pr[c];
+                if (jr >= c) cov[sym_row_offset(n, c) + (jr - c)] = Pr.get(c);
             const int rowl = jr * n - (jr * (jr - 1)) / 2 - jr;         // sym_row_offset(n, l) - l
 #pragma unroll
-            for (int k = 0; k < K; ++k) cov[rowl + N + k] = Pr[N + k];
+            for (int k = 0; k < K; ++k) cov[rowl + N + k] = Pr.get(N + k);
             wave_lds_sync();                                            // the previous record's staging reads are done
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -154,13 +237,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < n; ++c) cov[c * n + jr] = Pr[c];            // (c, l) <- P[l][c]: a contiguous run per model
+            for (int c = 0; c < n; ++c) cov[c * n + jr] = Pr.get(c);            // (c, l) <- P[l][c]: a contiguous run per model
             if constexpr (K % 2 == 0 && N % 2 == 0) {                       // (l, N+k) <- P[l][N+k]: K contiguous doubles
 #pragma unroll
-                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(cov + jr * n + N + k) = v2d{Pr[N + k], Pr[N + k + 1]};
+                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(cov + jr * n + N + k) = v2d{Pr.get(N + k), Pr.get(N + k + 1)};
             } else {
 #pragma unroll
-                for (int k = 0; k < K; ++k) cov[jr * n + N + k] = Pr[N + k];
+                for (int k = 0; k < K; ++k) cov[jr * n + N + k] = Pr.get(N + k);
             }
             wave_lds_sync();                                                // the previous record's staging reads are done
 #pragma unroll
@@ -220,7 +303,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int k = 0; k < K; ++k) xk[k] = phc[N + k] * xk[k];
 #pragma unroll
-                for (int c = 0; c < n; ++c) P[c] = fma(P[c] * phi_l, phc[c], c == jv ? qv : 0.0);
+                for (int c = 0; c < n; ++c) P.set(c, fma(P.get(c) * phi_l, phc[c], c == jv ? qv : 0.0));
 #pragma unroll
                 for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -270,11 +353,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 vl += vl2;
                 // d = P Z_j^T (:349-357): column j of the own row through a wavefront-uniform switch per model
                 double dr = 0.0;
-                sfor<0, M>(MK_LAMBDA(gg) { // lanes of group g: dr = P[l][j_g] (jump table, exec = the group's lanes)
-                    constexpr int g = decltype(gg)::value;
-                    constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
-                    pick_column<N, n, GM>(dr, __builtin_amdgcn_readfirstlane(jsel[g]), P);
-                });
+                { // lanes of group g: dr = P[l][j_g] (VGPR index mode, exec = the group's lanes: LaneRow)
+                    int ju[M];
+#pragma unroll
+                    for (int g = 0; g < M; ++g) ju[g] = __builtin_amdgcn_readfirstlane(jsel[g]);
+                    P.template pick<H>(dr, ju);
+                }
                 double gj[K];
                 {
                     const double *gp = gtab + jl * K; // loadings of series j of the lane's model
@@ -293,8 +377,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 double df[K]; // d_{N+k}: right at lane l == j (its P[l][N+k] is P[N+k][j])
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    dr = fma(P[N + k], gj[k], dr);
-                    double s = P[N + k];
+                    dr = fma(P.get(N + k), gj[k], dr);
+                    double s = P.get(N + k);
 #pragma unroll
                     for (int k2 = 0; k2 < K; ++k2) s = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], gj[k2], s);
                     df[k] = s;
@@ -395,7 +479,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < DB; ++i)
-                            if (c0 + i < n) P[c0 + i] = fma(-cur[i], kr, P[c0 + i]);
+                            if (c0 + i < n) P.set(c0 + i, fma(-cur[i], kr, P.get(c0 + i)));
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (b + 1 < NBT) {
 #pragma unroll
@@ -468,7 +552,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         yh = fma(gam[k], xk[k], yh);
-                        double sq = P[N + k];
+                        double sq = P.get(N + k);
 #pragma unroll
                         for (int k2 = 0; k2 < K; ++k2) sq = fma(gam[k2], PF[k <= k2 ? pf(k, k2) : pf(k2, k)], sq);
                         Q[k] = sq;
@@ -504,10 +588,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     wave_lds_sync(); // the previous step's table reads are done
                     if constexpr (K % 2 == 0) {
 #pragma unroll
-                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(fct + jr * KP + k) = v2d{P[N + k], P[N + k + 1]};
+                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(fct + jr * KP + k) = v2d{P.get(N + k), P.get(N + k + 1)};
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) fct[jr * KP + k] = P[N + k];
+                        for (int k = 0; k < K; ++k) fct[jr * KP + k] = P.get(N + k);
                     }
                     wave_lds_sync();
                     // static loop over the series (the column P[.][c] is a named register, the loadings / factor-column
@@ -520,7 +604,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         constexpr int c = decltype(cc)::value;
                         if (uany & (1u << c)) {
                             const double *gp = gtab + c * K, *fp = fct + c * KP;
-                            double pt = P[c], pt2 = 0.0;
+                            double pt = P.get(c), pt2 = 0.0;
                             if constexpr (K % 2 == 0) {
 #pragma unroll
                                 for (int k = 0; k < K; k += 2) {
@@ -683,7 +767,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // initial moments (run_filter defaults, kalmanfilter.py:747-750, or the caller's) into the observable basis:
     // xt = T x0, Pt = T P0 T':  Pt[l][N+k] = P0[l][N+k] + sum_k' g_lk' P0[N+k'][N+k],
     // Pt[l][c] = P0[l][c] + sum_k g_ck P0[l][N+k] + sum_k g_lk Pt[c][N+k]  (the last sum uses lane c's factor columns: through wtab)
-    double xo, xk[K], P[n], PF[KF];
+    double xo, xk[K], PF[KF];
+    LaneRow<N, K> P;
 #pragma unroll
     for (int k = 0; k < K; ++k) xk[k] = a.x0 ? a.x0[inst * n + N + k] : 0.0;
     xo = a.x0 ? a.x0[inst * n + jr] : 0.0;
@@ -703,7 +788,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             double v = p0f[k];
 #pragma unroll
             for (int k2 = 0; k2 < K; ++k2) v = fma(gam[k2], PF[k <= k2 ? pf(k, k2) : pf(k2, k)], v);
-            P[N + k] = v;
+            P.set(N + k, v);
             wtab[jr * KP + k] = v;
         }
         wave_lds_sync();
@@ -718,7 +803,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 v = fma(gc[k], p0f[k], v);
                 v = fma(gam[k], wc[k], v);
             }
-            P[c] = v;
+            P.set(c, v);
             __builtin_amdgcn_sched_barrier(0);
         });
     } else { // P0 = I:  Pt = [[I + G G', G], [G', I]]
@@ -735,11 +820,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             double v = c == jv0 ? 1.0 : 0.0;
 #pragma unroll
             for (int k = 0; k < K; ++k) v = fma(gam[k], gc[k], v);
-            P[c] = v;
+            P.set(c, v);
             if constexpr (c % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
-        for (int k = 0; k < K; ++k) P[N + k] = gam[k];
+        for (int k = 0; k < K; ++k) P.set(N + k, gam[k]);
     }
     wave_lds_sync(); // wtab is rewritten by the first prediction
 
@@ -783,7 +868,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 load_k(ftab, phif);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    A[k] = phi_l * P[N + k];
+                    A[k] = phi_l * P.get(N + k);
                     double w = A[k];
 #pragma unroll
                     for (int k2 = 0; k2 < K; ++k2) w = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], Cl[k2], w);
@@ -813,7 +898,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     load_k(gtab + c * GP, gc);
                     load_k(wtab + c * KP, wc);
                     const double phc = gtab[c * GP + K];
-                    double u = P[c] * phi_l;
+                    double u = P.get(c) * phi_l;
 #pragma unroll
                     for (int k = 0; k < K; ++k) u = fma(-gc[k], A[k], u);
                     double sacc = fma(u, phc, c == jv ? qv : 0.0);
@@ -822,11 +907,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         sacc = fma(gc[k], E[k], sacc);
                         sacc = fma(Cl[k], wc[k], sacc);
                     }
-                    P[c] = sacc;
+                    P.set(c, sacc);
                     if constexpr (c % 2 == 1) __builtin_amdgcn_sched_barrier(0); // bounds the table rows in flight (2 x (2K + 1) doubles)
                 });
 #pragma unroll
-                for (int k = 0; k < K; ++k) P[N + k] = fma(phif[k], W[k], Bq[k]);
+                for (int k = 0; k < K; ++k) P.set(N + k, fma(phif[k], W[k], Bq[k]));
                 double qf[K];
                 load_k(ftab + KP, qf);
 #pragma unroll
@@ -865,20 +950,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 const double vl = y - xo;          // innovation of THIS lane's series; lane j's is the model's (:344-347)
                 double dr = 0.0;                   // d_l = Pt[l][j]: column j of the own row (:349-357 with Z_j = e_j)
-                sfor<0, M>(MK_LAMBDA(gg) {
-                    constexpr int g = decltype(gg)::value;
-                    constexpr unsigned long long GM = (H == 32 ? 0xffffffffull : 0xffffull) << (g * H);
-                    pick_column<N, n, GM>(dr, __builtin_amdgcn_readfirstlane(jsel[g]), P);
-                });
+                {
+                    int ju[M];
+#pragma unroll
+                    for (int g = 0; g < M; ++g) ju[g] = __builtin_amdgcn_readfirstlane(jsel[g]);
+                    P.template pick<H>(dr, ju);
+                }
                 double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
                 dv[jr] = dr;
                 if (l == jl) { // lane j: the factor part of d is its own factor columns; v and f = R_j + d_j (:359-362) ride along
                     if constexpr (PAIRS) {
 #pragma unroll
-                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(dv + N + k) = v2d{P[N + k], P[N + k + 1]};
+                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(dv + N + k) = v2d{P.get(N + k), P.get(N + k + 1)};
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) dv[N + k] = P[N + k];
+                        for (int k = 0; k < K; ++k) dv[N + k] = P.get(N + k);
                     }
                     *reinterpret_cast<v2d *>(dv + NP) = v2d{vl, rvar + dr};
                 }
@@ -952,7 +1038,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < DB; ++i)
-                            if (c0 + i < n) P[c0 + i] = fma(-cur[i], kr, P[c0 + i]); // Pt -= k k' f (:368-372)
+                            if (c0 + i < n) P.set(c0 + i, fma(-cur[i], kr, P.get(c0 + i))); // Pt -= k k' f (:368-372)
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (b + 1 < NBT) {
 #pragma unroll
@@ -1008,7 +1094,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (a.tape == 2) { // STATE tape: entry N + k = [ Pt[.][N+k] | PF[.][k] | xf_k | PF[k][k] | NaN | 0 ]
                     sfor<0, K>(MK_LAMBDA(kk) {
                         constexpr int k = decltype(kk)::value;
-                        trec[(N + k) * XS + jr] = P[N + k];
+                        trec[(N + k) * XS + jr] = P.get(N + k);
                         if (l == 0) {
                             double *sd = trec + SO + (N + k) * SS;
                             if constexpr (PAIRS) {
@@ -1036,19 +1122,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         constexpr int c = decltype(cc)::value;
                         if (uany & (1u << c)) {
                             if ((uml >> c) & 1u) {
-                                trec[c * XS + jr] = P[c];
+                                trec[c * XS + jr] = P.get(c);
                                 if (lv == c) {
                                     double *sd = trec + SO + c * SS;
                                     if constexpr (PAIRS) {
 #pragma unroll
-                                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{P[N + k], P[N + k + 1]};
-                                        *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{xo, P[c]};
+                                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{P.get(N + k), P.get(N + k + 1)};
+                                        *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{xo, P.get(c)};
                                         *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
                                     } else {
 #pragma unroll
-                                        for (int k = 0; k < K; ++k) sd[k] = P[N + k];
+                                        for (int k = 0; k < K; ++k) sd[k] = P.get(N + k);
                                         sd[SW - 4] = xo;
-                                        sd[SW - 3] = P[c];
+                                        sd[SW - 3] = P.get(c);
                                         sd[SW - 2] = qnan;
                                         sd[SW - 1] = 0.0;
                                     }

@@ -1,0 +1,8 @@
+mkdir -p gpurun_out
+log=gpurun_out/r06_ab_gpr_pick.log
+: > $log
+python scripts/ab_libs.py ab/lib_base.so ab/lib_gpr.so ab/lib_gpr2.so >> $log 2>&1
+python scripts/ab_libs.py ab/lib_base.so ab/lib_gpr.so ab/lib_gpr2.so --state >> $log 2>&1
+echo "== parity of the index-mode library (tape tests + the AOT wide groups of the sweep)" >> $log
+METRAN_HIP_LIBRARY=$PWD/ab/lib_gpr2.so timeout 900 python -m pytest tests/test_dk_tape.py tests/test_gpu_property.py -q -m gpu -k "not 48 and (dk_tape or 32x4 or 14x3)" 2>&1 | tail -15 >> $log
+cat $log

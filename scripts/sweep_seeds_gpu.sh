@@ -1,0 +1,8 @@
+mkdir -p gpurun_out
+log=gpurun_out/r06_sweep_seeds_new_tolerance.log
+: > $log
+for s in 62 68 88 122 125 $(seq 71 100); do
+  echo "== seed $s" >> $log
+  METRAN_SWEEP_SEED=$s timeout 300 python -m pytest tests/test_gpu_property.py -q 2>&1 | grep -E "^E  |FAILED|passed|failed|Error" | head -20 >> $log
+done
+tail -50 $log
