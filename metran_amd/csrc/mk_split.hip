@@ -70,6 +70,39 @@ struct LaneRow {
             f[c - N] = v;
         }
     }
+    // lo / hi: d_0 .. d_15 / d_16 .. d_31 of the lane's model in EVERY 16-lane row of the model, from d_l in lane l.  H = 32: the two
+    // rows of a model trade places through v_permlane16_swap (odd rows of the first operand <-> even rows of the second: with both
+    // operands copies of d the first comes back as [row 0, row 0, row 2, row 2], the second as [row 1, row 1, row 3, row 3]).
+    template <int H>
+    static __device__ __forceinline__ void split_rows(double d, double &lo, double &hi)
+    {
+        if constexpr (H == 32) {
+            const unsigned a = (unsigned)__double2loint(d), b = (unsigned)__double2hiint(d);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+            lo = __hiloint2double((int)r1[0], (int)r0[0]);
+            hi = __hiloint2double((int)r1[1], (int)r0[1]);
+        } else {
+            lo = hi = d;
+        }
+    }
+    // series columns of the rank-one update  P[l][c] += d_c m  (m = -k_l: kalmanfilter.py:368-372), d_c broadcast inside the rows
+    // by v_fmac_f64_dpp row_newbcast -- one instruction per column on the pinned tuples, no LDS read of d
+    template <int BASE, int C>
+    static __device__ __forceinline__ void fmac_col(v16d &t, double s, double m) // element C of the tuple at v[BASE : BASE + 31]
+    {
+        if constexpr (BASE == 0)
+            asm volatile("v_fmac_f64_dpp v[%[r0]:%[r1]], %[s], %[m] row_newbcast:%[j]" MK_DPPMASK
+                         : [t] "+{v[0:31]}"(t) : [r0] "n"(2 * C), [r1] "n"(2 * C + 1), [s] "v"(s), [m] "v"(m), [j] "n"(C));
+        else
+            asm volatile("v_fmac_f64_dpp v[%[r0]:%[r1]], %[s], %[m] row_newbcast:%[j]" MK_DPPMASK
+                         : [t] "+{v[32:63]}"(t) : [r0] "n"(32 + 2 * C), [r1] "n"(32 + 2 * C + 1), [s] "v"(s), [m] "v"(m), [j] "n"(C));
+    }
+    __device__ __forceinline__ void rank_one(double lo, double hi, double m)
+    {
+        sfor<0, (N < 16 ? N : 16)>(MK_LAMBDA(cc) { fmac_col<0, decltype(cc)::value>(s0, lo, m); });
+        if constexpr (N > 16) sfor<16, N>(MK_LAMBDA(cc) { fmac_col<32, decltype(cc)::value - 16>(s1, hi, m); });
+    }
     // dst (lanes of model g) = column j[g] of the own row; j[g] wavefront-uniform, < N.  H lanes per model, 64 / H models.
     template <int H>
     __device__ __forceinline__ void pick(double &dst, const int (&j)[64 / H]) const
@@ -384,7 +417,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     df[k] = s;
                 }
                 double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
-                dv[jr] = dr;
+                double dlo, dhi;               // d in every row of the model: the operands of the rank-one update
+                LaneRow<N, K>::template split_rows<H>(dr, dlo, dhi);
                 // innovation variance f = R_j + Z_j d (:359-362), all from lane j's own values
                 double fl = rvar + dr, fl2 = 0.0;
 #pragma unroll
@@ -409,11 +443,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 rf = okl ? rf : 0.0;
                 const double kr = dr * rf;     // Kalman gain element l (:364-366)
                 {
-                    // P -= k k^T f (:368-372): P[l][c] -= d_c k_l.  d is read back from LDS (group-uniform addresses) in
-                    // pieces of DB doubles, one piece ahead of its multiply-adds: the whole vector at once is 2n VGPRs
-                    // next to the 2n of the row, and two resident wavefronts per SIMD leave 256
-                    constexpr int DB = 12, NBT = (n + DB - 1) / DB;
-                    double kf[K];
+                    // P -= k k^T f (:368-372): P[l][c] -= d_c k_l.  The series columns by broadcast multiply-adds inside the rows of
+                    // the model (LaneRow::rank_one; until the end of round 6 d was read back from LDS in pieces), the factor columns
+                    // from lane j's entries
+                    double kf[K], dfk[K];
                     {   // the factor entries first: they feed the replicated block and the factor means
                         double dfa[K];
                         if constexpr (K % 2 == 0 && N % 2 == 0) {
@@ -429,6 +462,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         }
 #pragma unroll
                         for (int k = 0; k < K; ++k) kf[k] = dfa[k] * rf;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) dfk[k] = dfa[k];
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
 #pragma unroll
@@ -460,32 +495,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             }
                         }
                     }
-                    double cur[DB], nxt[DB];
-                    auto fetch = [&](auto bb, double(&dst)[DB]) __attribute__((always_inline)) {
-                        constexpr int c0 = DB * decltype(bb)::value;
+                    P.rank_one(dlo, dhi, -kr);
 #pragma unroll
-                        for (int i = 0; i < DB; i += 2) {
-                            if (c0 + i < n) { // (dv has NP = n rounded up to even doubles: the pair read stays inside)
-                                const v2d t2 = *reinterpret_cast<const v2d *>(dv + c0 + i);
-                                dst[i] = t2.x;
-                                dst[i + 1] = t2.y;
-                            }
-                        }
-                    };
-                    fetch(std::integral_constant<int, 0>{}, cur);
-                    sfor<0, NBT>(MK_LAMBDA(bb) {
-                        constexpr int b = decltype(bb)::value, c0 = DB * b;
-                        if constexpr (b + 1 < NBT) fetch(std::integral_constant<int, b + 1>{}, nxt);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < DB; ++i)
-                            if (c0 + i < n) P.set(c0 + i, fma(-cur[i], kr, P.get(c0 + i)));
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (b + 1 < NBT) {
-#pragma unroll
-                            for (int i = 0; i < DB; ++i) cur[i] = nxt[i];
-                        }
-                    });
+                    for (int k = 0; k < K; ++k) P.set(N + k, fma(-dfk[k], kr, P.get(N + k)));
                 }
                 x = fma(kr, v, x);             // :374-375
                 sigma = fma(v * v, rf, sigma); // :377
@@ -957,7 +969,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     P.template pick<H>(dr, ju);
                 }
                 double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
-                dv[jr] = dr;
+                double dlo, dhi;                   // d in every row of the model: the operands of the rank-one update
+                LaneRow<N, K>::template split_rows<H>(dr, dlo, dhi);
                 if (l == jl) { // lane j: the factor part of d is its own factor columns; v and f = R_j + d_j (:359-362) ride along
                     if constexpr (PAIRS) {
 #pragma unroll
@@ -976,8 +989,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 rf = okl ? rf : 0.0;
                 const double kr = dr * rf;         // gain element l (:364-366) = the tape's vector
                 {
-                    constexpr int DB = 8, NBT = (n + DB - 1) / DB; // (pieces of 12, as in the kernel above, spill the tape pointers here)
                     double kf[K];
+                    double dfk[K];
                     {
                         double dfa[K];
                         if constexpr (PAIRS) {
@@ -993,6 +1006,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         }
 #pragma unroll
                         for (int k = 0; k < K; ++k) kf[k] = dfa[k] * rf;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) dfk[k] = dfa[k];
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
 #pragma unroll
@@ -1019,32 +1034,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             }
                         }
                     }
-                    double cur[DB], nxt[DB];
-                    auto fetch = [&](auto bb, double(&dst)[DB]) __attribute__((always_inline)) {
-                        constexpr int c0 = DB * decltype(bb)::value;
+                    // Pt -= k k' f (:368-372): the series columns by broadcast multiply-adds inside the rows (LaneRow::rank_one -- until the
+                    // end of round 6 every lane read d back from LDS, 18 sixteen-byte reads a pass), the factor columns from lane j's entries
+                    P.rank_one(dlo, dhi, -kr);
 #pragma unroll
-                        for (int i = 0; i < DB; i += 2) {
-                            if (c0 + i < n) {
-                                const v2d t2 = *reinterpret_cast<const v2d *>(dv + c0 + i);
-                                dst[i] = t2.x;
-                                dst[i + 1] = t2.y;
-                            }
-                        }
-                    };
-                    fetch(std::integral_constant<int, 0>{}, cur);
-                    sfor<0, NBT>(MK_LAMBDA(bb) {
-                        constexpr int b = decltype(bb)::value, c0 = DB * b;
-                        if constexpr (b + 1 < NBT) fetch(std::integral_constant<int, b + 1>{}, nxt);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < DB; ++i)
-                            if (c0 + i < n) P.set(c0 + i, fma(-cur[i], kr, P.get(c0 + i))); // Pt -= k k' f (:368-372)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (b + 1 < NBT) {
-#pragma unroll
-                            for (int i = 0; i < DB; ++i) cur[i] = nxt[i];
-                        }
-                    });
+                    for (int k = 0; k < K; ++k) P.set(N + k, fma(-dfk[k], kr, P.get(N + k)));
                 }
                 xo = fma(kr, v, xo);               // :374-375
                 sigma = fma(v * v, rf, sigma);     // :377

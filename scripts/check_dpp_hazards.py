@@ -60,6 +60,8 @@ def vgpr_written(inst):
         return set()  # memory returns are guarded by s_waitcnt, not by this hazard
     if not inst["ops"]:
         return set()
+    if op.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap")) and len(inst["ops"]) > 1:
+        return regs_of(inst["ops"][0]) | regs_of(inst["ops"][1])  # both operands are written
     return regs_of(inst["ops"][0])
 
 
@@ -115,7 +117,7 @@ def check_function(name, lines):
 
 def main(argv):
     path = argv[1]
-    want = argv[2:] or ["filter_kernel", "smoother_", "adjoint_kernel", "loglik_sparse"]
+    want = argv[2:] or ["filter_kernel", "filter_obs_kernel", "filter_split_kernel", "smoother_", "adjoint_kernel", "loglik_sparse"]
     lines = open(path).read().split("\n")
     starts = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):", l)] if m]
     total_err = []
