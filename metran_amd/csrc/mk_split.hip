@@ -942,36 +942,45 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int g = 0; g < M; ++g) many |= mrem[g];
             while (many) {
+                // The pass's bookkeeping on the SCALAR unit, spelled out (left to the compiler the loop-carried masks move to vector
+                // registers: bit scans, pops, selects and lane compares were a quarter of the pass's 32-bit vector instructions, and
+                // a wave64 instruction of any width holds the SIMD for four cycles): next set bit of every model's mask (0 and
+                // "invalid" for a model that has none left), the lanes of the valid models, the models' lanes j.
                 int jsel[M];
-                bool val[M];
+                unsigned long long okm = 0, jm = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) {
-                    val[g] = mrem[g] != 0u;
-                    jsel[g] = val[g] ? (int)__builtin_ctz(mrem[g]) : 0;
-                    mrem[g] &= mrem[g] - 1u;
+                    unsigned vs, tt;
+                    asm volatile("s_ff1_i32_b32 %[j], %[m]\n\t"
+                                 "s_cmp_lg_u32 %[m], 0\n\t"
+                                 "s_cselect_b32 %[j], %[j], 0\n\t"
+                                 "s_cselect_b32 %[v], -1, 0\n\t"
+                                 "s_add_i32 %[t], %[m], -1\n\t"
+                                 "s_and_b32 %[m], %[m], %[t]"
+                                 : [j] "=&s"(jsel[g]), [v] "=&s"(vs), [t] "=&s"(tt), [m] "+s"(mrem[g])
+                                 :
+                                 : "scc");
+                    okm |= (unsigned long long)(vs & HM) << (g * H);
+                    jm |= (unsigned long long)(vs & (1u << jsel[g])) << (g * H);
                 }
                 many = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) many |= mrem[g];
-                int jl = jsel[0];
-                bool okl = val[0];
+                double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
+                ++nupd;
+                // a model with no observation left sits the pass out: exec = the lanes of the valid models, straight from the
+                // scalar mask (until the end of round 6 its lanes ran the body as a no-op through six selects on v, f and 1/f)
+                if (__builtin_amdgcn_inverse_ballot_w64(okm)) {
+                const bool isj = __builtin_amdgcn_inverse_ballot_w64(jm); // l == j of the lane's model
+                int jl = jsel[0];                  // per lane: only the tape's address needs it
 #pragma unroll
-                for (int g = 1; g < M; ++g) {
-                    jl = (h == g) ? jsel[g] : jl;
-                    okl = (h == g) ? val[g] : okl;
-                }
+                for (int g = 1; g < M; ++g) jl = (h == g) ? jsel[g] : jl;
                 const double vl = y - xo;          // innovation of THIS lane's series; lane j's is the model's (:344-347)
                 double dr = 0.0;                   // d_l = Pt[l][j]: column j of the own row (:349-357 with Z_j = e_j)
-                {
-                    int ju[M];
-#pragma unroll
-                    for (int g = 0; g < M; ++g) ju[g] = __builtin_amdgcn_readfirstlane(jsel[g]);
-                    P.template pick<H>(dr, ju);
-                }
-                double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
+                P.template pick<H>(dr, jsel);      // (writes the lanes of every model; those sitting out do not read it)
                 double dlo, dhi;                   // d in every row of the model: the operands of the rank-one update
                 LaneRow<N, K>::template split_rows<H>(dr, dlo, dhi);
-                if (l == jl) { // lane j: the factor part of d is its own factor columns; v and f = R_j + d_j (:359-362) ride along
+                if (isj) { // lane j: the factor part of d is its own factor columns; v and f = R_j + d_j (:359-362) ride along
                     if constexpr (PAIRS) {
 #pragma unroll
                         for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(dv + N + k) = v2d{P.get(N + k), P.get(N + k + 1)};
@@ -983,10 +992,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 wave_lds_sync();
                 const v2d vf = *reinterpret_cast<const v2d *>(dv + NP);
-                const double v = okl ? vf.x : 0.0; // a model with no observation left: the body is a no-op (lane 0's series may be
-                const double f = okl ? vf.y : 1.0; // missing there: its "innovation" is a NaN that 0 x would keep)
-                double rf = rcp_nr(f);
-                rf = okl ? rf : 0.0;
+                const double v = vf.x, f = vf.y;
+                const double rf = rcp_nr(f);
                 const double kr = dr * rf;         // gain element l (:364-366) = the tape's vector
                 {
                     double kf[K];
@@ -1015,10 +1022,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             xk[k] = fma(kf[k], v, xk[k]);
                         }
                     }
-                    if (trec && okl) { // tape entry of the observed series jl
+                    if (trec) { // tape entry of the observed series jl
                         trec[jl * XS + jr] = kr;
-                        if (l == jl) {
-                            double *sd = trec + SO + jl * SS;
+                        if (isj) {
+                            double *sd = trec + SO + l * SS;
                             if constexpr (PAIRS) {
 #pragma unroll
                                 for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{kf[k], kf[k + 1]};
@@ -1042,12 +1049,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 xo = fma(kr, v, xo);               // :374-375
                 sigma = fma(v * v, rf, sigma);     // :377
-                fmant *= f;                        // detf += log f (:378) as mantissa * 2^exp
-                if ((++nupd & 3) == 0) {
-                    fexp += __builtin_amdgcn_frexp_exp(fmant);
-                    fmant = __builtin_amdgcn_frexp_mant(fmant);
-                }
+                fmant *= f;                        // detf += log f (:378) as mantissa * 2^exp, renormalised every pass (three
+                fexp += __builtin_amdgcn_frexp_exp(fmant);   // instructions; every fourth pass under selects was six)
+                fmant = __builtin_amdgcn_frexp_mant(fmant);
                 fmin_seen = min_f64(fmin_seen, f);
+                } // lanes of the valid models
             }
             fexp += __builtin_amdgcn_frexp_exp(fmant);
             fmant = __builtin_amdgcn_frexp_mant(fmant);
