@@ -358,24 +358,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int g = 0; g < M; ++g) many |= mrem[g];
             while (many) {
+                // the pass's bookkeeping on the scalar unit and exec = the lanes of the models that still have an observation
+                // (the same block as filter_obs_kernel's, where it is explained and was measured: -4 % of the launch)
                 int jsel[M];
-                bool val[M];
+                unsigned long long okm = 0, jm = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) {
-                    val[g] = mrem[g] != 0u;
-                    jsel[g] = val[g] ? (int)__builtin_ctz(mrem[g]) : 0;
-                    mrem[g] &= mrem[g] - 1u;
+                    unsigned vs, tt;
+                    asm volatile("s_ff1_i32_b32 %[j], %[m]\n\t"
+                                 "s_cmp_lg_u32 %[m], 0\n\t"
+                                 "s_cselect_b32 %[j], %[j], 0\n\t"
+                                 "s_cselect_b32 %[v], -1, 0\n\t"
+                                 "s_add_i32 %[t], %[m], -1\n\t"
+                                 "s_and_b32 %[m], %[m], %[t]"
+                                 : [j] "=&s"(jsel[g]), [v] "=&s"(vs), [t] "=&s"(tt), [m] "+s"(mrem[g])
+                                 :
+                                 : "scc");
+                    okm |= (unsigned long long)(vs & HM) << (g * H);
+                    jm |= (unsigned long long)(vs & (1u << jsel[g])) << (g * H);
                 }
                 many = 0;
 #pragma unroll
                 for (int g = 0; g < M; ++g) many |= mrem[g];
+                double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
+                ++nupd;
+                if (__builtin_amdgcn_inverse_ballot_w64(okm)) {
+                const bool isj = __builtin_amdgcn_inverse_ballot_w64(jm); // l == j of the lane's model
                 int jl = jsel[0];
-                bool okl = val[0];
 #pragma unroll
-                for (int g = 1; g < M; ++g) {
-                    jl = (h == g) ? jsel[g] : jl;
-                    okl = (h == g) ? val[g] : okl;
-                }
+                for (int g = 1; g < M; ++g) jl = (h == g) ? jsel[g] : jl;
                 // innovation (:344-347): every lane forms v_l with ITS loadings; lane j's value is the model's
                 double vl = y - x, vl2 = 0.0;
 #pragma unroll
@@ -386,12 +397,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 vl += vl2;
                 // d = P Z_j^T (:349-357): column j of the own row through a wavefront-uniform switch per model
                 double dr = 0.0;
-                { // lanes of group g: dr = P[l][j_g] (VGPR index mode, exec = the group's lanes: LaneRow)
-                    int ju[M];
-#pragma unroll
-                    for (int g = 0; g < M; ++g) ju[g] = __builtin_amdgcn_readfirstlane(jsel[g]);
-                    P.template pick<H>(dr, ju);
-                }
+                P.template pick<H>(dr, jsel); // lanes of group g: dr = P[l][j_g] (VGPR index mode, exec = the group's lanes: LaneRow)
                 double gj[K];
                 {
                     const double *gp = gtab + jl * K; // loadings of series j of the lane's model
@@ -416,7 +422,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int k2 = 0; k2 < K; ++k2) s = fma(PF[k <= k2 ? pf(k, k2) : pf(k2, k)], gj[k2], s);
                     df[k] = s;
                 }
-                double *dv = dbuf + (nupd & 1) * DVS; // two buffers: one fence per update
                 double dlo, dhi;               // d in every row of the model: the operands of the rank-one update
                 LaneRow<N, K>::template split_rows<H>(dr, dlo, dhi);
                 // innovation variance f = R_j + Z_j d (:359-362), all from lane j's own values
@@ -427,7 +432,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     else fl2 = fma(gam[k], df[k], fl2);
                 }
                 fl += fl2;
-                if (l == jl) {
+                if (isj) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) dv[N + k] = df[k];
                     // lane j's innovation and its variance travel with d through LDS (round 4: gathering them with two readlane
@@ -436,11 +441,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 wave_lds_sync();
                 const v2d vf = *reinterpret_cast<const v2d *>(dv + NP);
-                double v = vf.x, f = vf.y;
-                f = okl ? f : 1.0;             // a model with no observation left: the body is a no-op
-                v = okl ? v : 0.0;
-                double rf = rcp_nr(f);
-                rf = okl ? rf : 0.0;
+                const double v = vf.x, f = vf.y;
+                const double rf = rcp_nr(f);
                 const double kr = dr * rf;     // Kalman gain element l (:364-366)
                 {
                     // P -= k k^T f (:368-372): P[l][c] -= d_c k_l.  The series columns by broadcast multiply-adds inside the rows of
@@ -475,10 +477,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         double kt = kr;
 #pragma unroll
                         for (int k = 0; k < K; ++k) kt = fma(gam[k], kf[k], kt);
-                        if (okl && !MK_TUNE_SKIP(a, 1)) {
+                        if (!MK_TUNE_SKIP(a, 1)) {
                             trec[jl * XS + jr] = kt;
-                            if (l == jl) {
-                                double *sd = trec + SO + jl * SS;
+                            if (isj) {
+                                double *sd = trec + SO + l * SS;
                                 if constexpr (PAIRS) {
 #pragma unroll
                                     for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{kf[k], kf[k + 1]};
@@ -502,11 +504,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 x = fma(kr, v, x);             // :374-375
                 sigma = fma(v * v, rf, sigma); // :377
                 fmant *= f;                    // detf += log f (:378) as mantissa * 2^exp
-                if ((++nupd & 3) == 0) {
-                    fexp += __builtin_amdgcn_frexp_exp(fmant);
-                    fmant = __builtin_amdgcn_frexp_mant(fmant);
-                }
+                fexp += __builtin_amdgcn_frexp_exp(fmant);
+                fmant = __builtin_amdgcn_frexp_mant(fmant);
                 fmin_seen = min_f64(fmin_seen, f);
+                } // lanes of the valid models
             }
             fexp += __builtin_amdgcn_frexp_exp(fmant);
             fmant = __builtin_amdgcn_frexp_mant(fmant);
