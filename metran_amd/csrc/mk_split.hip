@@ -730,7 +730,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const long T = a.T;
 
     constexpr int DVS = NP + 2;                  // a d buffer: d [n] (+ pad), then the innovation v and its variance f of lane j
-    __shared__ __attribute__((aligned(16))) double lds[M * (2 * DVS + N * GP + N * KP + 2 * KP + TS * N + N * 2 * KP)];
+    // DIST: the K x K factor block and the factor means, replicated in every lane by the other kernels, live here ONE ELEMENT PER
+    // LANE between the predictions (lane e < KF: PF element e; lane KF + k: factor mean k): a scalar update is then two
+    // instructions on that lane's element (with its two operands read from d's buffer at the lane's own addresses) instead of
+    // KF + 2K replicated ones, and the step's prediction reads the elements back through FS doubles of LDS per model.
+    constexpr bool DIST = (KF + K <= H) && (K % 2 == 0) && !MK_TUNE_SKIP(a, 512);
+    constexpr int FS = DIST ? H : 0;
+    __shared__ __attribute__((aligned(16))) double lds[M * (2 * DVS + N * GP + N * KP + 2 * KP + TS * N + N * 2 * KP + FS)];
     double *dbuf = lds + h * 2 * DVS;                                        // d = Pt e_j, two buffers
     double *gtab = lds + M * 2 * DVS + h * N * GP;                           // [N][GP]: loadings of series c, then phi_c
     double *wtab = lds + M * (2 * DVS + N * GP) + h * N * KP;                // [N][KP]: W[.][c] of the step
@@ -739,6 +745,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // the lane's own prediction constants C[l][.] and (G Q_f)[l][.] wait in LDS between steps (registers are what this kernel is
     // short of: the row of Pt, the factor block and the update's pieces of d fill a two-wavefront budget)
     double *ltab = lds + M * (2 * DVS + N * GP + N * KP + 2 * KP + TS * N) + h * N * 2 * KP + jr * 2 * KP;
+    [[maybe_unused]] double *fbuf = lds + M * (2 * DVS + N * GP + N * KP + 2 * KP + TS * N + N * 2 * KP) + h * FS;
 
     auto load_k = [](const double *src, double(&dst)[K]) __attribute__((always_inline)) { // K doubles from a 16-byte aligned row
         if constexpr (K % 2 == 0) {
@@ -841,6 +848,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     wave_lds_sync(); // wtab is rewritten by the first prediction
 
+    // DIST: this lane's element (facc), where its two operands sit in a d buffer (a: dfa[k] / -v, b: dfa[k2] / dfa[k]), and the
+    // constants of its transition  facc <- (facc pa) pb + qd  (the replicated form's operations, element by element)
+    [[maybe_unused]] double facc = 0.0, fpa = 0.0, fpb = 0.0, fqd = 0.0;
+    [[maybe_unused]] int fao = 0, fbo = 0;
+    if constexpr (DIST) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double pk = a.phi[inst * n + N + k], qk = a.q[inst * n + N + k];
+#pragma unroll
+            for (int k2 = k; k2 < K; ++k2) {
+                const double pk2 = a.phi[inst * n + N + k2];
+                if (l == pf(k, k2)) {
+                    facc = PF[pf(k, k2)];
+                    fao = N + k;
+                    fbo = N + k2;
+                    fpa = pk;
+                    fpb = pk2;
+                    fqd = k == k2 ? qk : 0.0;
+                }
+            }
+            if (l == KF + k) {
+                facc = xk[k];
+                fao = 0;                         // -v rides in d's slot 0
+                fbo = N + k;
+                fpa = pk;
+                fpb = 1.0;
+                fqd = -0.0;                      // (x pa) 1 + (-0) = x pa, signed zeros included
+            }
+        }
+        fbuf[l < FS ? l : 0] = facc;
+        wave_lds_sync();
+    }
+
     const double *obase = a.obs + rec * a.obs_bs * N + jr;
     const long ostep = a.obs_ts * N;
     double *trec = a.F ? a.F + inst * a.bs * a.rs : nullptr; // tape block of (model, step); nullptr: objective only
@@ -876,6 +916,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // ---- predict in the observable basis (header) ----
             {
                 double A[K], E[K], W[K], Cl[K], Bq[K], phif[K];
+                if constexpr (DIST) { // the filtered factor block and means of the previous step, every lane a copy for this block only
+                    double fv[KF + K];
+#pragma unroll
+                    for (int e = 0; e < KF + K; e += 2) {
+                        const v2d t2 = *reinterpret_cast<const v2d *>(fbuf + e);
+                        fv[e] = t2.x;
+                        fv[e + 1] = t2.y;
+                    }
+#pragma unroll
+                    for (int e = 0; e < KF; ++e) PF[e] = fv[e];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) xk[k] = fv[KF + k];
+                    facc = fma(facc * fpa, fpb, fqd);
+                }
                 load_k(ltab, Cl);
                 load_k(ltab + KP, Bq);
                 load_k(ftab, phif);
@@ -899,8 +953,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 xo = phi_l * xo;
 #pragma unroll
                 for (int k = 0; k < K; ++k) xo = fma(Cl[k], xk[k], xo);
+                if constexpr (!DIST) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) xk[k] = phif[k] * xk[k];
+                    for (int k = 0; k < K; ++k) xk[k] = phif[k] * xk[k];
+                }
                 wave_lds_sync();
                 int jv = jr; // opaque copies: keeps the selects inside the loop
                 double qv = q_l;
@@ -925,18 +981,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 });
 #pragma unroll
                 for (int k = 0; k < K; ++k) P.set(N + k, fma(phif[k], W[k], Bq[k]));
-                double qf[K];
-                load_k(ftab + KP, qf);
+                if constexpr (!DIST) {
+                    double qf[K];
+                    load_k(ftab + KP, qf);
 #pragma unroll
-                for (int k = 0; k < K; ++k)
+                    for (int k = 0; k < K; ++k)
 #pragma unroll
-                    for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = fma(PF[pf(k, k2)] * phif[k], phif[k2], k == k2 ? qf[k] : 0.0);
+                        for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = fma(PF[pf(k, k2)] * phif[k], phif[k2], k == k2 ? qf[k] : 0.0);
+                }
             }
 
             // ---- sequential scalar updates (:341-378), ascending series order, one observation of every model per pass ----
             double sigma = 0.0, fmant = 1.0;
             int fexp = 0, nupd = 0;
             unsigned many = 0;
+            double skf[K], svr = 0.0, srf = 0.0;   // this lane's side row of the step's tape block (see the end of the pass)
+#pragma unroll
+            for (int k = 0; k < K; ++k) skf[k] = 0.0;
             unsigned urem[M];
 #pragma unroll
             for (int g = 0; g < M; ++g) urem[g] = ~mrem[g] & NM;
@@ -990,11 +1051,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         for (int k = 0; k < K; ++k) dv[N + k] = P.get(N + k);
                     }
                     *reinterpret_cast<v2d *>(dv + NP) = v2d{vl, rvar + dr};
+                    if constexpr (DIST) *reinterpret_cast<v2d *>(dv) = v2d{-vl, 0.0};
                 }
                 wave_lds_sync();
+                [[maybe_unused]] double fa = 0.0, fb = 0.0;
+                if constexpr (DIST) {
+                    fa = dv[fao];
+                    fb = dv[fbo];
+                }
                 const v2d vf = *reinterpret_cast<const v2d *>(dv + NP);
-                const double v = vf.x, f = vf.y;
-                const double rf = rcp_nr(f);
+                const double v = MK_TUNE_SKIP(a, 2048) ? vl : vf.x, f = MK_TUNE_SKIP(a, 2048) ? rvar + dr : vf.y; // (timing builds)
+                const double rf = MK_TUNE_SKIP(a, 1024) ? __builtin_amdgcn_rcp(f) : rcp_nr(f);
                 const double kr = dr * rf;         // gain element l (:364-366) = the tape's vector
                 {
                     double kf[K];
@@ -1013,33 +1080,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             for (int k = 0; k < K; ++k) dfa[k] = dv[N + k];
                         }
 #pragma unroll
-                        for (int k = 0; k < K; ++k) kf[k] = dfa[k] * rf;
+                        for (int k = 0; k < K; ++k) kf[k] = dfa[k] * rf; // (DIST: only the tape's writer, lane j, still needs them)
 #pragma unroll
                         for (int k = 0; k < K; ++k) dfk[k] = dfa[k];
+                        if constexpr (DIST) {
+                            facc = fma(-fa, fb * rf, facc); // PF[k][k2] -= dfa[k] kf[k2]  |  xf[k] += v kf[k]: the same two roundings
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
+                            for (int k = 0; k < K; ++k) {
 #pragma unroll
-                            for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = fma(-dfa[k], kf[k2], PF[pf(k, k2)]);
-                            xk[k] = fma(kf[k], v, xk[k]);
+                                for (int k2 = k; k2 < K; ++k2) PF[pf(k, k2)] = fma(-dfa[k], kf[k2], PF[pf(k, k2)]);
+                                xk[k] = fma(kf[k], v, xk[k]);
+                            }
                         }
                     }
-                    if (trec) { // tape entry of the observed series jl
+                    if (trec && !MK_TUNE_SKIP(a, 1)) { // tape entry of the observed series jl
                         trec[jl * XS + jr] = kr;
+                        // the entry's side row [ kf | v/f | 1/f | y | 0 ] is lane j's own: it KEEPS it (a series is observed once a
+                        // step) and every lane stores its series' side row once, at the end of the step -- stored here, under
+                        // exec = lane j, the K/2 + 2 sixteen-byte stores of one or two lanes per pass were 5.6 of the launch's 39.7 ms
+                        // at configs[3] (timing builds, profiles/r06: a store instruction costs its trip through the address unit
+                        // whatever its exec mask)
                         if (isj) {
-                            double *sd = trec + SO + l * SS;
-                            if constexpr (PAIRS) {
 #pragma unroll
-                                for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{kf[k], kf[k + 1]};
-                                *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{v * rf, rf};
-                                *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{y, 0.0};
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < K; ++k) sd[k] = kf[k];
-                                sd[SW - 4] = v * rf;
-                                sd[SW - 3] = rf;
-                                sd[SW - 2] = y;
-                                sd[SW - 1] = 0.0;
-                            }
+                            for (int k = 0; k < K; ++k) skf[k] = kf[k];
+                            svr = v * rf;
+                            srf = rf;
                         }
                     }
                     // Pt -= k k' f (:368-372): the series columns by broadcast multiply-adds inside the rows (LaneRow::rank_one -- until the
@@ -1058,6 +1124,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             fexp += __builtin_amdgcn_frexp_exp(fmant);
             fmant = __builtin_amdgcn_frexp_mant(fmant);
+            if constexpr (DIST) { // the filtered factor block and means: where the state tape's writer and the next prediction read them
+                fbuf[l < FS ? l : 0] = facc;
+                wave_lds_sync();
+            }
 
             if (cnt > 0) { // :380-382 compressed bookkeeping (per model: lanes of a group agree)
                 if constexpr (BOOK) {
@@ -1082,7 +1152,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             if (t >= a.warmup) nobs += cnt; // observation_count[warmup:] is a TIME index (:565)
 
-            if (trec) {
+            if (trec && MK_TUNE_SKIP(a, 2)) trec += tstep;
+            if (trec && !MK_TUNE_SKIP(a, 2)) {
                 // entries of the series NOT observed at this step: column u of the filtered Pt, the filtered observable and its
                 // variance -- all of them registers (static loop: the column is a named register; a wavefront-uniform branch skips
                 // the series every model of the wavefront observed)
@@ -1093,6 +1164,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 int lv = l; // opaque copy: the 32 comparisons l == c below stay inside the loop (hoisted, they are 32 SGPR pairs and spills)
                 asm volatile("" : "+v"(lv));
                 if (a.tape == 2) { // STATE tape: entry N + k = [ Pt[.][N+k] | PF[.][k] | xf_k | PF[k][k] | NaN | 0 ]
+                    if constexpr (DIST) { // the filtered factor block and means: from the exchange buffer
+#pragma unroll
+                        for (int e = 0; e < KF + K; e += 2) {
+                            const v2d t2 = *reinterpret_cast<const v2d *>(fbuf + e);
+                            if (e < KF) PF[e] = t2.x; else xk[e - KF] = t2.x;
+                            if (e + 1 < KF) PF[e + 1] = t2.y; else xk[e + 1 - KF] = t2.y;
+                        }
+                    }
                     sfor<0, K>(MK_LAMBDA(kk) {
                         constexpr int k = decltype(kk)::value;
                         trec[(N + k) * XS + jr] = P.get(N + k);
@@ -1124,25 +1203,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         if (uany & (1u << c)) {
                             if ((uml >> c) & 1u) {
                                 trec[c * XS + jr] = P.get(c);
-                                if (lv == c) {
-                                    double *sd = trec + SO + c * SS;
-                                    if constexpr (PAIRS) {
-#pragma unroll
-                                        for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{P.get(N + k), P.get(N + k + 1)};
-                                        *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{xo, P.get(c)};
-                                        *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{qnan, 0.0};
-                                    } else {
-#pragma unroll
-                                        for (int k = 0; k < K; ++k) sd[k] = P.get(N + k);
-                                        sd[SW - 4] = xo;
-                                        sd[SW - 3] = P.get(c);
-                                        sd[SW - 2] = qnan;
-                                        sd[SW - 1] = 0.0;
-                                    }
-                                }
+                                if (lv == c) srf = P.get(c);   // the filtered variance of the unobserved series c, for its side row below
                             }
                         }
                     });
+                }
+                // side rows, every series' by its own lane: [ kf | v/f | 1/f | y | 0 ] kept from its pass if it was observed,
+                // [ Pt[l][N..] | xo | Pt[l][l] | NaN | 0 ] otherwise
+                if (!MK_TUNE_SKIP(a, 4096)) {
+                    double sy = y;
+                    if (!((maskl >> l) & 1u)) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) skf[k] = P.get(N + k);
+                        svr = xo;
+                        sy = qnan;
+                    }
+                    if (l < N) {
+                        double *sd = trec + SO + l * SS;
+                        if constexpr (PAIRS) {
+#pragma unroll
+                            for (int k = 0; k < K; k += 2) *reinterpret_cast<v2d *>(sd + k) = v2d{skf[k], skf[k + 1]};
+                            *reinterpret_cast<v2d *>(sd + SW - 4) = v2d{svr, srf};
+                            *reinterpret_cast<v2d *>(sd + SW - 2) = v2d{sy, 0.0};
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) sd[k] = skf[k];
+                            sd[SW - 4] = svr;
+                            sd[SW - 3] = srf;
+                            sd[SW - 2] = sy;
+                            sd[SW - 1] = 0.0;
+                        }
+                    }
                 }
                 trec += tstep;
             }
