@@ -17,10 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAR_C4 = 0.40 * 8000e9 / (8 * 2000 * (32 + 4 * (36 + 36 * 36)))   # 40 % of 8 TB/s in full-output accounting = 37 313 models/s
 # smooth_state_variances at configs[3]'s shape: the bar of the same accounting (the floor used to be the OLD
 # path's 31.7 k, so the tier stayed green while the line sat under the bar)
-STATE_VARIANCES_FLOOR = 0.96 * BAR_C4
-# (round 6: 36.6-37.1 k measured over the round's boxes -- 1-2 % UNDER the bar: the beta / observable-basis-filter gains of the round
-# were 1.3 % and 2.4 %; the floor is the bar less the box-to-box spread, so a regression of either kernel by
-# more than that turns the tier red.  The line itself prints the bar beside the figure: bar_models_per_s.)
+STATE_VARIANCES_FLOOR = BAR_C4
+# (end of round 6: 42.4 k measured -- the bar is passed by 13 %, so the floor IS the bar, as the round-5 verdict asked; earlier in the
+# round the line sat 1-2 % under it and the floor was the bar less the box-to-box spread.  The line prints the bar: bar_models_per_s.)
+C4_FLOOR = 43000.0   # configs[3], projection outputs: 47.3 k measured at the end of round 6 (the round-5 verdict asked for 45 k in the line); the floor leaves 9 % for a slow lease
 SECONDARIES = ("c4", "c5", "c4_state_variances", "c4_full_sym", "generic_c2", "generic_c4", "generic_96x4", "f4_factor_analysis", "f4_factor_analysis_32x4",
                "f1_calibration", "f1_calibration_32x4", "c1_dropin", "c1w_dropin")
 
@@ -106,7 +106,7 @@ def test_secondary_configs3_throughput_floor(line, full):
     # the floor IS the north-star bar in SURVEY 8d's full-output accounting (0.40 x 8 TB/s / 85.76 MB per model = 37 313 models/s;
     # a floor of 32 k would have stayed green with configs[3] back under it)
     assert 37300.0 < s["bar_models_per_s"] < 37330.0 and abs(s["bar_models_per_s"] - BAR_C4) < 1.0
-    assert s["models_per_s"] >= s["bar_models_per_s"], s
+    assert s["models_per_s"] >= s["bar_models_per_s"] and s["models_per_s"] >= C4_FLOOR, s
     assert 0.0 < s["roofline"]["frac"] < 1.0
     # the real fraction is printed beside the equivalent ones: 0.2x executed against 0.4x / 0.6 equivalent
     assert s["roofline"]["real_frac"] < s["roofline"]["frac"] and s["roofline"]["real_frac"] < s["roofline"]["8d_frac"]
