@@ -269,7 +269,7 @@ def prune():
 # the shapes the GPU test tier specialises at run time (tests/test_hip_parity.py, test_adjoint.py, test_hip_layouts.py,
 # test_dk_tape.py, test_gpu_property.py, the golden fixtures): `python -m metran_amd.jit --tests` prebuilds them on the build
 # machine so that the GPU box spends its minutes on kernels, not on hipcc
-TEST_SHAPES = [(7, 2), (11, 3), (14, 2), (20, 2), (16, 2), (32, 1), (48, 3), (17, 1), (17, 3), (20, 4), (11, 6), (12, 3), (9, 2)]
+TEST_SHAPES = [(7, 2), (11, 3), (14, 2), (20, 2), (16, 2), (32, 1), (48, 3), (17, 1), (17, 3), (20, 4), (11, 6), (12, 3), (9, 2), (19, 2)]
 
 
 if __name__ == "__main__":
