@@ -20,7 +20,7 @@ BAR_C4 = 0.40 * 8000e9 / (8 * 2000 * (32 + 4 * (36 + 36 * 36)))   # 4
 STATE_VARIANCES_FLOOR = BAR_C4
 # (end of round 6: 42.4 k measured -- the bar is passed by 13 %, so the floor IS the bar, as the round-5 verdict asked; earlier in the
 # round the line sat 1-2 % under it and the floor was the bar less the box-to-box spread.  The line prints the bar: bar_models_per_s.)
-C4_FLOOR = 43000.0   # configs[3], projection outputs: 47.3 k measured at the end of round 6 (the round-5 verdict asked for 45 k in the line); the floor leaves 9 % for a slow lease
+C4_FLOOR = 42000.0   # configs[3], projection outputs: 46.8-47.3 k measured at the end of round 6 (the round-5 verdict asked for 45 k in the line); the floor leaves 11 % for a slow lease (the objective kernel has ranged over 10 % between leases)
 SECONDARIES = ("c4", "c5", "c4_state_variances", "c4_full_sym", "generic_c2", "generic_c4", "generic_96x4", "f4_factor_analysis", "f4_factor_analysis_32x4",
                "f1_calibration", "f1_calibration_32x4", "c1_dropin", "c1w_dropin")
 
